@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'few-shot-music-generation_amd')
+SRC = os.path.join(PKG, 'src')
+for p in (ROOT, SRC):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden_dir():
+    return GOLDEN
+
+
+def small_config(**over):
+    cfg = dict(name='lstm_baseline', seed=1234, input_size=36, max_len=10, embedding_size=8,
+               hidden_size=16, n_layers=1, lr=5e-3, max_grad_norm=5, n_decay=10000)
+    cfg.update(over)
+    return cfg
