@@ -1,0 +1,384 @@
+// HBM-bound and small kernels of the step: token staging, softmax cross-entropy rows,
+// deterministic reductions, embedding-gradient segmented sum, global-norm + TF-style Adam,
+// parameter init and the greedy-decode GEMVs.  wave64 everywhere; reductions use
+// __shfl_xor over 64 lanes.
+#include "fsmg_kernels.h"
+
+namespace fsmg {
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- token prep (K0)
+// Reference: convert_tokens_to_input_and_target + concat (src/models/base_model.py:63-86,
+// src/models/lstm_baseline.py:91-96).  One thread per (sequence b, step t): coalesced reads
+// of the [nseq][T] token rows, time-major writes.
+__global__ void k_token_prep(const int* __restrict__ support, int n_support, const int* __restrict__ query,
+                             int n_query, int T, int vocab, int start_word, int* __restrict__ X,
+                             int* __restrict__ Y, int* __restrict__ err_flag) {
+    const int B = n_support + n_query;
+    const long long total = (long long)B * T;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / T), t = (int)(i % T);
+        const int* row = (b < n_support) ? support + (long long)b * T : query + (long long)(b - n_support) * T;
+        int tok = row[t];
+        if (tok < 0 || tok >= vocab) {
+            atomicOr(err_flag, 1);
+            tok = min(max(tok, 0), vocab - 1);
+        }
+        Y[(long long)t * B + b] = tok;
+        if (t + 1 < T) X[(long long)(t + 1) * B + b] = tok;
+        if (t == 0) X[b] = start_word;
+    }
+}
+
+// ---------------------------------------------------------------- softmax cross entropy per row (K6)
+// One 256-thread block per logits row; pass 1 row max, pass 2 sum exp (second read is an L2 hit).
+__global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ logits, int ld, int n_vocab,
+                                                 const int* __restrict__ tgt, float* __restrict__ lse,
+                                                 float* __restrict__ ce) {
+    __shared__ float sh[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = logits + (long long)r * ld;
+    const int nv4 = n_vocab & ~3;
+    float m = -INFINITY;
+    for (int v = 4 * tid; v < nv4; v += 1024) {
+        const float4 x = *reinterpret_cast<const float4*>(row + v);
+        m = fmaxf(fmaxf(m, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
+    }
+    if (tid < n_vocab - nv4) m = fmaxf(m, row[nv4 + tid]);
+    m = wave_max(m);
+    if (lane == 0) sh[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    float s = 0.0f;
+    for (int v = 4 * tid; v < nv4; v += 1024) {
+        const float4 x = *reinterpret_cast<const float4*>(row + v);
+        s += (expf(x.x - m) + expf(x.y - m)) + (expf(x.z - m) + expf(x.w - m));
+    }
+    if (tid < n_vocab - nv4) s += expf(row[nv4 + tid] - m);
+    s = wave_sum(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const float l = m + logf((sh[0] + sh[1]) + (sh[2] + sh[3]));
+        lse[r] = l;
+        ce[r] = l - row[tgt[r]];
+    }
+}
+
+// out[g] = sum_{t, b in group g} ce[t*B+b] / (T*rpg + 1e-12), double accumulation, fixed order.
+__global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ ce, int T, int B, int rpg,
+                                                     float* __restrict__ out) {
+    __shared__ double sh[4];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = T * rpg;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const int t = i / rpg, b = g * rpg + i % rpg;
+        s += (double)ce[(long long)t * B + b];
+    }
+    s = wave_sum_d(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (tid == 0) out[g] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / ((double)n + 1e-12));
+}
+
+// ---------------------------------------------------------------- embedding gradient (K7 tail)
+// dEmb[tok] = sum of dX rows of every occurrence of tok, accumulated in increasing position
+// order by the block of the FIRST occurrence (owner computes: no atomics, deterministic).
+__global__ __launch_bounds__(256) void k_embed_grad(const int* __restrict__ X, int n, const float* __restrict__ dX,
+                                                    int Ep, float* __restrict__ dEmb) {
+    __shared__ unsigned long long mask[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tok = X[r];
+    // earlier duplicate? then another block owns this token
+    int dup = 0;
+    for (int i = tid; i < r; i += 256) dup |= (X[i] == tok);
+    if (__syncthreads_or(dup)) return;
+
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};       // columns tid, tid+256, ... (Ep <= 1024)
+    for (int base = r; base < n; base += 256) {
+        const int i = base + tid;
+        const bool hit = (i < n) && (X[i] == tok);
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) mask[wave] = bal;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned long long mk = mask[w];
+            while (mk) {
+                const int bit = __ffsll((long long)mk) - 1;
+                mk &= mk - 1;
+                const float* src = dX + (long long)(base + 64 * w + bit) * Ep;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (tid + 256 * c < Ep) acc[c] += src[tid + 256 * c];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (tid + 256 * c < Ep) dEmb[(long long)tok * Ep + tid + 256 * c] = acc[c];
+}
+
+// ---------------------------------------------------------------- global norm + Adam (K8 + K9)
+constexpr int SQ_CHUNK = 256 * 16;   // elements per block
+__global__ __launch_bounds__(256) void k_sqnorm_partials(const float* __restrict__ x, long long n,
+                                                         double* __restrict__ partials) {
+    __shared__ double sh[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = (long long)blockIdx.x * SQ_CHUNK;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long idx = base + 4 * (tid + 256 * i);
+        if (idx + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + idx);
+            s += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        } else {
+            for (long long j = idx; j < n && j < idx + 4; ++j) s += (double)x[j] * x[j];
+        }
+    }
+    s = wave_sum_d(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (tid == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// clip_by_global_norm + exponential_decay + TF AdamOptimizer (reference
+// src/models/lstm_baseline.py:77-87; SURVEY.md A.4: epsilon added to the un-corrected sqrt(v)).
+// Every block re-derives the scalars from the same partials in the same order, so all blocks
+// (and all ranks of an episode-parallel job) use bit-identical alpha and scale.
+__global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
+    __shared__ double sh[4];
+    __shared__ float s_scale, s_alpha;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;
+    for (int i = tid; i < a.n_partials; i += 256) s += a.partials[i];
+    s = wave_sum_d(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double sq = ((sh[0] + sh[1]) + (sh[2] + sh[3])) * (double)a.grad_scale * (double)a.grad_scale;
+        if (a.use_slices) sq += (double)a.tail[0] * (double)a.grad_scale * (double)a.grad_scale;
+        const double gnorm = sqrt(sq);
+        const double clip = (double)a.clip;
+        s_scale = (float)(clip / fmax(gnorm, clip) * (double)a.grad_scale);
+        const long long step = *a.step;
+        const double t = (double)(step + 1);
+        const double lr_s = (double)a.lr * pow(0.5, (double)step / (double)a.n_decay);
+        s_alpha = (float)(lr_s * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
+        if (a.gnorm_out != nullptr && blockIdx.x == 0) *a.gnorm_out = (float)gnorm;
+    }
+    __syncthreads();
+    const float scale = s_scale, alpha = s_alpha;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const long long n4 = a.n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < n4; i += (long long)gridDim.x * 256) {
+        float4 g = reinterpret_cast<const float4*>(a.g)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+#define FSMG_ADAM1(c)                                         \
+        {                                                     \
+            const float gc = g.c * scale;                     \
+            m.c = b1 * m.c + (1.0f - b1) * gc;                \
+            v.c = b2 * v.c + (1.0f - b2) * gc * gc;           \
+            p.c = p.c - alpha * m.c / (sqrtf(v.c) + eps);     \
+        }
+        FSMG_ADAM1(x) FSMG_ADAM1(y) FSMG_ADAM1(z) FSMG_ADAM1(w)
+#undef FSMG_ADAM1
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+        reinterpret_cast<float4*>(a.p)[i] = p;
+    }
+}
+
+__global__ void k_step_increment(long long* step, const float* loss_src, float loss_scale, float* ring,
+                                 int ring_cap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const long long s = *step;
+        if (ring != nullptr && loss_src != nullptr) ring[s % ring_cap] = *loss_src * loss_scale;
+        *step = s + 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partials, int n, float* dst) {
+    __shared__ double sh[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += partials[i];
+    s = wave_sum_d(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (tid == 0) dst[0] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
+// ---------------------------------------------------------------- greedy decode (K10)
+// One cell step for one sequence: z = x*Kx + h*Kh + b over packed gate columns; block nb owns
+// units 4nb..4nb+3 (16 packed columns); 256 threads split the (in + Hp) reduction.
+__global__ __launch_bounds__(256) void k_decode_cell(const float* __restrict__ Kx, int in_dim,
+                                                     const float* __restrict__ Kh, const float* __restrict__ bias,
+                                                     const float* __restrict__ x, const float* __restrict__ h_in,
+                                                     float* __restrict__ h_out, float* __restrict__ c, int Hp) {
+    __shared__ float part[16][17];
+    const int nb = blockIdx.x, tid = threadIdx.x;
+    const int col = tid & 15, slice = tid >> 4;         // 16 k-slices x 16 columns
+    const int G4 = 4 * Hp;
+    float s = 0.0f;
+    for (int k = slice; k < in_dim; k += 16) s += x[k] * Kx[(long long)k * G4 + 16 * nb + col];
+    for (int k = slice; k < Hp; k += 16) s += h_in[k] * Kh[(long long)k * G4 + 16 * nb + col];
+    part[slice][col] = s;
+    __syncthreads();
+    if (tid < 4) {
+        float zg[4];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const int cc = 4 * gi + tid;
+            float t = bias[16 * nb + cc];
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) t += part[sl][cc];
+            zg[gi] = t;
+        }
+        const int u = 4 * nb + tid;
+        const float si = 1.0f / (1.0f + expf(-zg[0])), tj = tanhf(zg[1]);
+        const float sf = 1.0f / (1.0f + expf(-(zg[2] + 1.0f))), so = 1.0f / (1.0f + expf(-zg[3]));
+        const float cn = c[u] * sf + si * tj;
+        c[u] = cn;
+        h_out[u] = tanhf(cn) * so;
+    }
+}
+
+// logits = h*W + b over n_vocab columns, argmax (lowest index on ties, like np.argmax).
+// Stage 1: each block handles 256 columns -> (max, idx) per block; stage 2: one block reduces.
+__global__ __launch_bounds__(256) void k_decode_logits(const float* __restrict__ W, int ldw,
+                                                       const float* __restrict__ bias, const float* __restrict__ h,
+                                                       int Hp, int n_vocab, float* __restrict__ blk_max,
+                                                       int* __restrict__ blk_idx) {
+    __shared__ float smax[256];
+    __shared__ int sidx[256];
+    const int tid = threadIdx.x, v = blockIdx.x * 256 + tid;
+    float s = -INFINITY;
+    if (v < n_vocab) {
+        s = bias[v];
+        for (int k = 0; k < Hp; ++k) s += h[k] * W[(long long)k * ldw + v];
+    }
+    smax[tid] = s; sidx[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float b = smax[tid + o];
+            const int bi = sidx[tid + o];
+            if (b > smax[tid] || (b == smax[tid] && bi < sidx[tid])) { smax[tid] = b; sidx[tid] = bi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { blk_max[blockIdx.x] = smax[0]; blk_idx[blockIdx.x] = sidx[0]; }
+}
+__global__ void k_decode_pick(const float* blk_max, const int* blk_idx, int nblk, int* out_token) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float best = blk_max[0]; int bi = blk_idx[0];
+        for (int i = 1; i < nblk; ++i)
+            if (blk_max[i] > best || (blk_max[i] == best && blk_idx[i] < bi)) { best = blk_max[i]; bi = blk_idx[i]; }
+        *out_token = bi;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, const int* query, int n_query,
+                             int T, int vocab, int start_word, int* X, int* Y, int* err_flag) {
+    const long long total = (long long)(n_support + n_query) * T;
+    if (total <= 0) return hipSuccess;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_token_prep, dim3(blocks), dim3(256), 0, s, support, n_support, query, n_query, T, vocab,
+                       start_word, X, Y, err_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt,
+                          float* lse, float* ce) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ce_rows, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce);
+    return hipGetLastError();
+}
+
+hipError_t launch_loss_reduce(hipStream_t s, const float* ce, int T, int B, int rows_per_group, int ngroups,
+                              float* out) {
+    hipLaunchKernelGGL(k_loss_reduce, dim3(ngroups), dim3(256), 0, s, ce, T, B, rows_per_group, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX, int Ep, float* dEmb) {
+    if (n <= 0) return hipSuccess;
+    if (Ep > 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_embed_grad, dim3(n), dim3(256), 0, s, X, n, dX, Ep, dEmb);
+    return hipGetLastError();
+}
+
+int sqnorm_blocks(long long n) { return (int)((n + SQ_CHUNK - 1) / SQ_CHUNK); }
+
+hipError_t launch_sqnorm_partials(hipStream_t s, const float* x, long long n, double* partials) {
+    const int nb = sqnorm_blocks(n);
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sqnorm_partials, dim3(nb), dim3(256), 0, s, x, n, partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_adam_update(hipStream_t s, const UpdateArgs& a) {
+    long long n4 = a.n >> 2;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_adam_update, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_step_increment(hipStream_t s, long long* step, const float* loss_src, float loss_scale,
+                                 float* loss_ring, int ring_cap) {
+    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(64), 0, s, step, loss_src, loss_scale, loss_ring, ring_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partials, n, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_cell(hipStream_t s, const float* Kx, int in_dim, const float* Kh, const float* bias,
+                              const float* x, const float* h_in, float* h_out, float* c, int Hp) {
+    // h_in is read by every block while every block writes its units of h_out: they must differ
+    hipLaunchKernelGGL(k_decode_cell, dim3(Hp / 4), dim3(256), 0, s, Kx, in_dim, Kh, bias, x, h_in, h_out, c, Hp);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_argmax(hipStream_t s, const float* W, int ldw, const float* bias, const float* h,
+                                int Hp, int n_vocab, int* out_token, float* scratch) {
+    const int nblk = (n_vocab + 255) / 256;
+    float* blk_max = scratch;
+    int* blk_idx = reinterpret_cast<int*>(scratch + nblk);
+    hipLaunchKernelGGL(k_decode_logits, dim3(nblk), dim3(256), 0, s, W, ldw, bias, h, Hp, n_vocab, blk_max, blk_idx);
+    hipLaunchKernelGGL(k_decode_pick, dim3(1), dim3(64), 0, s, blk_max, blk_idx, nblk, out_token);
+    return hipGetLastError();
+}
+
+}  // namespace fsmg

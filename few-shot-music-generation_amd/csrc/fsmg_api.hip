@@ -1,0 +1,855 @@
+// C-ABI of libfsmg (include/fsmg.h): model handle, HBM layout, step orchestration.
+// Host-side C++ only; every kernel lives in gemm.hip / lstm_step.hip / elementwise.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <new>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fsmg.h"
+#include "fsmg_kernels.h"
+
+using namespace fsmg;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+constexpr int RING_CAP = 1024;
+constexpr int64_t FLAT_ALIGN = 64;   // floats (256 B)
+
+struct ParamDesc {
+    std::string name;
+    int64_t rows, cols;     // reference shape (cols == 1 for vectors)
+    int kind;               // 0 embedding, 1 kernel, 2 bias, 3 softmax_w, 4 softmax_b
+    int layer;
+    int64_t off, count;     // placement inside a flat buffer (floats)
+};
+
+struct TimerClass {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+}  // namespace
+
+struct fsmg_model {
+    fsmg_config cfg{};
+    int V = 0, V1 = 0, T = 0, E = 0, H = 0, L = 0, Ep = 0, Hp = 0, V1p = 0, G4 = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // ---- persistent state: flat fp32 buffers P (params), G (grads + tail), M, V (Adam)
+    char* state = nullptr;
+    bool own_state = false;
+    int64_t n_flat = 0;
+    float *P = nullptr, *G = nullptr, *M = nullptr, *Vv = nullptr;
+    std::vector<ParamDesc> params;
+    int64_t off_emb = 0, off_w = 0, off_d = 0;
+    std::vector<int64_t> off_kx, off_kh, off_b;
+    std::vector<int> in_dim;            // padded input width of each layer (Ep or Hp)
+
+    // ---- small device scalars
+    long long* d_step = nullptr;
+    int* d_err = nullptr;
+    float* d_ring = nullptr;
+    float* d_gnorm = nullptr;
+    float* d_eval = nullptr;            // per-episode eval NLLs
+    int eval_cap = 0;
+
+    // ---- activations (scratch), sized for Bcap sequences
+    int Bcap = 0;
+    char* scratch = nullptr;
+    int* d_tok = nullptr; int *X = nullptr, *Y = nullptr;
+    std::vector<float*> Z, Hs, Cs;
+    float *dC = nullptr, *dH = nullptr, *logits = nullptr, *lse = nullptr, *ce = nullptr, *dXemb = nullptr;
+    double* partials = nullptr;
+    int partials_cap = 0;
+    // decode
+    float* dec = nullptr; int* dec_tok = nullptr;
+
+    int lastB = 0;
+    bool have_grads = false;
+    std::string err;
+    bool timing = false;
+    std::string timing_only;
+    std::map<std::string, TimerClass> timers;
+};
+
+namespace {
+
+int fail(fsmg_model* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCK(h, call)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(h, FSMG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+struct ScopedTimer {
+    fsmg_model* h; TimerClass* tc = nullptr; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(fsmg_model* h_, const char* cls) : h(h_) {
+        if (!h->timing) return;
+        if (!h->timing_only.empty() && h->timing_only != cls) return;
+        tc = &h->timers[cls];
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { tc = nullptr; return; }
+        hipEventRecord(a, h->stream);
+    }
+    ~ScopedTimer() {
+        if (!tc) return;
+        hipEventRecord(b, h->stream);
+        tc->pending.emplace_back(a, b);
+    }
+};
+
+void drain_timers(fsmg_model* h) {
+    hipStreamSynchronize(h->stream);
+    for (auto& kv : h->timers) {
+        for (auto& pr : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                kv.second.total_ms += ms;
+                kv.second.launches += 1;
+            }
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+// ------------------------------------------------------------------ layout
+void compute_dims(const fsmg_config& c, fsmg_model* m) {
+    m->V = c.input_size; m->V1 = c.input_size + 1; m->T = c.max_len; m->E = c.embedding_size;
+    m->H = c.hidden_size; m->L = c.n_layers;
+    m->Ep = (int)round_up(m->E, 16);
+    m->Hp = (int)round_up(m->H, 16);
+    m->V1p = (int)round_up(m->V1, 4);
+    m->G4 = 4 * m->Hp;
+}
+
+// Flat order: embedding | per layer: Kx (in x 4Hp), Kh (Hp x 4Hp) [contiguous = padded `kernel`], bias | softmax_w | softmax_b
+int64_t build_layout(fsmg_model* m) {
+    int64_t off = 0;
+    auto place = [&](int64_t count) { int64_t o = off; off = round_up(off + count, FLAT_ALIGN); return o; };
+    m->params.clear(); m->off_kx.clear(); m->off_kh.clear(); m->off_b.clear(); m->in_dim.clear();
+    m->off_emb = place((int64_t)m->V1 * m->Ep);
+    m->params.push_back({"embedding", m->V1, m->E, 0, 0, m->off_emb, (int64_t)m->V1 * m->Ep});
+    for (int l = 0; l < m->L; ++l) {
+        const int in_p = l == 0 ? m->Ep : m->Hp, in_r = l == 0 ? m->E : m->H;
+        m->in_dim.push_back(in_p);
+        const int64_t kcount = (int64_t)(in_p + m->Hp) * m->G4;
+        const int64_t ko = place(kcount);
+        m->off_kx.push_back(ko);
+        m->off_kh.push_back(ko + (int64_t)in_p * m->G4);
+        m->params.push_back({"kernel_" + std::to_string(l), in_r + m->H, 4 * m->H, 1, l, ko, kcount});
+        const int64_t bo = place(m->G4);
+        m->off_b.push_back(bo);
+        m->params.push_back({"bias_" + std::to_string(l), 4 * m->H, 1, 2, l, bo, m->G4});
+    }
+    m->off_w = place((int64_t)m->Hp * m->V1p);
+    m->params.push_back({"softmax_w", m->H, m->V1, 3, 0, m->off_w, (int64_t)m->Hp * m->V1p});
+    m->off_d = place(m->V1p);
+    m->params.push_back({"softmax_b", m->V1, 1, 4, 0, m->off_d, m->V1p});
+    return off;
+}
+
+int64_t state_bytes_for(int64_t n_flat) { return (4 * n_flat + FSMG_GRAD_TAIL) * (int64_t)sizeof(float); }
+
+const ParamDesc* find_param(fsmg_model* h, const char* name) {
+    for (auto& p : h->params) if (p.name == name) return &p;
+    return nullptr;
+}
+
+// packed gate column of (unit u, gate gi)
+inline int64_t pcol(int u, int gi) { return 16 * (int64_t)(u >> 2) + 4 * gi + (u & 3); }
+
+// reference-layout host tensor -> internal padded segment (zero padded), and back
+void pack_param(const fsmg_model* m, const ParamDesc& p, const float* ref, float* seg) {
+    std::memset(seg, 0, sizeof(float) * p.count);
+    const int H = m->H, G4 = m->G4;
+    switch (p.kind) {
+    case 0:
+        for (int64_t r = 0; r < m->V1; ++r) std::memcpy(seg + r * m->Ep, ref + r * m->E, sizeof(float) * m->E);
+        break;
+    case 1: {
+        const int in_r = p.layer == 0 ? m->E : m->H, in_p = m->in_dim[p.layer];
+        for (int64_t r = 0; r < in_r + H; ++r) {
+            const int64_t ir = r < in_r ? r : in_p + (r - in_r);
+            for (int gi = 0; gi < 4; ++gi)
+                for (int u = 0; u < H; ++u) seg[ir * G4 + pcol(u, gi)] = ref[r * 4 * H + (int64_t)gi * H + u];
+        }
+        break;
+    }
+    case 2:
+        for (int gi = 0; gi < 4; ++gi)
+            for (int u = 0; u < H; ++u) seg[pcol(u, gi)] = ref[(int64_t)gi * H + u];
+        break;
+    case 3:
+        for (int64_t r = 0; r < H; ++r) std::memcpy(seg + r * m->V1p, ref + r * m->V1, sizeof(float) * m->V1);
+        break;
+    case 4:
+        std::memcpy(seg, ref, sizeof(float) * m->V1);
+        break;
+    }
+}
+
+void unpack_param(const fsmg_model* m, const ParamDesc& p, const float* seg, float* ref) {
+    const int H = m->H, G4 = m->G4;
+    switch (p.kind) {
+    case 0:
+        for (int64_t r = 0; r < m->V1; ++r) std::memcpy(ref + r * m->E, seg + r * m->Ep, sizeof(float) * m->E);
+        break;
+    case 1: {
+        const int in_r = p.layer == 0 ? m->E : m->H, in_p = m->in_dim[p.layer];
+        for (int64_t r = 0; r < in_r + H; ++r) {
+            const int64_t ir = r < in_r ? r : in_p + (r - in_r);
+            for (int gi = 0; gi < 4; ++gi)
+                for (int u = 0; u < H; ++u) ref[r * 4 * H + (int64_t)gi * H + u] = seg[ir * G4 + pcol(u, gi)];
+        }
+        break;
+    }
+    case 2:
+        for (int gi = 0; gi < 4; ++gi)
+            for (int u = 0; u < H; ++u) ref[(int64_t)gi * H + u] = seg[pcol(u, gi)];
+        break;
+    case 3:
+        for (int64_t r = 0; r < H; ++r) std::memcpy(ref + r * m->V1, seg + r * m->V1p, sizeof(float) * m->V1);
+        break;
+    case 4:
+        std::memcpy(ref, seg, sizeof(float) * m->V1);
+        break;
+    }
+}
+
+int upload_tensor(fsmg_model* h, float* flat, const char* name, const float* host, int64_t count) {
+    const ParamDesc* p = find_param(h, name);
+    if (!p) return fail(h, FSMG_ERR_NAME, std::string("unknown parameter '") + name + "'");
+    if (count != p->rows * p->cols) return fail(h, FSMG_ERR_SIZE, std::string("size mismatch for '") + name + "'");
+    std::vector<float> seg(p->count);
+    pack_param(h, *p, host, seg.data());
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipMemcpy(flat + p->off, seg.data(), sizeof(float) * p->count, hipMemcpyHostToDevice));
+    return FSMG_OK;
+}
+
+int download_tensor(fsmg_model* h, const float* flat, const char* name, float* host, int64_t count) {
+    const ParamDesc* p = find_param(h, name);
+    if (!p) return fail(h, FSMG_ERR_NAME, std::string("unknown parameter '") + name + "'");
+    if (count != p->rows * p->cols) return fail(h, FSMG_ERR_SIZE, std::string("size mismatch for '") + name + "'");
+    std::vector<float> seg(p->count);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipMemcpy(seg.data(), flat + p->off, sizeof(float) * p->count, hipMemcpyDeviceToHost));
+    unpack_param(h, *p, seg.data(), host);
+    return FSMG_OK;
+}
+
+// ------------------------------------------------------------------ scratch
+int ensure_scratch(fsmg_model* h, int B) {
+    if (B <= h->Bcap) return FSMG_OK;
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->scratch) { HIPCK(h, hipFree(h->scratch)); h->scratch = nullptr; }
+    const int64_t T = h->T, Hp = h->Hp, G4 = h->G4, rows = T * (int64_t)B;
+    int64_t off = 0;
+    auto place = [&](int64_t bytes) { int64_t o = off; off = round_up(off + bytes, 256); return o; };
+    const int64_t o_tok = place(4 * rows), o_x = place(4 * rows), o_y = place(4 * rows);
+    std::vector<int64_t> o_z(h->L), o_h(h->L), o_c(h->L);
+    for (int l = 0; l < h->L; ++l) {
+        o_z[l] = place(4 * rows * G4);
+        o_h[l] = place(4 * (T + 1) * B * Hp);
+        o_c[l] = place(4 * (T + 1) * B * Hp);
+    }
+    const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
+    const int64_t o_lg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
+    const int64_t o_dx = place(4 * rows * h->Ep);
+    h->partials_cap = sqnorm_blocks(h->n_flat) + sqnorm_blocks(rows * h->Ep) + 8;
+    const int64_t o_part = place(8 * (int64_t)h->partials_cap);
+    hipError_t e = hipMalloc((void**)&h->scratch, off);
+    if (e != hipSuccess) {
+        h->Bcap = 0;
+        return fail(h, FSMG_ERR_NOMEM, "hipMalloc of " + std::to_string(off) + " activation bytes failed: " +
+                                           hipGetErrorString(e));
+    }
+    char* s = h->scratch;
+    h->d_tok = (int*)(s + o_tok); h->X = (int*)(s + o_x); h->Y = (int*)(s + o_y);
+    h->Z.assign(h->L, nullptr); h->Hs.assign(h->L, nullptr); h->Cs.assign(h->L, nullptr);
+    for (int l = 0; l < h->L; ++l) {
+        h->Z[l] = (float*)(s + o_z[l]); h->Hs[l] = (float*)(s + o_h[l]); h->Cs[l] = (float*)(s + o_c[l]);
+    }
+    h->dC = (float*)(s + o_dc); h->dH = (float*)(s + o_dh); h->logits = (float*)(s + o_lg);
+    h->lse = (float*)(s + o_lse); h->ce = (float*)(s + o_ce); h->dXemb = (float*)(s + o_dx);
+    h->partials = (double*)(s + o_part);
+    h->Bcap = B;
+    return FSMG_OK;
+}
+
+// ------------------------------------------------------------------ the step pieces
+int stage_tokens(fsmg_model* h, const int32_t* support, int n_sup, const int32_t* query, int n_qry, int on_device) {
+    const int T = h->T;
+    const int* d_sup = support; const int* d_qry = query;
+    if (!on_device) {
+        if (n_sup > 0) HIPCK(h, hipMemcpyAsync(h->d_tok, support, sizeof(int) * (size_t)n_sup * T, hipMemcpyHostToDevice, h->stream));
+        if (n_qry > 0) HIPCK(h, hipMemcpyAsync(h->d_tok + (size_t)n_sup * T, query, sizeof(int) * (size_t)n_qry * T, hipMemcpyHostToDevice, h->stream));
+        d_sup = h->d_tok; d_qry = h->d_tok + (size_t)n_sup * T;
+    }
+    HIPCK(h, launch_token_prep(h->stream, d_sup, n_sup, d_qry, n_qry, T, h->V, h->V, h->X, h->Y, h->d_err));
+    return FSMG_OK;
+}
+
+int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_out) {
+    const int T = h->T, Hp = h->Hp, G4 = h->G4;
+    const int64_t rows = (int64_t)T * B;
+    hipStream_t s = h->stream;
+    for (int l = 0; l < h->L; ++l) {
+        HIPCK(h, hipMemsetAsync(h->Hs[l], 0, sizeof(float) * (size_t)B * Hp, s));
+        HIPCK(h, hipMemsetAsync(h->Cs[l], 0, sizeof(float) * (size_t)B * Hp, s));
+        {
+            ScopedTimer tm(h, "gemm_zx");
+            GemmArgs g{};
+            if (l == 0) { g.A = h->P + h->off_emb; g.lda = h->Ep; g.gather = h->X; g.K = h->Ep; }
+            else { g.A = h->Hs[l - 1] + (size_t)B * Hp; g.lda = Hp; g.K = Hp; }
+            g.B = h->P + h->off_kx[l]; g.ldb = G4;
+            g.C = h->Z[l]; g.ldc = G4; g.M = (int)rows; g.N = G4;
+            g.bias = h->P + h->off_b[l]; g.ksplit = 1;
+            HIPCK(h, launch_gemm(s, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
+        }
+        {
+            ScopedTimer tm(h, "lstm_fwd");
+            for (int t = 0; t < T; ++t) {
+                LstmFwdArgs a{};
+                a.Kh = h->P + h->off_kh[l];
+                a.h_prev = h->Hs[l] + (size_t)t * B * Hp;
+                a.z = h->Z[l] + (size_t)t * B * G4;
+                a.c_prev = h->Cs[l] + (size_t)t * B * Hp;
+                a.c_next = h->Cs[l] + (size_t)(t + 1) * B * Hp;
+                a.h_next = h->Hs[l] + (size_t)(t + 1) * B * Hp;
+                a.B = B; a.Hp = Hp;
+                HIPCK(h, launch_lstm_fwd_step(s, a));
+            }
+        }
+    }
+    {
+        ScopedTimer tm(h, "gemm_logits");
+        GemmArgs g{};
+        g.A = h->Hs[h->L - 1] + (size_t)B * Hp; g.lda = Hp;
+        g.B = h->P + h->off_w; g.ldb = h->V1p;
+        g.C = h->logits; g.ldc = h->V1p; g.M = (int)rows; g.N = h->V1p; g.K = Hp;
+        g.bias = h->P + h->off_d; g.ksplit = 1;
+        HIPCK(h, launch_gemm(s, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
+    }
+    {
+        ScopedTimer tm(h, "ce");
+        HIPCK(h, launch_ce_rows(s, h->logits, h->V1p, (int)rows, h->V1, h->Y, h->lse, h->ce));
+        HIPCK(h, launch_loss_reduce(s, h->ce, T, B, rows_per_group, ngroups, loss_out));
+    }
+    h->lastB = B;
+    return FSMG_OK;
+}
+
+int backward(fsmg_model* h, int B) {
+    const int T = h->T, Hp = h->Hp, G4 = h->G4;
+    const int64_t rows = (int64_t)T * B;
+    hipStream_t s = h->stream;
+    const float inv_n = (float)(1.0 / ((double)rows + 1e-12));
+    float* Hout = h->Hs[h->L - 1] + (size_t)B * Hp;
+    HIPCK(h, hipMemsetAsync(h->G + h->off_emb, 0, sizeof(float) * (size_t)h->V1 * h->Ep, s));
+    {
+        ScopedTimer tm(h, "gemm_dhout");     // dH = dlogits * W^T
+        GemmArgs g{};
+        g.A = h->logits; g.lda = h->V1p; g.B = h->P + h->off_w; g.ldb = h->V1p;
+        g.C = h->dH; g.ldc = Hp; g.M = (int)rows; g.N = Hp; g.K = h->V1p;
+        g.lse = h->lse; g.tgt = h->Y; g.inv_n = inv_n; g.n_vocab = h->V1; g.ksplit = 1;
+        HIPCK(h, launch_gemm(s, OP_KC, OP_KC, TR_DLOGITS, TR_NONE, g));
+    }
+    {
+        ScopedTimer tm(h, "gemm_dw");        // dW = Hout^T * dlogits, dd = colsum(dlogits)
+        GemmArgs g{};
+        g.A = Hout; g.lda = Hp; g.B = h->logits; g.ldb = h->V1p;
+        g.C = h->G + h->off_w; g.ldc = h->V1p; g.M = Hp; g.N = h->V1p; g.K = (int)rows;
+        g.lse = h->lse; g.tgt = h->Y; g.inv_n = inv_n; g.n_vocab = h->V1;
+        g.colsum = h->G + h->off_d; g.ksplit = 1;
+        HIPCK(h, launch_gemm(s, OP_XC, OP_XC, TR_NONE, TR_DLOGITS, g));
+    }
+    for (int l = h->L - 1; l >= 0; --l) {
+        HIPCK(h, hipMemsetAsync(h->dC, 0, sizeof(float) * (size_t)B * Hp, s));
+        {
+            ScopedTimer tm(h, "lstm_bwd");
+            for (int t = T - 1; t >= 0; --t) {
+                LstmBwdArgs a{};
+                a.Kh = h->P + h->off_kh[l];
+                a.dz_next = (t + 1 < T) ? h->Z[l] + (size_t)(t + 1) * B * G4 : nullptr;
+                a.gates = h->Z[l] + (size_t)t * B * G4;
+                a.c_t = h->Cs[l] + (size_t)(t + 1) * B * Hp;
+                a.c_prev = h->Cs[l] + (size_t)t * B * Hp;
+                a.dc = h->dC;
+                a.dh_top = h->dH + (size_t)t * B * Hp;
+                a.B = B; a.Hp = Hp;
+                HIPCK(h, launch_lstm_bwd_step(s, a));
+            }
+        }
+        const int in_p = h->in_dim[l];
+        {
+            ScopedTimer tm(h, "gemm_dk");
+            GemmArgs g{};                     // dKh = Hprev^T * dZ, db = colsum(dZ)
+            g.A = h->Hs[l]; g.lda = Hp; g.B = h->Z[l]; g.ldb = G4;
+            g.C = h->G + h->off_kh[l]; g.ldc = G4; g.M = Hp; g.N = G4; g.K = (int)rows;
+            g.colsum = h->G + h->off_b[l]; g.ksplit = 1;
+            HIPCK(h, launch_gemm(s, OP_XC, OP_XC, TR_NONE, TR_NONE, g));
+            GemmArgs k{};                     // dKx = in^T * dZ
+            if (l == 0) { k.A = h->P + h->off_emb; k.lda = h->Ep; k.gather = h->X; }
+            else { k.A = h->Hs[l - 1] + (size_t)B * Hp; k.lda = Hp; }
+            k.B = h->Z[l]; k.ldb = G4; k.C = h->G + h->off_kx[l]; k.ldc = G4;
+            k.M = in_p; k.N = G4; k.K = (int)rows; k.ksplit = 1;
+            HIPCK(h, launch_gemm(s, OP_XC, OP_XC, TR_NONE, TR_NONE, k));
+        }
+        {
+            ScopedTimer tm(h, "gemm_dx");     // d_in = dZ * Kx^T
+            GemmArgs g{};
+            g.A = h->Z[l]; g.lda = G4; g.B = h->P + h->off_kx[l]; g.ldb = G4;
+            g.C = (l == 0) ? h->dXemb : h->dH; g.ldc = in_p;
+            g.M = (int)rows; g.N = in_p; g.K = G4; g.ksplit = 1;
+            HIPCK(h, launch_gemm(s, OP_KC, OP_KC, TR_NONE, TR_NONE, g));
+        }
+    }
+    {
+        ScopedTimer tm(h, "embed_grad");
+        HIPCK(h, launch_embed_grad(s, h->X, (int)rows, h->dXemb, h->Ep, h->G + h->off_emb));
+        const int nb = sqnorm_blocks(rows * h->Ep);
+        HIPCK(h, launch_sqnorm_partials(s, h->dXemb, rows * h->Ep, h->partials));
+        HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0));
+    }
+    h->have_grads = true;
+    return FSMG_OK;
+}
+
+int apply_update(fsmg_model* h, float grad_scale) {
+    hipStream_t s = h->stream;
+    ScopedTimer tm(h, "update");
+    const bool slices = h->cfg.clip_norm_mode == FSMG_CLIP_TF1_SLICES;
+    const int64_t skip = slices ? round_up((int64_t)h->V1 * h->Ep, FLAT_ALIGN) : 0;   // embedding is the first segment
+    const int64_t n = h->n_flat - skip;
+    const int nb = sqnorm_blocks(n);
+    HIPCK(h, launch_sqnorm_partials(s, h->G + skip, n, h->partials));
+    UpdateArgs a{};
+    a.p = h->P; a.m = h->M; a.v = h->Vv; a.g = h->G; a.n = h->n_flat;
+    a.partials = h->partials; a.n_partials = nb; a.tail = h->G + h->n_flat; a.use_slices = slices ? 1 : 0;
+    a.grad_scale = grad_scale; a.lr = h->cfg.lr; a.n_decay = h->cfg.n_decay; a.clip = h->cfg.max_grad_norm;
+    a.step = h->d_step; a.gnorm_out = h->d_gnorm;
+    HIPCK(h, launch_adam_update(s, a));
+    HIPCK(h, launch_step_increment(s, h->d_step, h->G + h->n_flat + 1, grad_scale, h->d_ring, RING_CAP));
+    h->have_grads = false;
+    return FSMG_OK;
+}
+
+int check_tokens_and_read(fsmg_model* h, const float* d_src, float scale, float* host_out, int n) {
+    // one synchronising readback: loss value(s) + the token-range flag
+    std::vector<float> tmp(n);
+    int err = 0;
+    HIPCK(h, hipMemcpyAsync(tmp.data(), d_src, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (err) {
+        HIPCK(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
+        return fail(h, FSMG_ERR_TOKEN_RANGE, "token id outside [0, input_size)");
+    }
+    for (int i = 0; i < n; ++i) host_out[i] = tmp[i] * scale;
+    return FSMG_OK;
+}
+
+int validate_shape(fsmg_model* h, int N, int K, int Q) {
+    if (N <= 0 || K < 0 || Q < 0 || (int64_t)N * (K + Q) <= 0 || (int64_t)N * (K + Q) > (1 << 20))
+        return fail(h, FSMG_ERR_INVALID, "bad episode shape N/K/Q");
+    return FSMG_OK;
+}
+
+// host RNG for Glorot init: value depends on (seed, tensor index, logical element index) only
+inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+}  // namespace
+
+// =========================================================================== C ABI
+extern "C" {
+
+int fsmg_version(void) { return FSMG_VERSION; }
+
+const char* fsmg_last_error(fsmg_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+uint64_t fsmg_state_bytes(const fsmg_config* cfg) {
+    if (!cfg) return 0;
+    fsmg_model m;
+    compute_dims(*cfg, &m);
+    return (uint64_t)state_bytes_for(build_layout(&m));
+}
+
+int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
+    if (!cfg || !out) return fail(nullptr, FSMG_ERR_INVALID, "null config/out");
+    *out = nullptr;
+    if (cfg->input_size <= 0 || cfg->max_len <= 0 || cfg->embedding_size <= 0 || cfg->hidden_size <= 0 ||
+        cfg->n_layers <= 0 || cfg->n_layers > 16 || cfg->embedding_size > 1024 || !(cfg->n_decay > 0.f) ||
+        !(cfg->max_grad_norm > 0.f))
+        return fail(nullptr, FSMG_ERR_INVALID, "config out of range (sizes must be > 0, embedding_size <= 1024, n_layers <= 16)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, FSMG_ERR_NO_DEVICE, "no HIP device visible: libfsmg has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, FSMG_ERR_NO_DEVICE, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipSetDevice(cfg->device) != hipSuccess || hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+        return fail(nullptr, FSMG_ERR_NO_DEVICE, "cannot select HIP device");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, FSMG_ERR_NO_DEVICE, std::string("libfsmg is built for gfx950 only, device is ") + prop.gcnArchName);
+
+    fsmg_model* h = new (std::nothrow) fsmg_model();
+    if (!h) return fail(nullptr, FSMG_ERR_NOMEM, "host allocation failed");
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    compute_dims(*cfg, h);
+    h->n_flat = build_layout(h);
+    auto bail = [&](int code, const std::string& msg) { g_create_error = msg; fsmg_destroy(h); return code; };
+
+    if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(FSMG_ERR_HIP, "hipStreamCreate failed");
+        h->own_stream = true;
+    }
+    const int64_t sb = state_bytes_for(h->n_flat);
+    if (cfg->state_arena) {
+        if (cfg->state_arena_bytes < (uint64_t)sb || ((uintptr_t)cfg->state_arena & 255u))
+            return bail(FSMG_ERR_INVALID, "state_arena too small or not 256-byte aligned");
+        h->state = (char*)cfg->state_arena; h->own_state = false;
+    } else {
+        if (hipMalloc((void**)&h->state, sb) != hipSuccess) return bail(FSMG_ERR_NOMEM, "hipMalloc(state) failed");
+        h->own_state = true;
+    }
+    h->P = (float*)h->state; h->G = h->P + h->n_flat;          // G has n_flat + FSMG_GRAD_TAIL floats
+    h->M = h->G + h->n_flat + FSMG_GRAD_TAIL; h->Vv = h->M + h->n_flat;
+    if (hipMemsetAsync(h->state, 0, sb, h->stream) != hipSuccess) return bail(FSMG_ERR_HIP, "memset(state) failed");
+
+    char* small = nullptr;
+    const size_t small_bytes = 256 * 4 + sizeof(float) * RING_CAP;
+    if (hipMalloc((void**)&small, small_bytes) != hipSuccess) return bail(FSMG_ERR_NOMEM, "hipMalloc(scalars) failed");
+    hipMemsetAsync(small, 0, small_bytes, h->stream);
+    h->d_step = (long long*)small; h->d_err = (int*)(small + 256); h->d_gnorm = (float*)(small + 512);
+    h->d_ring = (float*)(small + 1024);
+
+    // decode scratch: per layer h ping/pong + c, plus x and argmax block scratch
+    {
+        const size_t nblk = (h->V1 + 255) / 256;
+        const size_t fl = (size_t)h->L * 3 * h->Hp + 2 * nblk + 64;
+        if (hipMalloc((void**)&h->dec, sizeof(float) * fl + 256) != hipSuccess) return bail(FSMG_ERR_NOMEM, "hipMalloc(decode) failed");
+        h->dec_tok = (int*)(h->dec + fl);
+    }
+    const int b0 = cfg->max_sequences > 0 ? cfg->max_sequences : 45;
+    if (ensure_scratch(h, b0) != FSMG_OK) { std::string e = h->err; return bail(FSMG_ERR_NOMEM, e); }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(FSMG_ERR_HIP, "stream sync failed");
+    *out = h;
+    return FSMG_OK;
+}
+
+int fsmg_destroy(fsmg_handle h) {
+    if (!h) return FSMG_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    drain_timers(h);
+    if (h->scratch) hipFree(h->scratch);
+    if (h->d_step) hipFree(h->d_step);
+    if (h->dec) hipFree(h->dec);
+    if (h->d_eval) hipFree(h->d_eval);
+    if (h->own_state && h->state) hipFree(h->state);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return FSMG_OK;
+}
+
+int fsmg_synchronize(fsmg_handle h) {
+    if (!h) return FSMG_ERR_INVALID;
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return FSMG_OK;
+}
+
+int fsmg_init_params(fsmg_handle h, uint64_t seed) {
+    if (!h) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    int idx = 0;
+    for (auto& p : h->params) {
+        const int64_t n = p.rows * p.cols;
+        std::vector<float> ref(n, 0.0f);
+        if (p.kind != 2) {                   // LSTM biases start at zero
+            const double fan_in = (double)p.rows, fan_out = p.cols == 1 ? (double)p.rows : (double)p.cols;
+            const float limit = (float)std::sqrt(6.0 / (fan_in + fan_out));
+            const uint64_t base = splitmix64(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(idx + 1)));
+            for (int64_t i = 0; i < n; ++i) {
+                const uint64_t r = splitmix64(base + (uint64_t)i);
+                const float u = (float)(((r >> 40) + 0.5) * (1.0 / 16777216.0));
+                ref[i] = (2.0f * u - 1.0f) * limit;
+            }
+        }
+        int rc = upload_tensor(h, h->P, p.name.c_str(), ref.data(), n);
+        if (rc != FSMG_OK) return rc;
+        ++idx;
+    }
+    HIPCK(h, hipMemsetAsync(h->M, 0, sizeof(float) * (size_t)h->n_flat, h->stream));
+    HIPCK(h, hipMemsetAsync(h->Vv, 0, sizeof(float) * (size_t)h->n_flat, h->stream));
+    HIPCK(h, hipMemsetAsync(h->d_step, 0, sizeof(long long), h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return FSMG_OK;
+}
+
+int fsmg_num_params(fsmg_handle h) { return h ? (int)h->params.size() : FSMG_ERR_INVALID; }
+
+int fsmg_param_info(fsmg_handle h, int idx, char* name, int name_cap, int64_t* rows, int64_t* cols) {
+    if (!h || idx < 0 || idx >= (int)h->params.size()) return FSMG_ERR_INVALID;
+    const ParamDesc& p = h->params[idx];
+    if (name && name_cap > 0) { std::strncpy(name, p.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (rows) *rows = p.rows;
+    if (cols) *cols = p.cols;
+    return FSMG_OK;
+}
+
+int fsmg_set_param(fsmg_handle h, const char* name, const float* host, int64_t count) {
+    if (!h || !name || !host) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    return upload_tensor(h, h->P, name, host, count);
+}
+int fsmg_get_param(fsmg_handle h, const char* name, float* host, int64_t count) {
+    if (!h || !name || !host) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    return download_tensor(h, h->P, name, host, count);
+}
+int fsmg_set_opt_state(fsmg_handle h, const char* name, const float* m, const float* v, int64_t count) {
+    if (!h || !name || !m || !v) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    int rc = upload_tensor(h, h->M, name, m, count);
+    return rc != FSMG_OK ? rc : upload_tensor(h, h->Vv, name, v, count);
+}
+int fsmg_get_opt_state(fsmg_handle h, const char* name, float* m, float* v, int64_t count) {
+    if (!h || !name || !m || !v) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    int rc = download_tensor(h, h->M, name, m, count);
+    return rc != FSMG_OK ? rc : download_tensor(h, h->Vv, name, v, count);
+}
+int fsmg_set_step(fsmg_handle h, int64_t global_step) {
+    if (!h || global_step < 0) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    long long v = global_step;
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipMemcpy(h->d_step, &v, sizeof(v), hipMemcpyHostToDevice));
+    return FSMG_OK;
+}
+int fsmg_get_step(fsmg_handle h, int64_t* global_step) {
+    if (!h || !global_step) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    long long v = 0;
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipMemcpy(&v, h->d_step, sizeof(v), hipMemcpyDeviceToHost));
+    *global_step = v;
+    return FSMG_OK;
+}
+int fsmg_get_grad(fsmg_handle h, const char* name, float* host, int64_t count) {
+    if (!h || !name || !host) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    return download_tensor(h, h->G, name, host, count);
+}
+
+int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K,
+                          int32_t Q, int32_t tokens_on_device) {
+    if (!h || !support || !query) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    int rc = validate_shape(h, N, K, Q);
+    if (rc != FSMG_OK) return rc;
+    const int B = N * (K + Q);
+    if ((rc = ensure_scratch(h, B)) != FSMG_OK) return rc;
+    if ((rc = stage_tokens(h, support, N * K, query, N * Q, tokens_on_device)) != FSMG_OK) return rc;
+    if ((rc = forward(h, B, B, 1, h->G + h->n_flat + 1)) != FSMG_OK) return rc;
+    return backward(h, B);
+}
+
+int fsmg_grad_buffer(fsmg_handle h, void** device_ptr, int64_t* count) {
+    if (!h || !device_ptr || !count) return FSMG_ERR_INVALID;
+    *device_ptr = h->G;
+    *count = h->n_flat + FSMG_GRAD_TAIL;
+    return FSMG_OK;
+}
+
+int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss) {
+    if (!h) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    if (!h->have_grads) return fail(h, FSMG_ERR_STATE, "fsmg_apply_update without a preceding fsmg_forward_backward");
+    if (!(grad_scale > 0.f)) return fail(h, FSMG_ERR_INVALID, "grad_scale must be > 0");
+    int rc = apply_update(h, grad_scale);
+    if (rc != FSMG_OK) return rc;
+    if (loss) return check_tokens_and_read(h, h->G + h->n_flat + 1, grad_scale, loss, 1);
+    return FSMG_OK;
+}
+
+int fsmg_train_step(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K, int32_t Q,
+                    int32_t tokens_on_device, float* loss) {
+    int rc = fsmg_forward_backward(h, support, query, N, K, Q, tokens_on_device);
+    if (rc != FSMG_OK) return rc;
+    return fsmg_apply_update(h, 1.0f, loss);
+}
+
+int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, int32_t N, int32_t Q,
+                    int32_t tokens_on_device, float* nll) {
+    if (!h || !queries || !nll || n_episodes <= 0) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    int rc = validate_shape(h, N, 0, Q);
+    if (rc != FSMG_OK) return rc;
+    const int per = N * Q;
+    if (per <= 0) return fail(h, FSMG_ERR_INVALID, "empty query set");
+    if ((rc = ensure_scratch(h, per)) != FSMG_OK) return rc;
+    const int chunk_eps = h->Bcap / per;
+    if (h->eval_cap < chunk_eps) {
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        if (h->d_eval) hipFree(h->d_eval);
+        HIPCK(h, hipMalloc((void**)&h->d_eval, sizeof(float) * chunk_eps));
+        h->eval_cap = chunk_eps;
+    }
+    for (int e0 = 0; e0 < n_episodes; e0 += chunk_eps) {
+        const int ne = std::min(chunk_eps, n_episodes - e0);
+        const int B = ne * per;
+        const int32_t* q = queries + (size_t)e0 * per * h->T;
+        if ((rc = stage_tokens(h, q, 0, q, B, tokens_on_device)) != FSMG_OK) return rc;
+        if ((rc = forward(h, B, per, ne, h->d_eval)) != FSMG_OK) return rc;
+        if ((rc = check_tokens_and_read(h, h->d_eval, 1.0f, nll + e0, ne)) != FSMG_OK) return rc;
+    }
+    return FSMG_OK;
+}
+
+int fsmg_eval_step(fsmg_handle h, const int32_t* query, int32_t N, int32_t Q, int32_t tokens_on_device, float* nll) {
+    return fsmg_eval_batch(h, query, 1, N, Q, tokens_on_device, nll);
+}
+
+int fsmg_sample(fsmg_handle h, int32_t num, int32_t* out_tokens) {
+    if (!h || num < 0 || (num > 0 && !out_tokens)) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    hipStream_t s = h->stream;
+    const int Hp = h->Hp, L = h->L;
+    float* hb = h->dec;                       // [L][2][Hp]
+    float* cb = h->dec + (size_t)L * 2 * Hp;  // [L][Hp]
+    float* arg_scratch = cb + (size_t)L * Hp;
+    HIPCK(h, hipMemsetAsync(h->dec, 0, sizeof(float) * (size_t)L * 3 * Hp, s));
+    std::vector<int> toks(num);
+    int word = h->V;                          // start word
+    int* d_hist = nullptr;
+    HIPCK(h, hipMalloc((void**)&d_hist, sizeof(int) * (size_t)(num + 1)));
+    HIPCK(h, hipMemcpyAsync(d_hist, &word, sizeof(int), hipMemcpyHostToDevice, s));
+    // greedy decode is a host loop in the reference too (one sess.run per token, lstm_baseline.py:142-154):
+    // the argmax token is read back each step because it selects the next embedding row.
+    for (int i = 0; i < num; ++i) {
+        const float* x = h->P + h->off_emb + (size_t)word * h->Ep;
+        const int pin = i & 1, pout = pin ^ 1;
+        for (int l = 0; l < L; ++l) {
+            float* h_in = hb + ((size_t)l * 2 + pin) * Hp;
+            float* h_out = hb + ((size_t)l * 2 + pout) * Hp;
+            hipError_t e = launch_decode_cell(s, h->P + h->off_kx[l], h->in_dim[l], h->P + h->off_kh[l],
+                                              h->P + h->off_b[l], x, h_in, h_out, cb + (size_t)l * Hp, Hp);
+            if (e != hipSuccess) { hipFree(d_hist); return fail(h, FSMG_ERR_HIP, hipGetErrorString(e)); }
+            x = h_out;
+        }
+        hipError_t e = launch_decode_argmax(s, h->P + h->off_w, h->V1p, h->P + h->off_d, x, Hp, h->V1,
+                                            d_hist + i + 1, arg_scratch);
+        if (e == hipSuccess) e = hipMemcpyAsync(&word, d_hist + i + 1, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { hipFree(d_hist); return fail(h, FSMG_ERR_HIP, hipGetErrorString(e)); }
+        toks[i] = word;
+    }
+    hipFree(d_hist);
+    for (int i = 0; i < num; ++i) out_tokens[i] = toks[i];
+    return FSMG_OK;
+}
+
+int fsmg_read_losses(fsmg_handle h, float* out, int32_t n) {
+    if (!h || !out || n <= 0 || n > RING_CAP) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    std::vector<float> ring(RING_CAP);
+    long long step = 0;
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipMemcpy(ring.data(), h->d_ring, sizeof(float) * RING_CAP, hipMemcpyDeviceToHost));
+    HIPCK(h, hipMemcpy(&step, h->d_step, sizeof(step), hipMemcpyDeviceToHost));
+    if (step < n) return fail(h, FSMG_ERR_INVALID, "fewer train steps than requested losses");
+    for (int i = 0; i < n; ++i) out[i] = ring[(step - n + i) % RING_CAP];
+    return FSMG_OK;
+}
+
+int fsmg_debug_dims(fsmg_handle h, int32_t dims[5]) {
+    if (!h || !dims) return FSMG_ERR_INVALID;
+    dims[0] = h->Ep; dims[1] = h->Hp; dims[2] = h->V1p; dims[3] = h->lastB; dims[4] = h->T;
+    return FSMG_OK;
+}
+
+int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count) {
+    if (!h || !what || !host || count <= 0) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    const int64_t B = h->lastB, T = h->T, Hp = h->Hp, G4 = h->G4, rows = T * B;
+    const float* src = nullptr; int64_t cap = 0;
+    auto layer_of = [&](const char* prefix) -> int {
+        const size_t n = std::strlen(prefix);
+        if (std::strncmp(what, prefix, n) != 0) return -1;
+        const int l = std::atoi(what + n);
+        return (l >= 0 && l < h->L && std::strlen(what) > n) ? l : -1;
+    };
+    int l;
+    if (!std::strcmp(what, "logits")) { src = h->logits; cap = rows * h->V1p; }
+    else if (!std::strcmp(what, "lse")) { src = h->lse; cap = rows; }
+    else if (!std::strcmp(what, "ce")) { src = h->ce; cap = rows; }
+    else if (!std::strcmp(what, "dx")) { src = h->dXemb; cap = rows * h->Ep; }
+    else if (!std::strcmp(what, "dh")) { src = h->dH; cap = rows * Hp; }
+    else if (!std::strcmp(what, "gnorm")) { src = h->d_gnorm; cap = 1; }
+    else if (!std::strcmp(what, "tail")) { src = h->G + h->n_flat; cap = FSMG_GRAD_TAIL; }
+    else if ((l = layer_of("gates")) >= 0) { src = h->Z[l]; cap = rows * G4; }
+    else if ((l = layer_of("h")) >= 0) { src = h->Hs[l]; cap = (T + 1) * B * Hp; }
+    else if ((l = layer_of("c")) >= 0) { src = h->Cs[l]; cap = (T + 1) * B * Hp; }
+    else return fail(h, FSMG_ERR_NAME, std::string("unknown debug buffer '") + what + "'");
+    if (count > cap) return fail(h, FSMG_ERR_SIZE, "debug read larger than the buffer");
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipMemcpy(host, src, sizeof(float) * count, hipMemcpyDeviceToHost));
+    return FSMG_OK;
+}
+
+int fsmg_timing_enable(fsmg_handle h, int32_t on) {
+    if (!h) return FSMG_ERR_INVALID;
+    drain_timers(h);
+    h->timing = on != 0;
+    return FSMG_OK;
+}
+int fsmg_timing_select(fsmg_handle h, const char* kernel_class) {
+    if (!h) return FSMG_ERR_INVALID;
+    drain_timers(h);
+    h->timing_only = kernel_class ? kernel_class : "";
+    return FSMG_OK;
+}
+int fsmg_timing_read(fsmg_handle h, const char* kernel_class, double* total_ms, int64_t* launches) {
+    if (!h || !kernel_class) return FSMG_ERR_INVALID;
+    drain_timers(h);
+    auto it = h->timers.find(kernel_class);
+    if (total_ms) *total_ms = it == h->timers.end() ? 0.0 : it->second.total_ms;
+    if (launches) *launches = it == h->timers.end() ? 0 : it->second.launches;
+    return FSMG_OK;
+}
+int fsmg_timing_reset(fsmg_handle h) {
+    if (!h) return FSMG_ERR_INVALID;
+    drain_timers(h);
+    h->timers.clear();
+    return FSMG_OK;
+}
+
+}  // extern "C"

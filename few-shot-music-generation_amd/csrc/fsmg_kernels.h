@@ -1,0 +1,105 @@
+// Internal launcher interface between the C-ABI orchestration (fsmg_api.hip) and the
+// gfx950 kernels.  Nothing here is exported; include/fsmg.h is the public surface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fsmg {
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+// C[M,N] (+)= op(A)[M,K] * op(B)[K,N], fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32.
+// Operand storage modes (what is contiguous in HBM):
+//   KC: the K index is contiguous  (A stored [M][K] / B stored [N][K])
+//   XC: the non-K index is contiguous (A stored [K][M] / B stored [K][N])
+enum { OP_KC = 0, OP_XC = 1 };
+// Operand element transforms fused into the global->LDS staging:
+//   TR_DLOGITS: element (row r, vocab col v) of the stored LOGITS is read as
+//               dlogits = (exp(logit - lse[r]) - [v == tgt[r]]) * inv_n, 0 for v >= n_vocab
+enum { TR_NONE = 0, TR_DLOGITS = 1 };
+
+struct GemmArgs {
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    int M, N, K;
+    const float* bias;      // optional [N], added in the epilogue
+    const int* gather;      // optional row gather for A: KC -> M-rows, XC -> K-rows index into A
+    const float* lse;       // TR_DLOGITS: per logits-row log-sum-exp
+    const int* tgt;         // TR_DLOGITS: per logits-row target id
+    float inv_n;            // TR_DLOGITS: 1/(rows + 1e-12)
+    int n_vocab;            // TR_DLOGITS: number of real vocabulary columns (V1)
+    float* colsum;          // optional [N]: column sums of op(B) over K (XC B only), written by M-tile 0
+    int ksplit;             // >= 1; slab z covers a K range, C/colsum slab stride below
+    long long c_slab;       // elements between consecutive K-split slabs of C
+    long long colsum_slab;
+};
+// amode/bmode in {OP_KC, OP_XC}; atr/btr in {TR_NONE, TR_DLOGITS}. Supported combinations:
+// (KC,XC,*,NONE) (XC,XC,NONE,*) (KC,KC,*,NONE)
+hipError_t launch_gemm(hipStream_t s, int amode, int bmode, int atr, int btr, const GemmArgs& g);
+// out[i] = sum_z slabs[z][i]  (fixed order -> deterministic split-K)
+hipError_t launch_reduce_slabs(hipStream_t s, const float* slabs, long long slab_stride, int nslab,
+                               float* out, long long n);
+
+// ---------------------------------------------------------------- recurrent steps (lstm_step.hip)
+struct LstmFwdArgs {
+    const float* Kh;     // [Hp][4Hp] recurrent weights, packed gate columns
+    const float* h_prev; // [B][Hp]
+    float* z;            // [B][4Hp] in: x-part pre-activations (+bias); out: activated gates i,j,f,o
+    const float* c_prev; // [B][Hp]
+    float* c_next;       // [B][Hp]
+    float* h_next;       // [B][Hp]
+    int B, Hp;
+};
+hipError_t launch_lstm_fwd_step(hipStream_t s, const LstmFwdArgs& a);
+
+struct LstmBwdArgs {
+    const float* Kh;      // [Hp][4Hp]
+    const float* dz_next; // [B][4Hp] dz of step t+1 (nullptr at the last step)
+    float* gates;         // [B][4Hp] in: activated gates of step t; out: dz of step t
+    const float* c_t;     // [B][Hp]
+    const float* c_prev;  // [B][Hp]
+    float* dc;            // [B][Hp] carried cell gradient (in/out)
+    const float* dh_top;  // [B][Hp] gradient arriving from above at step t
+    int B, Hp;
+};
+hipError_t launch_lstm_bwd_step(hipStream_t s, const LstmBwdArgs& a);
+
+// ---------------------------------------------------------------- everything else (elementwise.hip)
+// tokens [nseq][T] (support rows then query rows) -> time-major input ids X[t][b] (start word at t=0)
+// and targets Y[t][b]; sets *err_flag if any id is outside [0, vocab).
+hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, const int* query, int n_query,
+                             int T, int vocab, int start_word, int* X, int* Y, int* err_flag);
+// per logits row: lse and cross entropy against the target
+hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt,
+                          float* lse, float* ce);
+// out[g] = sum over t and b in group g of ce[t*B+b] / (T*rows_per_group + 1e-12); fixed order
+hipError_t launch_loss_reduce(hipStream_t s, const float* ce, int T, int B, int rows_per_group, int ngroups,
+                              float* out);
+// dEmb[tok] = sum over occurrences r (increasing r) of dX[r]; dEmb must be zero-filled before
+hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX, int Ep, float* dEmb);
+// partial sums of squares (double) of x[0..n) into partials[pofs .. pofs+nblocks); returns nblocks via out param
+int sqnorm_blocks(long long n);
+hipError_t launch_sqnorm_partials(hipStream_t s, const float* x, long long n, double* partials);
+
+struct UpdateArgs {
+    float* p; float* m; float* v; const float* g; long long n;   // flat buffers
+    const double* partials; int n_partials;       // squared-norm partials of everything that counts
+    const float* tail;                            // grad tail scalars (tail[0] = slices_sq, used when slices)
+    int use_slices;                               // add tail[0]*grad_scale^2 to the norm
+    float grad_scale;                             // 1/world (g is a SUM over ranks)
+    float lr, n_decay, clip;
+    const long long* step;                        // global_step BEFORE this update (device)
+    float* gnorm_out;                             // optional: pre-clip global norm
+};
+hipError_t launch_adam_update(hipStream_t s, const UpdateArgs& a);
+hipError_t launch_step_increment(hipStream_t s, long long* step, const float* loss_src, float loss_scale,
+                                 float* loss_ring, int ring_cap);
+// dst[0] = (float) sum of partials[0..n) (fixed order)
+hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst);
+// greedy decode step pieces (sample)
+hipError_t launch_decode_cell(hipStream_t s, const float* Kx, int in_dim, const float* Kh, const float* bias,
+                              const float* x, const float* h_in, float* h_out, float* c, int Hp);
+hipError_t launch_decode_argmax(hipStream_t s, const float* W, int ldw, const float* bias, const float* h,
+                                int Hp, int n_vocab, int* out_token, float* scratch);
+
+}  // namespace fsmg

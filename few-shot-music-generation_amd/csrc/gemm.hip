@@ -1,0 +1,305 @@
+// fp32 GEMM for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak).
+//
+// One kernel template serves every dense contraction of the LSTM-baseline step
+// (DESIGN.md "Kernels"): the hoisted input projection with the embedding gather fused
+// into the A-operand load, the vocabulary projection, and their backward pairs with the
+// softmax-gradient transform (exp(logit - lse) - onehot) fused into the operand load so
+// dlogits is never materialised.
+//
+// Tiling: 128x128 block tile, BK = 32, 256 threads = 4 wave64 as 2x2, each wave owns a
+// 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs).  Both operands are staged
+// through LDS K-major ([k][x]) so that the MFMA operand read is one conflict-free
+// ds_read_b32 per 32-lane half (lanes 0-31 take k, lanes 32-63 take k+1):
+//   * XC sources (x contiguous in HBM) are copied with 16-B loads + ds_write_b128, row
+//     stride 132 floats;
+//   * KC sources (k contiguous in HBM) are loaded 16 B along k and transposed on the way
+//     in with 4 ds_write_b32, row stride 129 floats (129 = 1 mod 32 makes the 32 lanes of
+//     a group hit 32 distinct banks).
+// Global loads for tile t+1 are issued before the MFMAs of tile t (register prefetch) and
+// written to the other LDS buffer afterwards: one barrier per K tile.
+// Blocks are numbered so that the 8 XCDs (block b -> XCD b % 8 as observed on MI355X) each
+// walk a contiguous range of tiles and share operand panels in their private L2.
+#include "fsmg_kernels.h"
+
+namespace fsmg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LD_KC = 129;
+constexpr int LD_XC = 132;
+constexpr int NTHREADS = 256;
+
+template <int MODE> struct TileLd { static constexpr int v = (MODE == OP_KC) ? LD_KC : LD_XC; };
+
+struct DlCtx {
+    const float* lse; const int* tgt; float inv_n; int n_vocab;
+};
+
+__device__ __forceinline__ float dl_elem(float logit, float lse, int tgt, int v, const DlCtx& c) {
+    float p = __expf(logit - lse);
+    p = (v == tgt) ? p - 1.0f : p;
+    return (v < c.n_vocab) ? p * c.inv_n : 0.0f;
+}
+
+// ---- KC source: tile [128 x][32 k], k contiguous.  thread -> rows x = tid/8 + 32*i, k quad kq = tid%8
+template <int TR>
+struct KcLoader {
+    const float* rowp[4];
+    float lse[4]; int tgt[4];
+    int kq;
+    __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather,
+                                         const DlCtx& dl, int tid) {
+        kq = tid & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int x = x0 + (tid >> 3) + 32 * i;
+            bool ok = x < X;
+            long long row = ok ? (gather ? (long long)gather[x] : (long long)x) : 0;
+            rowp[i] = ok ? src + row * ld : nullptr;
+            if (TR == TR_DLOGITS) {
+                lse[i] = ok ? dl.lse[x] : 0.0f;
+                tgt[i] = ok ? dl.tgt[x] : -1;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(float4 (&r)[4], int k0, int kend, const DlCtx& dl) const {
+        int k = k0 + 4 * kq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowp[i] != nullptr && k < kend) {
+                v = *reinterpret_cast<const float4*>(rowp[i] + k);
+                if (TR == TR_DLOGITS) {
+                    v.x = dl_elem(v.x, lse[i], tgt[i], k + 0, dl);
+                    v.y = dl_elem(v.y, lse[i], tgt[i], k + 1, dl);
+                    v.z = dl_elem(v.z, lse[i], tgt[i], k + 2, dl);
+                    v.w = dl_elem(v.w, lse[i], tgt[i], k + 3, dl);
+                }
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, const float4 (&r)[4], int tid) const {
+        float* base = lds + (4 * kq) * LD_KC + (tid >> 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            base[0 * LD_KC + 32 * i] = r[i].x;
+            base[1 * LD_KC + 32 * i] = r[i].y;
+            base[2 * LD_KC + 32 * i] = r[i].z;
+            base[3 * LD_KC + 32 * i] = r[i].w;
+        }
+    }
+};
+
+// ---- XC source: tile [32 k][128 x], x contiguous.  thread -> k rows tid/32 + 8*i, x quad xq = tid%32
+template <int TR>
+struct XcLoader {
+    const float* colp;   // src + x  (nullptr if x beyond X)
+    const int* gather;
+    int ld, x;
+    __device__ __forceinline__ void init(const float* src, int ld_, int X, int x0, const int* gather_,
+                                         const DlCtx&, int tid) {
+        ld = ld_;
+        gather = gather_;
+        x = x0 + 4 * (tid & 31);
+        colp = (x < X) ? src + x : nullptr;
+    }
+    __device__ __forceinline__ void load(float4 (&r)[4], int k0, int kend, const DlCtx& dl, int tid) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int k = k0 + (tid >> 5) + 8 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (colp != nullptr && k < kend) {
+                long long row = gather ? (long long)gather[k] : (long long)k;
+                v = *reinterpret_cast<const float4*>(colp + row * ld);
+                if (TR == TR_DLOGITS) {
+                    float l = dl.lse[k];
+                    int t = dl.tgt[k];
+                    v.x = dl_elem(v.x, l, t, x + 0, dl);
+                    v.y = dl_elem(v.y, l, t, x + 1, dl);
+                    v.z = dl_elem(v.z, l, t, x + 2, dl);
+                    v.w = dl_elem(v.w, l, t, x + 3, dl);
+                }
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, const float4 (&r)[4], int tid) const {
+        float* base = lds + (tid >> 5) * LD_XC + 4 * (tid & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(base + 8 * i * LD_XC) = r[i];
+    }
+};
+
+template <int MODE, int TR> struct Loader;
+template <int TR> struct Loader<OP_KC, TR> : KcLoader<TR> {
+    __device__ __forceinline__ void fetch(float4 (&r)[4], int k0, int kend, const DlCtx& dl, int) const {
+        this->load(r, k0, kend, dl);
+    }
+};
+template <int TR> struct Loader<OP_XC, TR> : XcLoader<TR> {
+    __device__ __forceinline__ void fetch(float4 (&r)[4], int k0, int kend, const DlCtx& dl, int tid) const {
+        this->load(r, k0, kend, dl, tid);
+    }
+};
+
+template <int AMODE, int BMODE, int ATR, int BTR>
+__global__ __launch_bounds__(NTHREADS, 2) void k_gemm(const GemmArgs g) {
+    constexpr int LDA = TileLd<AMODE>::v, LDB = TileLd<BMODE>::v;
+    constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * ASZ + 2 * BSZ];
+    float* As = smem;
+    float* Bs = smem + 2 * ASZ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+
+    // ---- XCD-aware tile numbering (bijective for any tile count)
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    const int nb = tilesM * tilesN;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nb >> 3, r = nb & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = bid % tilesM, tn = bid / tilesM;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- K range of this split
+    const int z = blockIdx.y;
+    int kb = 0, ke = g.K;
+    if (g.ksplit > 1) {
+        int per = ((g.K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK;
+        kb = z * per;
+        ke = min(g.K, kb + per);
+    }
+    const int nk = (ke > kb) ? (ke - kb + BK - 1) / BK : 0;
+
+    DlCtx dl{g.lse, g.tgt, g.inv_n, g.n_vocab};
+    Loader<AMODE, ATR> la;
+    Loader<BMODE, BTR> lb;
+    la.init(g.A, g.lda, g.M, m0, g.gather, dl, tid);
+    lb.init(g.B, g.ldb, g.N, n0, nullptr, dl, tid);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0 && tid < BN;
+    float csum = 0.0f;
+
+    float4 ra[4], rb[4];
+    if (nk > 0) {
+        la.fetch(ra, kb, ke, dl, tid);
+        lb.fetch(rb, kb, ke, dl, tid);
+        la.store(As, ra, tid);
+        lb.store(Bs, rb, tid);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            la.fetch(ra, kb + (kt + 1) * BK, ke, dl, tid);
+            lb.fetch(rb, kb + (kt + 1) * BK, ke, dl, tid);
+        }
+        const float* a_base = As + cur * ASZ + khalf * LDA + wm * 64 + l31;
+        const float* b_base = Bs + cur * BSZ + khalf * LDB + wn * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = a_base[kk * LDA], a1 = a_base[kk * LDA + 32];
+            const float b0 = b_base[kk * LDB], b1 = b_base[kk * LDB + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (do_colsum) {
+            const float* bc = Bs + cur * BSZ + tid;
+#pragma unroll
+            for (int k = 0; k < BK; ++k) csum += bc[k * LDB];
+        }
+        if (more) {
+            la.store(As + (cur ^ 1) * ASZ, ra, tid);
+            lb.store(Bs + (cur ^ 1) * BSZ, rb, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* C = g.C + (long long)z * g.c_slab;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= g.N) continue;
+        const float bv = (g.bias != nullptr && z == 0) ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (row < g.M) C[(long long)row * g.ldc + col] = acc[i][j][r] + bv;
+            }
+        }
+    }
+    if (do_colsum && n0 + tid < g.N) g.colsum[(long long)z * g.colsum_slab + n0 + tid] = csum;
+}
+
+template <int AMODE, int BMODE, int ATR, int BTR>
+hipError_t launch_t(hipStream_t s, const GemmArgs& g) {
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    dim3 grid(tilesM * tilesN, g.ksplit > 1 ? g.ksplit : 1);
+    hipLaunchKernelGGL((k_gemm<AMODE, BMODE, ATR, BTR>), grid, dim3(NTHREADS), 0, s, g);
+    return hipGetLastError();
+}
+
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, long long stride, int nslab,
+                               float* __restrict__ out, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        float s = slabs[i];
+        for (int z = 1; z < nslab; ++z) s += slabs[z * stride + i];
+        out[i] = s;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_gemm(hipStream_t s, int amode, int bmode, int atr, int btr, const GemmArgs& g) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (amode == OP_KC && bmode == OP_XC && btr == TR_NONE) {
+        return atr == TR_NONE ? launch_t<OP_KC, OP_XC, TR_NONE, TR_NONE>(s, g)
+                              : launch_t<OP_KC, OP_XC, TR_DLOGITS, TR_NONE>(s, g);
+    }
+    if (amode == OP_XC && bmode == OP_XC && atr == TR_NONE) {
+        return btr == TR_NONE ? launch_t<OP_XC, OP_XC, TR_NONE, TR_NONE>(s, g)
+                              : launch_t<OP_XC, OP_XC, TR_NONE, TR_DLOGITS>(s, g);
+    }
+    if (amode == OP_KC && bmode == OP_KC && btr == TR_NONE) {
+        return atr == TR_NONE ? launch_t<OP_KC, OP_KC, TR_NONE, TR_NONE>(s, g)
+                              : launch_t<OP_KC, OP_KC, TR_DLOGITS, TR_NONE>(s, g);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_reduce_slabs(hipStream_t s, const float* slabs, long long slab_stride, int nslab,
+                               float* out, long long n) {
+    if (n <= 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, slabs, slab_stride, nslab, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace fsmg

@@ -1,0 +1,69 @@
+"""Episode-parallel training over the GPUs of one node.
+
+One process per GPU.  Every outer step each rank runs forward+backward on ITS episode,
+the flat fp32 gradient buffer (plus its tail scalars: squared embedding-slice norm and
+loss) is summed with ONE all-reduce (RCCL over xGMI when the backend is "nccl"), and
+every rank then applies the identical clip + Adam update with grad_scale = 1/world, so
+replicas stay bit-identical without ever broadcasting parameters again.
+
+The reference has no distributed code; R = 1 is its semantics, R > 1 is "R episodes per
+Adam step" = the gradient of the mean loss over the R episodes' rows.
+
+`engine` is anything with forward_backward(support, query), grad_tensor (a torch tensor
+aliasing the flat gradient buffer) and apply_update(grad_scale) -> loss: the HIP model
+(models.hip_model.HIPModel) in production, a CPU stand-in in the gloo tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world)."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+class EpisodeParallel(object):
+    def __init__(self, engine, group=None):
+        self.engine = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def broadcast_parameters(self, tensor):
+        """One-time parameter / optimiser-state broadcast from rank 0 (after init or restore)."""
+        if self.world > 1:
+            ctx = getattr(self.engine, 'stream_context', None)
+            if ctx is not None:
+                with ctx():
+                    dist.broadcast(tensor, src=0, group=self.group)
+            else:
+                dist.broadcast(tensor, src=0, group=self.group)
+
+    def train_step(self, support, query, want_loss=True, **kw):
+        self.engine.forward_backward(support, query, **kw)
+        if self.world > 1:
+            ctx = getattr(self.engine, 'stream_context', None)
+            if ctx is not None:
+                with ctx():                  # same stream as the HIP kernels: no host sync needed
+                    dist.all_reduce(self.engine.grad_tensor, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                dist.all_reduce(self.engine.grad_tensor, op=dist.ReduceOp.SUM, group=self.group)
+        return self.engine.apply_update(1.0 / self.world, want_loss=want_loss)
+
+    def mean_scalar(self, value):
+        """Mean of a host float over ranks (validation NLL sharded over ranks)."""
+        if self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.float64)
+        if dist.get_backend(self.group) == 'nccl':
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t.item()) / self.world

@@ -1,0 +1,141 @@
+"""Device plumbing shared by the HIP-backed plugins: handle creation, checkpoints, init.
+
+Plays the role /root/reference/src/models/tf_model.py plays for the TensorFlow plugins
+(session, Saver, initialisation) with the same observable behaviour:
+  * save(dir)            -> <dir>/<name>/<name>-<global_step>.npz, newest 10 kept
+                            (tf_model.py:96-97,106-114; file format is ours);
+  * recover_or_init(dir) -> restore the latest checkpoint under <dir>/<name> if there is one --
+                            every tensor whose name AND shape match ("optimistic restore",
+                            tf_model.py:28-75) -- then initialise what was not restored
+                            (Glorot-uniform / zeros); works with dir == ''.
+A checkpoint holds what TF's held: weights, Adam m/v, global_step.
+PyTorch is used for device memory, the stream and torch.distributed only.
+"""
+import glob
+import os
+import re
+
+import numpy as np
+
+from fsmg.binding import FsmgError, FsmgModel
+from models.base_model import BaseModel
+
+MAX_TO_KEEP = 10
+
+
+class HIPModel(BaseModel):
+    def __init__(self, config):
+        super(HIPModel, self).__init__(config)
+        import torch
+        if not torch.cuda.is_available():
+            raise FsmgError(-2, 'no MI355X visible to PyTorch-ROCm: the HIP path has no CPU fallback')
+        self._torch = torch
+        self._device = int(config.get('device', os.environ.get('LOCAL_RANK', 0)))
+        torch.cuda.set_device(self._device)
+        nbytes = FsmgModel.state_bytes(config)
+        # params | grads (+tail) | adam m | adam v, owned by the torch allocator so that the gradient
+        # region can be handed to torch.distributed (RCCL) as an ordinary tensor
+        self._arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device='cuda:%d' % self._device)
+        base = self._arena.data_ptr()
+        pad = (-base) % 256
+        # a dedicated (non-default) torch stream: its handle is a real hipStream_t the library can launch
+        # on, and collectives issued under `stream_context()` are ordered with the library's kernels
+        self._stream = torch.cuda.Stream(device=self._device)
+        self._model = FsmgModel(config, device=self._device, stream=self._stream.cuda_stream,
+                                state_arena=base + pad, state_arena_bytes=nbytes,
+                                max_sequences=int(config.get('max_sequences', 0)),
+                                clip_norm_mode=config.get('clip_norm_mode', 'tf1_slices'),
+                                use_graph=bool(config.get('use_graph', False)))
+        gptr, gcount = self._model.grad_buffer()
+        off = gptr - base
+        self.grad_tensor = self._arena[off:off + 4 * gcount].view(torch.float32)
+        self._initialised = False
+        self._train_calls = 0
+        self._eval_calls = 0
+        self._scalars = None
+        if config.get('checkpt_dir'):
+            os.makedirs(config['checkpt_dir'], exist_ok=True)
+            self._scalars = open(os.path.join(config['checkpt_dir'], 'scalars.jsonl'), 'a')
+
+    # -- engine interface used by fsmg.dist.EpisodeParallel ------------------------------------
+    def forward_backward(self, support, query, **kw):
+        self._model.forward_backward(support, query, **kw)
+
+    def apply_update(self, grad_scale=1.0, want_loss=True):
+        return self._model.apply_update(grad_scale, want_loss=want_loss)
+
+    @property
+    def engine(self):
+        return self._model
+
+    def stream_context(self):
+        return self._torch.cuda.stream(self._stream)
+
+    def _log_scalar(self, tag, value, step):
+        # the reference writes TensorBoard summaries (lstm_baseline.py:106-111,126-131); no TB here -> JSONL
+        if self._scalars is not None:
+            self._scalars.write('{"tag": "%s", "step": %d, "value": %.9g}\n' % (tag, step, value))
+            self._scalars.flush()
+
+    # -- checkpoints ----------------------------------------------------------------------------
+    def _checkpt_prefix(self, checkpt_path):
+        directory = os.path.join(checkpt_path, self.name)
+        os.makedirs(directory, exist_ok=True)
+        return os.path.join(directory, self.name)
+
+    def save(self, checkpt_path):
+        step = self._model.step
+        blob = {'global_step': np.int64(step)}
+        for name in self._model.param_shapes:
+            blob['param/' + name] = self._model.get_param(name)
+            m, v = self._model.get_opt_state(name)
+            blob['adam_m/' + name], blob['adam_v/' + name] = m, v
+        prefix = self._checkpt_prefix(checkpt_path)
+        tmp = '%s-%d.tmp.npz' % (prefix, step)
+        np.savez(tmp, **blob)
+        os.replace(tmp, '%s-%d.npz' % (prefix, step))
+        for old in self._checkpoints(os.path.dirname(prefix))[:-MAX_TO_KEEP]:
+            os.remove(old[1])
+
+    def _checkpoints(self, directory):
+        found = []
+        for path in glob.glob(os.path.join(directory, '%s-*.npz' % self.name)):
+            m = re.search(r'-(\d+)\.npz$', path)
+            if m:
+                found.append((int(m.group(1)), path))
+        return sorted(found)
+
+    def _recover(self, checkpt_path):
+        if not checkpt_path:
+            return set()
+        found = self._checkpoints(os.path.join(checkpt_path, self.name))
+        if not found:
+            return set()
+        path = found[-1][1]
+        print('recovering %s from %s' % (self.name, path))
+        restored = set()
+        with np.load(path) as blob:
+            for name, shape in self._model.param_shapes.items():
+                want = (shape[0],) if shape[1] == 1 else tuple(shape)
+                key = 'param/' + name
+                if key in blob and blob[key].shape == want:
+                    self._model.set_param(name, blob[key])
+                    restored.add(name)
+                    if 'adam_m/' + name in blob and blob['adam_m/' + name].shape == want:
+                        self._model.set_opt_state(name, blob['adam_m/' + name], blob['adam_v/' + name])
+            if 'global_step' in blob:
+                self._model.step = int(blob['global_step'])
+        return restored
+
+    def recover_or_init(self, init_path):
+        missing = [n for n in self._model.param_shapes]
+        # initialise everything first (also zeroes Adam state and the step), then overlay the checkpoint
+        self._model.init_params(int(self._config.get('seed', 0)))
+        restored = self._recover(init_path)
+        print('Initializing vars:')
+        print([n for n in missing if n not in restored])
+        self._initialised = True
+
+    def _require_init(self):
+        if not self._initialised:
+            raise RuntimeError('call recover_or_init() before train/eval/sample')

@@ -1,0 +1,73 @@
+"""LSTM language-model baseline -- MI355X-native plugin.
+
+Drop-in for /root/reference/src/models/lstm_baseline.py: same module path and class name
+(`model_module_name: models.lstm_baseline`, `model_class_name: LSTMBaseline`), same config
+keys, same six plugin members with the same meaning -- but the TensorFlow graph and session
+are replaced by libfsmg (hand-written gfx950 kernels behind include/fsmg.h):
+
+  train(episode)  support + query flattened support-first, one clip+Adam update, returns the
+                  mean NLL under the PRE-update weights      (reference :89-113)
+  eval(episode)   query-only mean NLL, no state change       (reference :115-133)
+  sample(s, num)  greedy argmax decode from the start word; the support set is ignored, as in
+                  the reference                              (reference :135-156)
+
+Optional config keys beyond the reference's: device, clip_norm_mode ('tf1_slices' | 'dense'),
+max_sequences, use_graph.  When torch.distributed is initialised, train() runs episode-parallel
+(one episode per rank, one gradient all-reduce per step, see fsmg/dist.py).
+"""
+import numpy as np
+
+from fsmg.dist import EpisodeParallel
+from models.hip_model import HIPModel
+
+
+class LSTMBaseline(HIPModel):
+    def __init__(self, config):
+        for key in ('name', 'input_size', 'max_len', 'embedding_size', 'hidden_size', 'n_layers',
+                    'lr', 'max_grad_norm', 'n_decay'):
+            if key not in config:
+                raise RuntimeError('required config key "%s" not found' % key)
+        super(LSTMBaseline, self).__init__(config)
+        self._start_word = int(config['input_size'])
+        self._time_steps = int(config['max_len'])
+        self._parallel = EpisodeParallel(self)
+
+    def recover_or_init(self, init_path):
+        super(LSTMBaseline, self).recover_or_init(init_path)
+        if self._parallel.world > 1:                     # replicas start from rank 0's state
+            self._parallel.broadcast_parameters(self._arena)
+
+    @staticmethod
+    def _tokens(arr, ndim):
+        a = np.ascontiguousarray(arr, dtype=np.int32)
+        if a.ndim != ndim:
+            raise ValueError('expected a %d-d token array, got shape %r' % (ndim, a.shape))
+        return a
+
+    def train(self, episode):
+        self._require_init()
+        loss = self._parallel.train_step(self._tokens(episode.support, 3), self._tokens(episode.query, 3))
+        self._log_scalar('Train/loss', loss, self._train_calls)
+        self._train_calls += 1
+        return loss
+
+    def eval(self, episode):
+        self._require_init()
+        nll = self._model.eval_step(self._tokens(episode.query, 3))
+        self._log_scalar('Eval/Avg_NLL', nll, self._eval_calls)
+        self._eval_calls += 1
+        return nll
+
+    def eval_many(self, episodes):
+        """[model.eval(e) for e in episodes] in one device pass (episodes must share N, Q)."""
+        self._require_init()
+        queries = np.stack([self._tokens(e.query, 3) for e in episodes])
+        nlls = self._model.eval_batch(queries)
+        for nll in nlls:
+            self._log_scalar('Eval/Avg_NLL', float(nll), self._eval_calls)
+            self._eval_calls += 1
+        return [float(x) for x in nlls]
+
+    def sample(self, support_set, num):
+        self._require_init()
+        return self._model.sample(int(num))

@@ -1,0 +1,149 @@
+"""`python -um train.train --data=... --model=... --task=... [--checkpt_dir=...] [--init_dir=...]`
+
+Same entrypoint, flags, YAML merge order (data <- task <- model, later wins) and log lines as
+/root/reference/src/train/train.py:36-126; run it from this `src/` directory exactly like the
+reference.  Differences, all deliberate:
+  * flags are parsed inside main() (Q15) and YAML is read with safe_load (Q1);
+  * sample directories are created with exist_ok (Q10);
+  * when launched under torchrun (WORLD_SIZE > 1) training is episode-parallel: rank r trains on
+    episodes r, r+R, ... of the single train stream, validation episodes are dealt round-robin to
+    the ranks and averaged, and only rank 0 prints / checkpoints / writes samples;
+  * validation uses the plugin's batched `eval_many` when it has one (same per-episode values).
+"""
+import argparse
+import os
+import pprint
+import sys
+from importlib import import_module
+
+import yaml
+
+from data.episode import ShardedEpisodeSampler, load_sampler_from_config
+
+PP = pprint.PrettyPrinter(depth=6)
+EVAL_CHUNK = 16          # episodes per eval_many call
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='Train a model.')
+    for flag in ('data', 'model', 'task', 'checkpt_dir', 'init_dir'):
+        parser.add_argument('--' + flag, dest=flag, default='')
+    return parser
+
+
+def load_config(args):
+    """data.yaml <- task.yaml <- model.yaml, then the driver-injected keys (train.py:49-53)."""
+    config = {}
+    for path in (args.data, args.task, args.model):
+        with open(path, 'r') as f:
+            config.update(yaml.safe_load(f) or {})
+    config['dataset_path'] = os.path.abspath(config['dataset_path'])
+    config['checkpt_dir'] = args.checkpt_dir
+    return config
+
+
+def load_model_from_config(config):
+    Model = getattr(import_module(config['model_module_name']), config['model_class_name'])
+    return Model(config)
+
+
+def write_seq(seq, dir, name):
+    if isinstance(seq, str):
+        with open(os.path.join(dir, name + '.txt'), 'w') as f:
+            f.write(seq)
+    else:
+        seq.write(os.path.join(dir, name + '.mid'))
+
+
+def evaluate(model, episode_sampler, n_episodes):
+    """Mean of model.eval over n_episodes fresh episodes (train.py:27-33)."""
+    total, done = 0.0, 0
+    many = getattr(model, 'eval_many', None)
+    while done < n_episodes:
+        n = min(EVAL_CHUNK, n_episodes - done) if many else 1
+        episodes = [episode_sampler.get_episode() for _ in range(n)]
+        total += sum(many(episodes)) if many else model.eval(episodes[0])
+        done += n
+    return total / n_episodes
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        from fsmg.dist import init_from_env
+        rank, world = init_from_env()
+    chief = rank == 0
+
+    def say(*a):
+        if chief:
+            print(*a)
+            sys.stdout.flush()
+
+    say('Args:')
+    say(PP.pformat(vars(args)))
+    config = load_config(args)
+    say('Config:')
+    say(PP.pformat(config))
+
+    episode_sampler = {}
+    for split in config['splits']:
+        config['split'] = split
+        sampler = load_sampler_from_config(config)
+        episode_sampler[split] = ShardedEpisodeSampler(sampler, rank, world) if world > 1 else sampler
+
+    config['input_size'] = episode_sampler['train'].get_num_unique_words()
+    if not config['input_size'] > 0:
+        raise RuntimeError('error reading data: %d unique tokens processed' % config['input_size'])
+    say('Num unique words: %d' % config['input_size'])
+
+    n_train, print_every_n, val_every_n = config['n_train'], config['print_every_n'], config['val_every_n']
+    n_val, n_test, n_samples, max_len = config['n_val'], config['n_test'], config['n_samples'], config['max_len']
+
+    model = load_model_from_config(config)
+    model.recover_or_init(args.init_dir)
+
+    def validate(split, n):
+        per_rank = max(1, n // world)
+        nll = evaluate(model, episode_sampler[split], per_rank)
+        parallel = getattr(model, '_parallel', None)
+        return parallel.mean_scalar(nll) if (world > 1 and parallel) else nll
+
+    say('Iter: %d, val-nll: %.3e' % (0, validate('val', n_val)))
+
+    avg_loss = 0.
+    for i in range(1, n_train + 1):
+        episode = episode_sampler['train'].get_episode()
+        avg_loss += model.train(episode)
+
+        if i % val_every_n == 0:            # val_every_n may be a float (Q11)
+            say('Iter: %d, val-nll: %.3e' % (i, validate('val', n_val)))
+            if args.checkpt_dir != '' and chief:
+                model.save(args.checkpt_dir)
+
+        if i % print_every_n == 0:
+            say('Iter: %d, loss: %.3e' % (i, avg_loss / print_every_n))
+            avg_loss = 0.
+
+    say('Train Avg NLL: %.3e' % validate('train', n_test))
+    say('Validation Avg NLL: %.3e' % validate('val', n_test))
+    say('Test Avg NLL: %.3e' % validate('test', n_test))
+
+    if not chief:
+        return
+    samples_dir = os.path.join(args.checkpt_dir, 'samples')
+    os.makedirs(samples_dir, exist_ok=True)
+    for i in range(n_samples):
+        curr_sample_dir = os.path.join(samples_dir, 'sample_%d' % i)
+        os.makedirs(curr_sample_dir, exist_ok=True)
+        episode = episode_sampler['test'].get_episode()
+        support_set = episode.support[0]
+        sample = model.sample(support_set, max_len)
+        for j in range(support_set.shape[0]):
+            write_seq(episode_sampler['test'].detokenize(support_set[j]), curr_sample_dir, 'support_%d' % j)
+        write_seq(episode_sampler['test'].detokenize(sample), curr_sample_dir, 'model_sample')
+
+
+if __name__ == '__main__':
+    main()

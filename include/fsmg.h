@@ -1,0 +1,167 @@
+/*
+ * libfsmg -- C-ABI of the MI355X-native LSTM-baseline episodic train / eval step.
+ *
+ * This is the drop-in boundary for the hot path of AI-ON/Few-Shot-Music-Generation
+ * (reference tree: /root/reference).  The reference has no FFI of its own: its only
+ * device boundary is `self._sess.run(...)` inside the `models/` plugin
+ * (src/models/lstm_baseline.py:104,125,150).  The entry points below are what a
+ * Python `models.lstm_baseline.LSTMBaseline` plugin binds with ctypes instead of a
+ * TensorFlow session; each one names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C, opaque handle, caller-allocated buffers, no C++ exceptions cross the boundary;
+ *   - every function returns 0 on success or a negative FSMG_ERR_* code;
+ *     fsmg_last_error(handle) (or fsmg_last_error(NULL) for create-time errors) has the text;
+ *   - a handle is NOT thread-safe; all work of a handle is ordered on ONE HIP stream
+ *     (its own, or the caller's when fsmg_config.stream is set);
+ *   - "host" pointers are ordinary CPU memory, "device" pointers are HBM addresses on the
+ *     handle's device (e.g. torch.Tensor.data_ptr()); token arrays are int32, C-contiguous,
+ *     ids in [0, input_size) exactly as the reference's Episode.support / Episode.query
+ *     (src/data/episode.py:63-74);
+ *   - parameters cross the boundary in the REFERENCE's variable layout (tf names and
+ *     shapes, src/models/lstm_baseline.py:39-40,44-49,60-62): embedding [V1,E],
+ *     kernel_<l> [(in+H),4H] with gate column blocks i,j,f,o, bias_<l> [4H],
+ *     softmax_w [H,V1], softmax_b [V1];  V1 = input_size + 1 (start word).
+ *     Inside, they live padded and gate-interleaved (DESIGN.md "HBM layout").
+ *   - there is no CPU fallback: without a gfx950 device fsmg_create fails with
+ *     FSMG_ERR_NO_DEVICE.
+ */
+#ifndef FSMG_H
+#define FSMG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSMG_VERSION 100 /* 0.1.0 */
+
+enum {
+    FSMG_OK = 0,
+    FSMG_ERR_INVALID = -1,     /* bad argument / config value                        */
+    FSMG_ERR_NO_DEVICE = -2,   /* no usable HIP device (no CPU fallback exists)      */
+    FSMG_ERR_HIP = -3,         /* a HIP runtime call failed                          */
+    FSMG_ERR_NOMEM = -4,       /* host or device allocation failed                   */
+    FSMG_ERR_NAME = -5,        /* unknown parameter / buffer name                    */
+    FSMG_ERR_SIZE = -6,        /* element count does not match the named tensor      */
+    FSMG_ERR_TOKEN_RANGE = -7, /* a token id was outside [0, input_size)             */
+    FSMG_ERR_STATE = -8        /* call sequence error (e.g. apply without backward)  */
+};
+
+enum { FSMG_CLIP_TF1_SLICES = 0, FSMG_CLIP_DENSE = 1 };
+
+typedef struct fsmg_model* fsmg_handle;
+
+/* Model / optimiser configuration == the YAML keys the reference plugin reads
+ * (src/models/lstm_baseline.py:21-29,80; src/models/tf_model.py:81). */
+typedef struct fsmg_config {
+    int32_t input_size;      /* config['input_size']: vocabulary WITHOUT the start word        */
+    int32_t max_len;         /* config['max_len'] = T                                         */
+    int32_t embedding_size;  /* config['embedding_size'] = E                                  */
+    int32_t hidden_size;     /* config['hidden_size'] = H                                     */
+    int32_t n_layers;        /* config['n_layers'] = L                                        */
+    float lr;                /* config['lr']                                                  */
+    float max_grad_norm;     /* config['max_grad_norm']                                       */
+    float n_decay;           /* config['n_decay'] (lr halves every n_decay steps, continuous) */
+    int32_t clip_norm_mode;  /* FSMG_CLIP_TF1_SLICES (reference behaviour) or FSMG_CLIP_DENSE */
+    int32_t device;          /* HIP device ordinal                                            */
+    int32_t max_sequences;   /* initial activation capacity in sequences (N*(K+Q)); grows on demand */
+    int32_t use_graph;       /* 1: replay the per-timestep launch chains as hipGraphs         */
+    void* stream;            /* optional caller hipStream_t; NULL = the library creates one   */
+    void* state_arena;       /* optional caller-owned DEVICE memory for params+grads+Adam state
+                                (fsmg_state_bytes() bytes, 256-B aligned); NULL = hipMalloc  */
+    uint64_t state_arena_bytes;
+} fsmg_config;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+int fsmg_version(void);
+const char* fsmg_last_error(fsmg_handle h);
+/* bytes a caller-provided state arena must have for this config */
+uint64_t fsmg_state_bytes(const fsmg_config* cfg);
+/* replaces TFModel.__init__ (session + graph build, src/models/tf_model.py:80-97) */
+int fsmg_create(const fsmg_config* cfg, fsmg_handle* out);
+int fsmg_destroy(fsmg_handle h);
+int fsmg_synchronize(fsmg_handle h);
+
+/* ---- parameters, optimiser state, checkpoints ------------------------------------------ */
+/* replaces the variable initialisation of recover_or_init (src/models/tf_model.py:16-25,127-129):
+ * Glorot-uniform for every matrix AND softmax_b, zeros for LSTM biases;
+ * also zeroes Adam m/v and global_step. */
+int fsmg_init_params(fsmg_handle h, uint64_t seed);
+int fsmg_num_params(fsmg_handle h);
+/* name (tf variable name without scope), rows, cols (cols = 1 for vectors) of parameter idx */
+int fsmg_param_info(fsmg_handle h, int idx, char* name, int name_cap, int64_t* rows, int64_t* cols);
+/* replace Saver.restore / Saver.save of a variable (src/models/tf_model.py:96-114); host
+ * float32 buffers in the reference layout, count = rows*cols */
+int fsmg_set_param(fsmg_handle h, const char* name, const float* host, int64_t count);
+int fsmg_get_param(fsmg_handle h, const char* name, float* host, int64_t count);
+/* Adam slots of a variable (what a TF checkpoint holds besides weights) */
+int fsmg_set_opt_state(fsmg_handle h, const char* name, const float* m, const float* v, int64_t count);
+int fsmg_get_opt_state(fsmg_handle h, const char* name, float* m, float* v, int64_t count);
+int fsmg_set_step(fsmg_handle h, int64_t global_step);
+int fsmg_get_step(fsmg_handle h, int64_t* global_step);
+/* gradient of the last backward, reference layout, before clipping (parity tests) */
+int fsmg_get_grad(fsmg_handle h, const char* name, float* host, int64_t count);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+/* replaces LSTMBaseline.train (src/models/lstm_baseline.py:89-113): support [N,K,T] and
+ * query [N,Q,T] are flattened support-rows-first, shifted against the start word on the
+ * device, forward + BPTT + clip_by_global_norm + Adam + global_step++.  *loss receives the
+ * mean NLL computed with the PRE-update parameters; passing loss == NULL skips the
+ * device->host readback (the loss stays in the handle's ring, see fsmg_read_losses).
+ * tokens_on_device != 0: support/query are device pointers (episode pool resident in HBM). */
+int fsmg_train_step(fsmg_handle h, const int32_t* support, const int32_t* query,
+                    int32_t N, int32_t K, int32_t Q, int32_t tokens_on_device, float* loss);
+
+/* Episode-parallel form of the same step: forward + backward only; the flat fp32
+ * gradient buffer (fsmg_grad_buffer) is then summed across ranks by the host (one RCCL
+ * all-reduce), and fsmg_apply_update(grad_scale = 1/world) clips and applies Adam identically
+ * on every rank. */
+int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* query,
+                          int32_t N, int32_t K, int32_t Q, int32_t tokens_on_device);
+/* device address + element count of the flat gradient buffer; the last FSMG_GRAD_TAIL floats
+ * are scalars that must be reduced with it: [0] = sum of squared embedding-slice gradients,
+ * [1] = loss */
+#define FSMG_GRAD_TAIL 16
+int fsmg_grad_buffer(fsmg_handle h, void** device_ptr, int64_t* count);
+int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss);
+
+/* replaces LSTMBaseline.eval (src/models/lstm_baseline.py:115-133): query-only mean NLL,
+ * no state change. */
+int fsmg_eval_step(fsmg_handle h, const int32_t* query, int32_t N, int32_t Q,
+                   int32_t tokens_on_device, float* nll);
+/* n_episodes independent eval calls in one pass: queries [n_episodes,N,Q,T] -> nll[n_episodes]
+ * (what train.evaluate's loop over model.eval computes, src/train/train.py:27-33) */
+int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, int32_t N, int32_t Q,
+                    int32_t tokens_on_device, float* nll);
+
+/* replaces LSTMBaseline.sample (src/models/lstm_baseline.py:135-156): greedy argmax decode of
+ * `num` tokens from the start word and a zero state (the support set is ignored there). */
+int fsmg_sample(fsmg_handle h, int32_t num, int32_t* out_tokens);
+
+/* last n train losses (oldest first), n <= 1024; synchronises the stream */
+int fsmg_read_losses(fsmg_handle h, float* out, int32_t n);
+
+/* ---- introspection for kernel-level parity tests and bench.py --------------------------- */
+/* copy an internal activation buffer of the last forward to the host, float32:
+ *   "h<l>" [T+1,B,Hp] (index 0 = zero state), "c<l>" [T+1,B,Hp], "gates<l>" [T,B,4Hp] (packed
+ *   gate order, holds dz after a backward), "logits" [T*B,V1p], "lse" [T*B], "ce" [T*B];
+ *   rows are TIME-major (row = t*B + b).  count = elements to copy (<= buffer size). */
+int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count);
+/* padded sizes: writes Ep, Hp, V1p, last B, T */
+int fsmg_debug_dims(fsmg_handle h, int32_t dims[5]);
+/* per-kernel-class HIP-event timing on the handle's stream (disables graph replay while on).
+ * classes: "gemm_zx","lstm_fwd","gemm_logits","ce","gemm_dhout","gemm_dw","lstm_bwd",
+ * "gemm_dk","gemm_dx","embed_grad","update" */
+int fsmg_timing_enable(fsmg_handle h, int32_t on);
+/* restrict event timing to ONE kernel class (NULL or "" = all classes): two event records per
+ * launch of that class, cheap enough to leave on inside a throughput measurement */
+int fsmg_timing_select(fsmg_handle h, const char* kernel_class);
+int fsmg_timing_read(fsmg_handle h, const char* kernel_class, double* total_ms, int64_t* launches);
+int fsmg_timing_reset(fsmg_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSMG_H */

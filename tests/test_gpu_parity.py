@@ -1,0 +1,267 @@
+"""-m gpu: the HIP path through the C-ABI vs the CPU oracle (fp64 restatement of the reference graph).
+
+Bar (BASELINE.json north_star): NLL within 1e-4 relative of the CPU reference, fp32.  Intermediate
+tensors and gradients are held to max|err| / max|ref| bounds written next to each check.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import small_config
+from gpu_utils import f64_params, new_model, oracle_step, read_states, rel_max, time_major
+from oracle import lstm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+NLL_RTOL = 1e-4
+
+SHAPES = [
+    # (config overrides, N, K, Q)
+    (dict(), 2, 2, 1),                                                        # B=6: one partial M tile
+    (dict(hidden_size=20, embedding_size=10, input_size=50, max_len=7), 1, 1, 1),   # H, E not multiples of 16/4
+    (dict(hidden_size=48, embedding_size=24, input_size=301, max_len=9), 5, 5, 4),  # B=45 like cfg-B
+    (dict(hidden_size=32, embedding_size=16, input_size=130, max_len=5), 10, 4, 3),  # B=70 > 48 rows: 2 row chunks
+    (dict(hidden_size=32, embedding_size=12, input_size=77, max_len=6, n_layers=2), 3, 2, 2),   # stacked
+]
+
+
+def _episode(cfg, N, K, Q, seed=0, realistic=True):
+    (sup, qry), = O.synthetic_episodes(1, N, K, Q, cfg['max_len'], cfg['input_size'], seed=seed, realistic=realistic)
+    return sup, qry
+
+
+@pytest.mark.parametrize('over,N,K,Q', SHAPES)
+def test_forward_backward_every_tensor(over, N, K, Q):
+    cfg = small_config(**over)
+    sup, qry = _episode(cfg, N, K, Q, seed=3)
+    model = new_model(cfg)
+    params = f64_params(model)
+    loss, cache, grads, aux = oracle_step(params, sup, qry, cfg)
+    B, T = N * (K + Q), cfg['max_len']
+
+    model.forward_backward(sup, qry)
+    tail = model.debug_read('tail', 16)
+    assert abs(tail[1] - loss) <= NLL_RTOL * abs(loss)
+    for l in range(cfg['n_layers']):
+        hs, cs, _ = read_states(model, cfg, l, B)          # gates now hold dz (checked through the grads)
+        assert rel_max(hs, cache['layers'][l]['hs']) < 2e-5, 'h layer %d' % l
+        assert rel_max(cs, cache['layers'][l]['cs']) < 2e-5, 'c layer %d' % l
+    V1p = model.debug_dims()['V1p']
+    logits = model.debug_read('logits', B * T * V1p).reshape(B * T, V1p)[:, :cfg['input_size'] + 1]
+    assert rel_max(logits, time_major(cache['logits'], B, T)) < 2e-5
+    assert rel_max(model.debug_read('lse', B * T), time_major(cache['lse'], B, T)) < 1e-5
+    assert rel_max(model.debug_read('ce', B * T), time_major(cache['ce'], B, T)) < 1e-5
+    for name in grads:
+        assert rel_max(model.get_grad(name), grads[name]) < 2e-4, name
+    assert abs(tail[0] - aux['embedding_slices_sq']) <= 1e-4 * aux['embedding_slices_sq']
+
+
+def test_forward_gates_before_backward():
+    cfg = small_config()
+    sup, qry = _episode(cfg, 2, 2, 1)
+    model = new_model(cfg)
+    params = f64_params(model)
+    nll = model.eval_step(qry)
+    X, Y = O.eval_xy(qry, cfg['input_size'])
+    want, cache = O.forward(params, X, Y, cfg)
+    assert abs(nll - want) <= NLL_RTOL * abs(want)
+    _, _, gates = read_states(model, cfg, 0, X.shape[0])
+    assert rel_max(gates, cache['layers'][0]['gates']) < 2e-5     # activated i, j, f(+1), o in reference gate order
+
+
+@pytest.mark.parametrize('mode', ['tf1_slices', 'dense'])
+@pytest.mark.parametrize('layers', [1, 2])
+def test_ten_update_trajectory(mode, layers):
+    """test_seed-style (reference src/train/test_seed.py): 10 consecutive train losses from identical
+    parameters and episodes, plus the final weights and Adam state."""
+    cfg = small_config(hidden_size=40, embedding_size=20, input_size=211, max_len=12, n_layers=layers,
+                       max_grad_norm=0.3)      # small clip: the clip branch is active from step 0
+    model = new_model(cfg, clip_norm_mode=mode)
+    params = f64_params(model)
+    opt = O.new_opt_state(params)
+    for s in range(10):
+        sup, qry = _episode(cfg, 3, 3, 2, seed=100 + s)
+        want = O.train_step(params, opt, sup, qry, cfg, clip_norm_mode=mode)
+        got = model.train_step(sup, qry)
+        assert abs(got - want) <= NLL_RTOL * abs(want), (s, got, want)
+    assert model.step == 10
+    for name, ref in params.items():
+        assert rel_max(model.get_param(name), ref) < 5e-4, name
+        m, v = model.get_opt_state(name)
+        assert rel_max(m, opt['m'][name]) < 2e-3, name
+        assert rel_max(v, opt['v'][name]) < 4e-3, name
+    np.testing.assert_allclose(model.read_losses(3)[-1], got, rtol=1e-6)
+
+
+def test_clip_modes_differ_and_gnorm_matches():
+    cfg = small_config(max_grad_norm=1e-3)
+    sup, qry = _episode(cfg, 2, 2, 1)
+    norms = {}
+    for mode in ('tf1_slices', 'dense'):
+        model = new_model(cfg, clip_norm_mode=mode)
+        params = f64_params(model)
+        _, _, grads, aux = oracle_step(params, sup, qry, cfg)
+        model.train_step(sup, qry)
+        norms[mode] = float(model.debug_read('gnorm', 1)[0])
+        assert abs(norms[mode] - O.global_norm(grads, aux, mode)) <= 1e-4 * norms[mode]
+    assert norms['tf1_slices'] != norms['dense']
+
+
+def test_reference_default_dims_on_golden_episodes(golden_dir):
+    """cfg-A: lyrics fixture episodes (captured from the reference sampler), E=250, H=200, T=32."""
+    gold = np.load(os.path.join(golden_dir, 'g2_episodes.npz'))
+    cfg = small_config(input_size=int(gold['vocab']), max_len=32, embedding_size=250, hidden_size=200)
+    model = new_model(cfg)
+    params = f64_params(model)
+    opt = O.new_opt_state(params)
+    for e in range(3):
+        qry = gold['n2_val_%d_query' % e]
+        want = O.eval_step(params, qry, cfg)
+        assert abs(model.eval_step(qry) - want) <= NLL_RTOL * abs(want)
+    for e in range(4):
+        sup, qry = gold['n2_train_%d_support' % e], gold['n2_train_%d_query' % e]
+        want = O.train_step(params, opt, sup, qry, cfg)
+        got = model.train_step(sup, qry)
+        assert abs(got - want) <= NLL_RTOL * abs(want), (e, got, want)
+
+
+def test_eval_batch_equals_eval_steps_and_chunks():
+    cfg = small_config(hidden_size=32, embedding_size=16, input_size=99, max_len=8)
+    model = new_model(cfg, max_sequences=10)          # capacity 10 sequences -> 3 episodes of 3 per chunk
+    eps = O.synthetic_episodes(7, 3, 2, 1, cfg['max_len'], cfg['input_size'], seed=5)
+    queries = np.stack([q for _, q in eps])
+    one_by_one = np.array([model.eval_step(q) for q in queries], np.float32)
+    batched = model.eval_batch(queries)
+    np.testing.assert_array_equal(batched, one_by_one)          # same kernels, rows independent -> bit-equal
+    params = f64_params(model)
+    for q, got in zip(queries, batched):
+        want = O.eval_step(params, q, cfg)
+        assert abs(got - want) <= NLL_RTOL * abs(want)
+
+
+def test_eval_does_not_change_state_and_train_is_deterministic():
+    cfg = small_config()
+    sup, qry = _episode(cfg, 2, 2, 1)
+    runs = []
+    for _ in range(2):
+        model = new_model(cfg)
+        before = model.get_params()
+        model.eval_step(qry)
+        after = model.get_params()
+        for k in before:
+            np.testing.assert_array_equal(before[k], after[k])
+        assert model.step == 0
+        losses = [model.train_step(sup, qry) for _ in range(3)]
+        runs.append((losses, model.get_params()))
+    assert runs[0][0] == runs[1][0]
+    for k in runs[0][1]:
+        np.testing.assert_array_equal(runs[0][1][k], runs[1][1][k])     # no float atomics anywhere
+
+
+def test_device_resident_tokens_match_host_tokens():
+    import torch
+    cfg = small_config()
+    sup, qry = _episode(cfg, 2, 2, 1)
+    a, b = new_model(cfg), new_model(cfg)
+    ds, dq = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    torch.cuda.synchronize()
+    la = [a.train_step(sup, qry) for _ in range(2)]
+    lb = [b.train_step(ds.data_ptr(), dq.data_ptr(), shape=(2, 2, 1)) for _ in range(2)]
+    assert la == lb
+    assert a.eval_step(qry) == b.eval_step(dq.data_ptr(), shape=(2, 1))
+
+
+def test_split_step_equals_fused_step():
+    cfg = small_config()
+    sup, qry = _episode(cfg, 2, 2, 1)
+    a, b = new_model(cfg), new_model(cfg)
+    la = a.train_step(sup, qry)
+    b.forward_backward(sup, qry)
+    lb = b.apply_update(1.0)
+    assert la == lb
+    for k, v in a.get_params().items():
+        np.testing.assert_array_equal(v, b.get_param(k))
+
+
+def test_errors():
+    from fsmg.binding import FsmgError
+    cfg = small_config()
+    model = new_model(cfg)
+    sup, qry = _episode(cfg, 2, 2, 1)
+    bad = qry.copy()
+    bad[0, 0, 3] = cfg['input_size']            # the start word is not a legal data token
+    with pytest.raises(FsmgError, match='TOKEN_RANGE'):
+        model.eval_step(bad)
+    assert np.isfinite(model.eval_step(qry))    # the handle stays usable
+    with pytest.raises(FsmgError, match='STATE'):
+        model.apply_update(1.0)
+    with pytest.raises(FsmgError, match='NAME'):
+        model.get_param('nope')
+    with pytest.raises(ValueError):
+        model.eval_step(qry[:, :, :-1])
+    with pytest.raises(FsmgError, match='INVALID'):
+        new_model(small_config(hidden_size=0))
+
+
+def test_param_roundtrip_and_opt_state_roundtrip():
+    cfg = small_config(hidden_size=20, embedding_size=10, n_layers=2)
+    model = new_model(cfg)
+    ref = O.glorot_init(cfg, 9, np.float32)
+    model.set_params(ref)
+    for k, v in ref.items():
+        np.testing.assert_array_equal(model.get_param(k), v)
+        model.set_opt_state(k, v * 2, v * v)
+        m, vv = model.get_opt_state(k)
+        np.testing.assert_array_equal(m, v * 2)
+        np.testing.assert_array_equal(vv, v * v)
+    model.step = 77
+    assert model.step == 77
+
+
+def test_init_distribution_is_glorot_uniform():
+    cfg = small_config(hidden_size=64, embedding_size=32, input_size=499)
+    model = new_model(cfg)
+    p = model.get_params()
+    for name, w in p.items():
+        if name.startswith('bias_'):
+            assert np.all(w == 0)
+            continue
+        fan_in, fan_out = (w.shape[0], w.shape[0]) if w.ndim == 1 else w.shape
+        limit = np.sqrt(6.0 / (fan_in + fan_out))
+        assert np.abs(w).max() <= limit and np.abs(w).max() > 0.9 * limit, name
+        assert abs(w.mean()) < 0.05 * limit and abs(w.std() - limit / np.sqrt(3)) < 0.05 * limit, name
+
+
+def test_sample_matches_oracle_greedy_decode():
+    cfg = small_config(hidden_size=24, embedding_size=12, input_size=61, n_layers=2)
+    model = new_model(cfg)
+    sup, qry = _episode(cfg, 2, 2, 1)
+    for _ in range(3):
+        model.train_step(sup, qry)
+    params = f64_params(model)
+    assert model.sample(15) == O.sample(params, 15, cfg)
+
+
+def test_plugin_api_checkpoint_resume(tmp_path):
+    from data.episode import Episode
+    from models.lstm_baseline import LSTMBaseline
+    cfg = small_config(checkpt_dir=str(tmp_path))
+    sup, qry = _episode(cfg, 2, 2, 1)
+    ep = Episode(sup, qry)
+    a = LSTMBaseline(dict(cfg))
+    assert a.name == 'lstm_baseline'
+    with pytest.raises(RuntimeError):
+        a.train(ep)                              # recover_or_init first
+    a.recover_or_init('')
+    l1 = [a.train(ep) for _ in range(3)]
+    a.save(str(tmp_path))
+    l2 = [a.train(ep) for _ in range(2)]
+    b = LSTMBaseline(dict(cfg))
+    b.recover_or_init(str(tmp_path))             # weights + Adam slots + global_step come back
+    assert b.engine.step == 3
+    assert [b.train(ep) for _ in range(2)] == l2
+    assert b.eval(ep) == a.eval(ep)
+    assert a.eval_many([ep, ep]) == [a.eval(ep)] * 2
+    assert os.path.isfile(os.path.join(str(tmp_path), 'lstm_baseline', 'lstm_baseline-3.npz'))
+    assert len(a.sample(sup[0], 5)) == 5 and l1[0] > 0
