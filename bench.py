@@ -53,14 +53,25 @@ def algorithmic_gflop(cfg, B):
     return {k: v / 1e9 for k, v in g.items()}
 
 
+T_START = time.time()
+
+
+def log(msg):
+    sys.stderr.write('[bench %7.1fs] %s\n' % (time.time() - T_START, msg))
+    sys.stderr.flush()
+
+
 def cpu_baseline(cfg, pool, budget_s=20.0):
     """oracle torch-CPU restatement timed on the host cores: bounded sample of the same workload"""
     import torch
     from oracle import lstm_oracle as O
     from oracle.torch_ref import TorchRef
-    cores = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = min(avail, int(os.environ.get('FSMG_CPU_THREADS', 32)))   # 45-row GEMMs stop scaling long before 32 threads
     ref = TorchRef(cfg, O.glorot_init(cfg, cfg['seed'], np.float32), dtype=torch.float32, threads=cores)
+    log('cpu_baseline: %d threads (of %d available), warm-up step' % (cores, avail))
     ref.train(*pool[0])                                   # warm-up
+    log('cpu_baseline: timing')
     n, t0 = 0, time.perf_counter()
     while True:
         ref.train(*pool[(n + 1) % len(pool)])
@@ -102,8 +113,10 @@ def main():
     d_qry = torch.from_numpy(np.stack([q for _, q in pool_host])).cuda()
     sup_stride, qry_stride = d_sup[0].numel() * 4, d_qry[0].numel() * 4
 
+    log('rank %d/%d: pool on device, creating model' % (rank, world))
     model = LSTMBaseline(cfg)
     model.recover_or_init('')
+    log('model ready')
     par = EpisodeParallel(model)
     eng = model.engine
     shape = (N_WAY, K_SHOT, Q_QUERY)
@@ -121,6 +134,9 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+        if i == 0:
+            torch.cuda.synchronize()
+            log('first step done')
     eng.timing_select(DOMINANT)
     eng.timing_enable(True)
     eng.timing_reset()
@@ -130,6 +146,7 @@ def main():
         step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    log('timed region done: %.3f s for %d steps' % (elapsed, args.steps))
     dom_ms, dom_n = eng.timing_read(DOMINANT)
     eng.timing_enable(False)
     if world > 1:
@@ -181,6 +198,7 @@ def main():
                     kernels[c]['frac_mfma_peak'] = gf[c] / per_step / PEAK_F32_MFMA_TFLOPS
         eng.timing_enable(False)
         out['kernels'] = kernels
+        log('breakdown done')
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(CFG_B, pool_host)
     elif rank == 0:

@@ -154,6 +154,8 @@ class FsmgModel(object):
 
     # -- parameters -------------------------------------------------------------------------
     def _shape(self, name):
+        if name not in self.param_shapes:
+            raise FsmgError(-5, "unknown parameter '%s'" % name)
         rows, cols = self.param_shapes[name]
         return (rows,) if cols == 1 else (rows, cols)
 
