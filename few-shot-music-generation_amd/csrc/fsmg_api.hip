@@ -75,6 +75,15 @@ struct fsmg_model {
     float *dC = nullptr, *dH = nullptr, *logits = nullptr, *lse = nullptr, *ce = nullptr, *dXemb = nullptr;
     double* partials = nullptr;
     int partials_cap = 0;
+    std::vector<float*> HF;             // fragment-ordered h per layer: [T+1][ceil(B/16)*16][Hp]
+    float* dzF = nullptr;               // fragment-ordered dz ping-pong: [2][ceil(B/16)*16][4Hp]
+    float* khf = nullptr;               // fragment-ordered recurrent weights: per layer fwd copy, bwd copy
+    bool khf_dirty = true;              // host wrote parameters since the last repack
+    float* slabs = nullptr;             // split-K partial outputs (shared by all GEMMs, stream ordered)
+    float* colsum_slabs = nullptr;
+    int64_t slab_cap = 0;
+    // whole-phase hipGraphs, keyed by the shape of the call; dropped when scratch moves
+    std::map<std::string, hipGraphExec_t> graphs;
     // decode
     float* dec = nullptr; int* dec_tok = nullptr;
 
@@ -244,6 +253,7 @@ int upload_tensor(fsmg_model* h, float* flat, const char* name, const float* hos
     pack_param(h, *p, host, seg.data());
     HIPCK(h, hipStreamSynchronize(h->stream));
     HIPCK(h, hipMemcpy(flat + p->off, seg.data(), sizeof(float) * p->count, hipMemcpyHostToDevice));
+    if (flat == h->P) h->khf_dirty = true;
     return FSMG_OK;
 }
 
@@ -258,10 +268,35 @@ int download_tensor(fsmg_model* h, const float* flat, const char* name, float* h
     return FSMG_OK;
 }
 
+
+// ------------------------------------------------------------------ split-K policy
+// A 128x128-tile GEMM with few output tiles leaves most of the 256 CUs (2 resident blocks each)
+// idle; splitting K multiplies the block count.  Cost model: MFMA time at ~100 TF/s divided by the
+// slot efficiency of tiles*S blocks over 512 slots, plus S slabs of C written and read back.
+constexpr int MAX_SPLIT = 16;
+int pick_split(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const double t_mfma = 2.0 * M * N * K / 100e12;
+    const double t_slab = 2.0 * M * N * 4.0 / 4e12;
+    int best = 1; double best_t = 1e30;
+    for (int S = 1; S <= MAX_SPLIT; ++S) {
+        if (S > 1 && K / S < 256) break;
+        const int64_t blocks = tiles * S;
+        const double eff = (double)blocks / (double)(((blocks + 511) / 512) * 512);
+        const double t = t_mfma / eff + (S > 1 ? S * t_slab : 0.0);
+        if (t < best_t - 1e-12) { best_t = t; best = S; }
+    }
+    return best;
+}
+
+
+void drop_graphs(fsmg_model* h);
+
 // ------------------------------------------------------------------ scratch
 int ensure_scratch(fsmg_model* h, int B) {
     if (B <= h->Bcap) return FSMG_OK;
     HIPCK(h, hipStreamSynchronize(h->stream));
+    drop_graphs(h);
     if (h->scratch) { HIPCK(h, hipFree(h->scratch)); h->scratch = nullptr; }
     const int64_t T = h->T, Hp = h->Hp, G4 = h->G4, rows = T * (int64_t)B;
     int64_t off = 0;
@@ -273,11 +308,27 @@ int ensure_scratch(fsmg_model* h, int B) {
         o_h[l] = place(4 * (T + 1) * B * Hp);
         o_c[l] = place(4 * (T + 1) * B * Hp);
     }
+    const int64_t Bp16 = (B + 15) / 16 * 16;
+    std::vector<int64_t> o_hf(h->L);
+    for (int l = 0; l < h->L; ++l) o_hf[l] = place(4 * (T + 1) * Bp16 * Hp);
+    const int64_t o_dzf = place(4 * 2 * Bp16 * G4);
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
     const int64_t o_lg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
     const int64_t o_dx = place(4 * rows * h->Ep);
     h->partials_cap = sqnorm_blocks(h->n_flat) + sqnorm_blocks(rows * h->Ep) + 8;
     const int64_t o_part = place(8 * (int64_t)h->partials_cap);
+    // split-K slabs: the largest S*M*N over the backward GEMMs of this shape
+    int64_t slab_need = 0;
+    {
+        auto need = [&](int64_t M, int64_t N, int64_t K) {
+            const int S = pick_split(M, N, K);
+            if (S > 1) slab_need = std::max(slab_need, (int64_t)S * M * N);
+        };
+        need(rows, Hp, h->V1p); need(Hp, h->V1p, rows); need(Hp, G4, rows);
+        need(h->Ep, G4, rows); need(rows, h->Ep, G4); need(rows, Hp, G4); need(rows, G4, h->Ep); need(rows, G4, Hp);
+    }
+    const int64_t o_slab = place(4 * std::max<int64_t>(slab_need, 64));
+    const int64_t o_cslab = place(4 * (int64_t)MAX_SPLIT * std::max<int64_t>(h->V1p, G4));
     hipError_t e = hipMalloc((void**)&h->scratch, off);
     if (e != hipSuccess) {
         h->Bcap = 0;
@@ -290,23 +341,96 @@ int ensure_scratch(fsmg_model* h, int B) {
     for (int l = 0; l < h->L; ++l) {
         h->Z[l] = (float*)(s + o_z[l]); h->Hs[l] = (float*)(s + o_h[l]); h->Cs[l] = (float*)(s + o_c[l]);
     }
+    h->HF.assign(h->L, nullptr);
+    for (int l = 0; l < h->L; ++l) h->HF[l] = (float*)(s + o_hf[l]);
+    h->dzF = (float*)(s + o_dzf);
+    // pad rows of the fragment buffers are never written: clear once so they hold finite values
+    HIPCK(h, hipMemsetAsync(s + o_hf[0], 0, (size_t)(o_dc - o_hf[0]), h->stream));
     h->dC = (float*)(s + o_dc); h->dH = (float*)(s + o_dh); h->logits = (float*)(s + o_lg);
     h->lse = (float*)(s + o_lse); h->ce = (float*)(s + o_ce); h->dXemb = (float*)(s + o_dx);
     h->partials = (double*)(s + o_part);
+    h->slabs = (float*)(s + o_slab); h->colsum_slabs = (float*)(s + o_cslab); h->slab_cap = slab_need;
     h->Bcap = B;
     return FSMG_OK;
 }
 
-// ------------------------------------------------------------------ the step pieces
-int stage_tokens(fsmg_model* h, const int32_t* support, int n_sup, const int32_t* query, int n_qry, int on_device) {
-    const int T = h->T;
-    const int* d_sup = support; const int* d_qry = query;
-    if (!on_device) {
-        if (n_sup > 0) HIPCK(h, hipMemcpyAsync(h->d_tok, support, sizeof(int) * (size_t)n_sup * T, hipMemcpyHostToDevice, h->stream));
-        if (n_qry > 0) HIPCK(h, hipMemcpyAsync(h->d_tok + (size_t)n_sup * T, query, sizeof(int) * (size_t)n_qry * T, hipMemcpyHostToDevice, h->stream));
-        d_sup = h->d_tok; d_qry = h->d_tok + (size_t)n_sup * T;
+
+void drop_graphs(fsmg_model* h) {
+    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+}
+
+// C (contiguous, ldc == N) = op(A) * op(B) with the K range split over pick_split() slabs that are
+// summed in a fixed order (deterministic); colsum likewise.
+int gemm(fsmg_model* h, int amode, int bmode, int atr, int btr, GemmArgs g) {
+    hipStream_t s = h->stream;
+    const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K) : 1;
+    if (S <= 1 || (int64_t)S * g.M * g.N > h->slab_cap) {
+        g.ksplit = 1;
+        HIPCK(h, launch_gemm(s, amode, bmode, atr, btr, g));
+        return FSMG_OK;
     }
-    HIPCK(h, launch_token_prep(h->stream, d_sup, n_sup, d_qry, n_qry, T, h->V, h->V, h->X, h->Y, h->d_err));
+    float* C = g.C; float* colsum = g.colsum;
+    const int64_t mn = (int64_t)g.M * g.N;
+    g.C = h->slabs; g.c_slab = mn; g.ksplit = S;
+    if (colsum) { g.colsum = h->colsum_slabs; g.colsum_slab = g.N; }
+    HIPCK(h, launch_gemm(s, amode, bmode, atr, btr, g));
+    HIPCK(h, launch_reduce_slabs(s, h->slabs, mn, S, C, mn));
+    if (colsum) HIPCK(h, launch_reduce_slabs(s, h->colsum_slabs, g.N, S, colsum, g.N));
+    return FSMG_OK;
+}
+#define GEMMCK(call) do { int rc_ = (call); if (rc_ != FSMG_OK) return rc_; } while (0)
+
+// Run `body` (a pure sequence of stream-ordered launches with call-invariant arguments) through a
+// cached hipGraph: captured on first use for this key, replayed afterwards.  The ~300 launches of a
+// step (one per time step and direction) then cost one hipGraphLaunch on the host.  Event timing
+// needs eager launches, so graphs are bypassed while it is on.
+template <class F>
+int run_graphed(fsmg_model* h, const std::string& key, F&& body) {
+    if (!h->cfg.use_graph || h->timing) return body();
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        HIPCK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = body();
+        const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        if (rc != FSMG_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess || graph == nullptr)
+            return fail(h, FSMG_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ei != hipSuccess) return fail(h, FSMG_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+        it = h->graphs.emplace(key, exec).first;
+    }
+    HIPCK(h, hipGraphLaunch(it->second, h->stream));
+    return FSMG_OK;
+}
+
+// ------------------------------------------------------------------ the step pieces
+// host-side parameter writes (init / set_param / restore) leave the fragment-ordered weight copies stale
+int ensure_khf(fsmg_model* h) {
+    if (!h->khf_dirty) return FSMG_OK;
+    for (int l = 0; l < h->L; ++l)
+        HIPCK(h, launch_repack_kh(h->stream, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
+                                  h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
+    h->khf_dirty = false;
+    return FSMG_OK;
+}
+
+// tokens -> the handle's fixed staging buffer (H2D or D2D), so that every later launch has
+// call-invariant arguments and can live in a replayed graph
+int stage_tokens(fsmg_model* h, const int32_t* support, int n_sup, const int32_t* query, int n_qry, int on_device) {
+    const size_t T = h->T;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (n_sup > 0) HIPCK(h, hipMemcpyAsync(h->d_tok, support, sizeof(int) * n_sup * T, kind, h->stream));
+    if (n_qry > 0) HIPCK(h, hipMemcpyAsync(h->d_tok + n_sup * T, query, sizeof(int) * n_qry * T, kind, h->stream));
+    return FSMG_OK;
+}
+
+int token_prep(fsmg_model* h, int n_sup, int n_qry) {
+    HIPCK(h, launch_token_prep(h->stream, h->d_tok, n_sup, h->d_tok + (size_t)n_sup * h->T, n_qry, h->T, h->V, h->V,
+                               h->X, h->Y, h->d_err));
     return FSMG_OK;
 }
 
@@ -315,7 +439,9 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     const int64_t rows = (int64_t)T * B;
     hipStream_t s = h->stream;
     for (int l = 0; l < h->L; ++l) {
+        const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
         HIPCK(h, hipMemsetAsync(h->Hs[l], 0, sizeof(float) * (size_t)B * Hp, s));
+        HIPCK(h, hipMemsetAsync(h->HF[l], 0, sizeof(float) * Bp16 * Hp, s));
         HIPCK(h, hipMemsetAsync(h->Cs[l], 0, sizeof(float) * (size_t)B * Hp, s));
         {
             ScopedTimer tm(h, "gemm_zx");
@@ -325,14 +451,15 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             g.B = h->P + h->off_kx[l]; g.ldb = G4;
             g.C = h->Z[l]; g.ldc = G4; g.M = (int)rows; g.N = G4;
             g.bias = h->P + h->off_b[l]; g.ksplit = 1;
-            HIPCK(h, launch_gemm(s, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
+            GEMMCK(gemm(h, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
         }
         {
             ScopedTimer tm(h, "lstm_fwd");
             for (int t = 0; t < T; ++t) {
                 LstmFwdArgs a{};
-                a.Kh = h->P + h->off_kh[l];
-                a.h_prev = h->Hs[l] + (size_t)t * B * Hp;
+                a.KhF = h->khf + (size_t)(2 * l) * Hp * G4;
+                a.hF_prev = h->HF[l] + (size_t)t * Bp16 * Hp;
+                a.hF_next = h->HF[l] + (size_t)(t + 1) * Bp16 * Hp;
                 a.z = h->Z[l] + (size_t)t * B * G4;
                 a.c_prev = h->Cs[l] + (size_t)t * B * Hp;
                 a.c_next = h->Cs[l] + (size_t)(t + 1) * B * Hp;
@@ -349,7 +476,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
         g.B = h->P + h->off_w; g.ldb = h->V1p;
         g.C = h->logits; g.ldc = h->V1p; g.M = (int)rows; g.N = h->V1p; g.K = Hp;
         g.bias = h->P + h->off_d; g.ksplit = 1;
-        HIPCK(h, launch_gemm(s, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
+        GEMMCK(gemm(h, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
     }
     {
         ScopedTimer tm(h, "ce");
@@ -373,7 +500,7 @@ int backward(fsmg_model* h, int B) {
         g.A = h->logits; g.lda = h->V1p; g.B = h->P + h->off_w; g.ldb = h->V1p;
         g.C = h->dH; g.ldc = Hp; g.M = (int)rows; g.N = Hp; g.K = h->V1p;
         g.lse = h->lse; g.tgt = h->Y; g.inv_n = inv_n; g.n_vocab = h->V1; g.ksplit = 1;
-        HIPCK(h, launch_gemm(s, OP_KC, OP_KC, TR_DLOGITS, TR_NONE, g));
+        GEMMCK(gemm(h, OP_KC, OP_KC, TR_DLOGITS, TR_NONE, g));
     }
     {
         ScopedTimer tm(h, "gemm_dw");        // dW = Hout^T * dlogits, dd = colsum(dlogits)
@@ -382,7 +509,7 @@ int backward(fsmg_model* h, int B) {
         g.C = h->G + h->off_w; g.ldc = h->V1p; g.M = Hp; g.N = h->V1p; g.K = (int)rows;
         g.lse = h->lse; g.tgt = h->Y; g.inv_n = inv_n; g.n_vocab = h->V1;
         g.colsum = h->G + h->off_d; g.ksplit = 1;
-        HIPCK(h, launch_gemm(s, OP_XC, OP_XC, TR_NONE, TR_DLOGITS, g));
+        GEMMCK(gemm(h, OP_XC, OP_XC, TR_NONE, TR_DLOGITS, g));
     }
     for (int l = h->L - 1; l >= 0; --l) {
         HIPCK(h, hipMemsetAsync(h->dC, 0, sizeof(float) * (size_t)B * Hp, s));
@@ -390,8 +517,10 @@ int backward(fsmg_model* h, int B) {
             ScopedTimer tm(h, "lstm_bwd");
             for (int t = T - 1; t >= 0; --t) {
                 LstmBwdArgs a{};
-                a.Kh = h->P + h->off_kh[l];
-                a.dz_next = (t + 1 < T) ? h->Z[l] + (size_t)(t + 1) * B * G4 : nullptr;
+                const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
+                a.KhF = h->khf + (size_t)(2 * l + 1) * Hp * G4;
+                a.dzF_next = (t + 1 < T) ? h->dzF + (size_t)((t + 1) & 1) * Bp16 * G4 : nullptr;
+                a.dzF_cur = h->dzF + (size_t)(t & 1) * Bp16 * G4;
                 a.gates = h->Z[l] + (size_t)t * B * G4;
                 a.c_t = h->Cs[l] + (size_t)(t + 1) * B * Hp;
                 a.c_prev = h->Cs[l] + (size_t)t * B * Hp;
@@ -408,13 +537,13 @@ int backward(fsmg_model* h, int B) {
             g.A = h->Hs[l]; g.lda = Hp; g.B = h->Z[l]; g.ldb = G4;
             g.C = h->G + h->off_kh[l]; g.ldc = G4; g.M = Hp; g.N = G4; g.K = (int)rows;
             g.colsum = h->G + h->off_b[l]; g.ksplit = 1;
-            HIPCK(h, launch_gemm(s, OP_XC, OP_XC, TR_NONE, TR_NONE, g));
+            GEMMCK(gemm(h, OP_XC, OP_XC, TR_NONE, TR_NONE, g));
             GemmArgs k{};                     // dKx = in^T * dZ
             if (l == 0) { k.A = h->P + h->off_emb; k.lda = h->Ep; k.gather = h->X; }
             else { k.A = h->Hs[l - 1] + (size_t)B * Hp; k.lda = Hp; }
             k.B = h->Z[l]; k.ldb = G4; k.C = h->G + h->off_kx[l]; k.ldc = G4;
             k.M = in_p; k.N = G4; k.K = (int)rows; k.ksplit = 1;
-            HIPCK(h, launch_gemm(s, OP_XC, OP_XC, TR_NONE, TR_NONE, k));
+            GEMMCK(gemm(h, OP_XC, OP_XC, TR_NONE, TR_NONE, k));
         }
         {
             ScopedTimer tm(h, "gemm_dx");     // d_in = dZ * Kx^T
@@ -422,7 +551,7 @@ int backward(fsmg_model* h, int B) {
             g.A = h->Z[l]; g.lda = G4; g.B = h->P + h->off_kx[l]; g.ldb = G4;
             g.C = (l == 0) ? h->dXemb : h->dH; g.ldc = in_p;
             g.M = (int)rows; g.N = in_p; g.K = G4; g.ksplit = 1;
-            HIPCK(h, launch_gemm(s, OP_KC, OP_KC, TR_NONE, TR_NONE, g));
+            GEMMCK(gemm(h, OP_KC, OP_KC, TR_NONE, TR_NONE, g));
         }
     }
     {
@@ -450,6 +579,9 @@ int apply_update(fsmg_model* h, float grad_scale) {
     a.grad_scale = grad_scale; a.lr = h->cfg.lr; a.n_decay = h->cfg.n_decay; a.clip = h->cfg.max_grad_norm;
     a.step = h->d_step; a.gnorm_out = h->d_gnorm;
     HIPCK(h, launch_adam_update(s, a));
+    for (int l = 0; l < h->L; ++l)           // refresh the fragment-ordered recurrent weights
+        HIPCK(h, launch_repack_kh(s, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
+                                  h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
     HIPCK(h, launch_step_increment(s, h->d_step, h->G + h->n_flat + 1, grad_scale, h->d_ring, RING_CAP));
     h->have_grads = false;
     return FSMG_OK;
@@ -557,6 +689,8 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (hipMalloc((void**)&h->dec, sizeof(float) * fl + 256) != hipSuccess) return bail(FSMG_ERR_NOMEM, "hipMalloc(decode) failed");
         h->dec_tok = (int*)(h->dec + fl);
     }
+    if (hipMalloc((void**)&h->khf, sizeof(float) * (size_t)h->L * 2 * h->Hp * h->G4) != hipSuccess)
+        return bail(FSMG_ERR_NOMEM, "hipMalloc(fragment weights) failed");
     const int b0 = cfg->max_sequences > 0 ? cfg->max_sequences : 45;
     if (ensure_scratch(h, b0) != FSMG_OK) { std::string e = h->err; return bail(FSMG_ERR_NOMEM, e); }
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(FSMG_ERR_HIP, "stream sync failed");
@@ -569,9 +703,11 @@ int fsmg_destroy(fsmg_handle h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     drain_timers(h);
+    drop_graphs(h);
     if (h->scratch) hipFree(h->scratch);
     if (h->d_step) hipFree(h->d_step);
     if (h->dec) hipFree(h->dec);
+    if (h->khf) hipFree(h->khf);
     if (h->d_eval) hipFree(h->d_eval);
     if (h->own_state && h->state) hipFree(h->state);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -677,9 +813,19 @@ int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* 
     if (rc != FSMG_OK) return rc;
     const int B = N * (K + Q);
     if ((rc = ensure_scratch(h, B)) != FSMG_OK) return rc;
+    if ((rc = ensure_khf(h)) != FSMG_OK) return rc;
     if ((rc = stage_tokens(h, support, N * K, query, N * Q, tokens_on_device)) != FSMG_OK) return rc;
-    if ((rc = forward(h, B, B, 1, h->G + h->n_flat + 1)) != FSMG_OK) return rc;
-    return backward(h, B);
+    const int n_sup = N * K, n_qry = N * Q;
+    rc = run_graphed(h, "fb:" + std::to_string(n_sup) + ":" + std::to_string(n_qry), [&]() -> int {
+        int r = token_prep(h, n_sup, n_qry);
+        if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1);
+        if (r == FSMG_OK) r = backward(h, B);
+        return r;
+    });
+    if (rc != FSMG_OK) return rc;
+    h->lastB = B;
+    h->have_grads = true;
+    return FSMG_OK;
 }
 
 int fsmg_grad_buffer(fsmg_handle h, void** device_ptr, int64_t* count) {
@@ -694,8 +840,10 @@ int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss) {
     hipSetDevice(h->device);
     if (!h->have_grads) return fail(h, FSMG_ERR_STATE, "fsmg_apply_update without a preceding fsmg_forward_backward");
     if (!(grad_scale > 0.f)) return fail(h, FSMG_ERR_INVALID, "grad_scale must be > 0");
-    int rc = apply_update(h, grad_scale);
+    uint32_t bits; std::memcpy(&bits, &grad_scale, 4);
+    int rc = run_graphed(h, "up:" + std::to_string(bits), [&]() -> int { return apply_update(h, grad_scale); });
     if (rc != FSMG_OK) return rc;
+    h->have_grads = false;
     if (loss) return check_tokens_and_read(h, h->G + h->n_flat + 1, grad_scale, loss, 1);
     return FSMG_OK;
 }
@@ -716,6 +864,7 @@ int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, i
     const int per = N * Q;
     if (per <= 0) return fail(h, FSMG_ERR_INVALID, "empty query set");
     if ((rc = ensure_scratch(h, per)) != FSMG_OK) return rc;
+    if ((rc = ensure_khf(h)) != FSMG_OK) return rc;
     const int chunk_eps = h->Bcap / per;
     if (h->eval_cap < chunk_eps) {
         HIPCK(h, hipStreamSynchronize(h->stream));
@@ -728,7 +877,13 @@ int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, i
         const int B = ne * per;
         const int32_t* q = queries + (size_t)e0 * per * h->T;
         if ((rc = stage_tokens(h, q, 0, q, B, tokens_on_device)) != FSMG_OK) return rc;
-        if ((rc = forward(h, B, per, ne, h->d_eval)) != FSMG_OK) return rc;
+        rc = run_graphed(h, "ev:" + std::to_string(per) + ":" + std::to_string(ne), [&]() -> int {
+            int r = token_prep(h, 0, B);
+            if (r == FSMG_OK) r = forward(h, B, per, ne, h->d_eval);
+            return r;
+        });
+        if (rc != FSMG_OK) return rc;
+        h->lastB = B;
         if ((rc = check_tokens_and_read(h, h->d_eval, 1.0f, nll + e0, ne)) != FSMG_OK) return rc;
     }
     return FSMG_OK;
@@ -822,6 +977,44 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
     if (count > cap) return fail(h, FSMG_ERR_SIZE, "debug read larger than the buffer");
     HIPCK(h, hipStreamSynchronize(h->stream));
     HIPCK(h, hipMemcpy(host, src, sizeof(float) * count, hipMemcpyDeviceToHost));
+    return FSMG_OK;
+}
+
+int fsmg_debug_step_profile(fsmg_handle h, int32_t which, uint64_t* stamps, int64_t cap, int32_t* n_blocks,
+                            int32_t* n_waves) {
+    if (!h || !stamps || !n_blocks || !n_waves || h->lastB <= 0 || h->T < 3) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    const int B = h->lastB, Hp = h->Hp, G4 = h->G4, l = h->L - 1, t = h->T / 2;
+    const int nb = which == 0 ? (G4 / 16) * ((B + 15) / 16) : (Hp / 16) * ((B + 15) / 16);
+    const int nw = which == 0 ? 4 : 8;
+    const int64_t n = (int64_t)nb * nw * 8;
+    if (cap < n) return fail(h, FSMG_ERR_SIZE, "stamp buffer too small");
+    unsigned long long* d = nullptr;
+    HIPCK(h, hipMalloc((void**)&d, sizeof(unsigned long long) * n));
+    HIPCK(h, hipMemsetAsync(d, 0, sizeof(unsigned long long) * n, h->stream));
+    for (int rep = 0; rep < 3; ++rep) {        // last repetition is the one read back (warm instruction cache)
+        if (which == 0) {
+            LstmFwdArgs a{};
+            const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
+            a.KhF = h->khf + (size_t)(2 * l) * Hp * G4; a.hF_prev = h->HF[l] + (size_t)t * Bp16 * Hp;
+            a.hF_next = h->HF[l] + (size_t)(t + 1) * Bp16 * Hp; a.z = h->Z[l] + (size_t)t * B * G4;
+            a.c_prev = h->Cs[l] + (size_t)t * B * Hp; a.c_next = h->Cs[l] + (size_t)(t + 1) * B * Hp;
+            a.h_next = h->Hs[l] + (size_t)(t + 1) * B * Hp; a.B = B; a.Hp = Hp;
+            HIPCK(h, launch_lstm_fwd_step(h->stream, a, d));
+        } else {
+            LstmBwdArgs a{};
+            const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
+            a.KhF = h->khf + (size_t)(2 * l + 1) * Hp * G4; a.dzF_next = h->dzF + (size_t)((t + 1) & 1) * Bp16 * G4;
+            a.dzF_cur = h->dzF + (size_t)(t & 1) * Bp16 * G4; a.gates = h->Z[l] + (size_t)t * B * G4;
+            a.c_t = h->Cs[l] + (size_t)(t + 1) * B * Hp; a.c_prev = h->Cs[l] + (size_t)t * B * Hp; a.dc = h->dC;
+            a.dh_top = h->dH + (size_t)t * B * Hp; a.B = B; a.Hp = Hp;
+            HIPCK(h, launch_lstm_bwd_step(h->stream, a, d));
+        }
+    }
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipMemcpy(stamps, d, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    hipFree(d);
+    *n_blocks = nb; *n_waves = nw;
     return FSMG_OK;
 }
 

@@ -42,19 +42,23 @@ hipError_t launch_reduce_slabs(hipStream_t s, const float* slabs, long long slab
 
 // ---------------------------------------------------------------- recurrent steps (lstm_step.hip)
 struct LstmFwdArgs {
-    const float* Kh;     // [Hp][4Hp] recurrent weights, packed gate columns
-    const float* h_prev; // [B][Hp]
+    const float* KhF;     // fragment-ordered recurrent weights (forward copy, see k_repack_kh)
+    const float* hF_prev; // fragment-ordered h_{t-1}: [ceil(B/16)][Hp/16][64 lanes][4]
+    float* hF_next;       // fragment-ordered h_t (written for step t+1)
     float* z;            // [B][4Hp] in: x-part pre-activations (+bias); out: activated gates i,j,f,o
     const float* c_prev; // [B][Hp]
     float* c_next;       // [B][Hp]
     float* h_next;       // [B][Hp]
     int B, Hp;
 };
-hipError_t launch_lstm_fwd_step(hipStream_t s, const LstmFwdArgs& a);
+// prof != nullptr selects the instrumented build: per wave 8 s_memtime stamps (entry, loads landed,
+// partials in LDS, past the barrier, done)
+hipError_t launch_lstm_fwd_step(hipStream_t s, const LstmFwdArgs& a, unsigned long long* prof = nullptr);
 
 struct LstmBwdArgs {
-    const float* Kh;      // [Hp][4Hp]
-    const float* dz_next; // [B][4Hp] dz of step t+1 (nullptr at the last step)
+    const float* KhF;      // fragment-ordered recurrent weights (backward copy)
+    const float* dzF_next; // fragment-ordered dz of step t+1: [ceil(B/16)][4Hp/16][64][4] (nullptr at the last step)
+    float* dzF_cur;        // fragment-ordered dz of step t (written for step t-1)
     float* gates;         // [B][4Hp] in: activated gates of step t; out: dz of step t
     const float* c_t;     // [B][Hp]
     const float* c_prev;  // [B][Hp]
@@ -62,7 +66,9 @@ struct LstmBwdArgs {
     const float* dh_top;  // [B][Hp] gradient arriving from above at step t
     int B, Hp;
 };
-hipError_t launch_lstm_bwd_step(hipStream_t s, const LstmBwdArgs& a);
+hipError_t launch_lstm_bwd_step(hipStream_t s, const LstmBwdArgs& a, unsigned long long* prof = nullptr);
+// recurrent weights [Hp][4Hp] -> the forward and backward fragment-ordered copies (Hp*4Hp floats each)
+hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp);
 
 // ---------------------------------------------------------------- everything else (elementwise.hip)
 // tokens [nseq][T] (support rows then query rows) -> time-major input ids X[t][b] (start word at t=0)

@@ -12,6 +12,13 @@
 // A[m][k_q] and B[k_q][n].  Any bijection slot->k is valid as long as A and B agree, so within
 // a group of 16 k's slot q takes k = 16g + 4q + s at sub-step s: every lane then reads its
 // four k's as ONE 16-byte load from the row-major activations instead of four strided dwords.
+//
+// Fragment-ordered operands: a row-major operand makes every wave-load touch 16 rows x 64 B (half cache
+// lines; measured 14-24 B/cycle/CU).  Both MFMA operands are therefore ALSO kept in "fragment order":
+// [tile][k-group g][lane][4 floats] with lane = 16*q + (row or column), so the load for one k-group is a
+// single contiguous 1 KiB per wave.  The weights are repacked once per Adam step (k_repack_kh), the
+// activations (h_t forward, dz_t backward) are written in fragment order by the epilogue of the step
+// that produces them, next to the row-major copy the big GEMMs consume.
 #include "fsmg_kernels.h"
 
 namespace fsmg {
@@ -23,143 +30,233 @@ namespace {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---------------------------------------------------------------- forward
-// grid (4Hp/16, ceil(B/48)); 256 threads = 4 waves, wave w owns a quarter of the K = Hp range.
-constexpr int FWD_ROWS = 48;
-__global__ __launch_bounds__(256) void k_lstm_fwd_step(const LstmFwdArgs a) {
-    __shared__ float red[4][FWD_ROWS][17];
+// grid (4Hp/16, ceil(B/16)); 256 threads = 4 waves, wave w owns a quarter of the K = Hp range.
+// Every operand of a wave's K range is requested before the first MFMA (the loop over groups is
+// unrolled in chunks of FWD_CHUNK with all loads hoisted), so a step pays ONE memory latency, not
+// one per k-group; the cell inputs of the epilogue (x-part pre-activations, c_{t-1}) are
+// prefetched by wave 0 at kernel entry as well.
+// N k-groups (16 k's each): all 2N 16-byte loads are issued before the first of the 4N MFMAs; no predicates.
+template <int N>
+__device__ __forceinline__ void fwd_chunk(const float4* __restrict__ af, const float4* __restrict__ bf, int g0,
+                                          f32x4& acc0, f32x4& acc1) {
+    float4 av[N], bv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        av[j] = af[(g0 + j) * 64];
+        bv[j] = bf[(g0 + j) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);      // keep every load ahead of the first MFMA (one latency per chunk)
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        f32x4& acc = (j & 1) ? acc1 : acc0;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc, 0, 0, 0);
+    }
+}
+
+#define FSMG_STAMP(i)                                                                                  \
+    if (PROF && lane == 0)                                                                              \
+        prof[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime()
+
+template <bool PROF>
+__global__ __launch_bounds__(256) void k_lstm_fwd_step(const LstmFwdArgs a, unsigned long long* prof) {
+    __shared__ float red[4][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     const int nb = blockIdx.x;           // unit block: units 4nb..4nb+3, packed cols 16nb..16nb+15
-    const int m0 = blockIdx.y * FWD_ROWS;
+    const int m0 = blockIdx.y * 16;
     const int Hp = a.Hp, G4 = 4 * a.Hp;
+    FSMG_STAMP(0);
+
+    // epilogue operands (wave 0: thread -> (row, unit))
+    const int erow = tid >> 2, euu = tid & 3;
+    const int eb = m0 + erow;
+    const bool eact = (tid < 64) && (eb < a.B);
+    float zin[4] = {0.f, 0.f, 0.f, 0.f};
+    float cp = 0.f;
+    float* zp = a.z + (long long)eb * G4 + 16 * nb + euu;
+    const int eu = 4 * nb + euu;
+    if (eact) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) zin[gi] = zp[4 * gi];
+        cp = a.c_prev[(long long)eb * Hp + eu];
+    }
 
     const int ngroups = Hp >> 4;
     const int g_beg = (wave * ngroups) >> 2, g_end = ((wave + 1) * ngroups) >> 2;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment-ordered operands: [tile][group][lane] float4 (pad rows of the last M tile feed discarded outputs)
+    const float4* af = reinterpret_cast<const float4*>(a.hF_prev) + ((size_t)blockIdx.y * ngroups) * 64 + lane;
+    const float4* bf = reinterpret_cast<const float4*>(a.KhF) + ((size_t)nb * ngroups) * 64 + lane;
 
-    f32x4 acc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const float* hrow[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int row = m0 + 16 * i + l15;
-        hrow[i] = (row < a.B) ? a.h_prev + (long long)row * Hp + 4 * q : nullptr;
-    }
-    const float* kcol = a.Kh + (long long)(4 * q) * G4 + 16 * nb + l15;
-
-    for (int g = g_beg; g < g_end; ++g) {
-        float4 av[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            av[i] = hrow[i] ? *reinterpret_cast<const float4*>(hrow[i] + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* kp = kcol + (long long)(16 * g) * G4;
-        const float b0 = kp[0], b1 = kp[G4], b2 = kp[2 * (long long)G4], b3 = kp[3 * (long long)G4];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, b0, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, b1, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, b2, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, b3, acc[i], 0, 0, 0);
-        }
-    }
+    int g = g_beg;
+    while (g + 8 <= g_end) { fwd_chunk<8>(af, bf, g, acc0, acc1); g += 8; }
+    if (g + 4 <= g_end) { fwd_chunk<4>(af, bf, g, acc0, acc1); g += 4; }
+    if (g + 2 <= g_end) { fwd_chunk<2>(af, bf, g, acc0, acc1); g += 2; }
+    if (g < g_end) fwd_chunk<1>(af, bf, g, acc0, acc1);
+    if (PROF) { __builtin_amdgcn_s_waitcnt(0); FSMG_STAMP(1); }        // all loads landed (profiling build only)
     // C/D layout 16x16: col = lane&15, row = 4*(lane>>4) + r
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][16 * i + 4 * q + r][l15] = acc[i][r];
+    for (int r = 0; r < 4; ++r) red[wave][4 * q + r][l15] = acc0[r] + acc1[r];
+    FSMG_STAMP(2);
     __syncthreads();
+    FSMG_STAMP(3);
 
-    if (tid < FWD_ROWS * 4) {
-        const int row = tid >> 2, uu = tid & 3;
-        const int b = m0 + row;
-        if (b < a.B) {
-            float zg[4];
-            float* zp = a.z + (long long)b * G4 + 16 * nb + uu;
+    if (eact) {
+        float zg[4];
 #pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-                const int c = 4 * gi + uu;
-                zg[gi] = zp[4 * gi] + ((red[0][row][c] + red[1][row][c]) + (red[2][row][c] + red[3][row][c]));
-            }
-            const int u = 4 * nb + uu;
-            const float si = sigmoidf_(zg[0]);
-            const float tj = tanhf(zg[1]);
-            const float sf = sigmoidf_(zg[2] + 1.0f);          // forget_bias = 1 added at run time
-            const float so = sigmoidf_(zg[3]);
-            const float cp = a.c_prev[(long long)b * Hp + u];
-            const float cn = cp * sf + si * tj;
-            a.c_next[(long long)b * Hp + u] = cn;
-            a.h_next[(long long)b * Hp + u] = tanhf(cn) * so;
-            zp[0] = si; zp[4] = tj; zp[8] = sf; zp[12] = so;  // activated gates kept for BPTT
+        for (int gi = 0; gi < 4; ++gi) {
+            const int c = 4 * gi + euu;
+            zg[gi] = zin[gi] + ((red[0][erow][c] + red[1][erow][c]) + (red[2][erow][c] + red[3][erow][c]));
         }
+        const float si = sigmoidf_(zg[0]);
+        const float tj = tanhf(zg[1]);
+        const float sf = sigmoidf_(zg[2] + 1.0f);          // forget_bias = 1 added at run time
+        const float so = sigmoidf_(zg[3]);
+        const float cn = cp * sf + si * tj;
+        const float hn = tanhf(cn) * so;
+        a.c_next[(long long)eb * Hp + eu] = cn;
+        a.h_next[(long long)eb * Hp + eu] = hn;
+        // fragment-ordered copy for the next step's A operand: group eu/16, slot q = (eu%16)/4, sub-step eu%4
+        a.hF_next[(((size_t)blockIdx.y * ngroups + (eu >> 4)) * 64 + 4 * (eu & 12) + erow) * 4 + (eu & 3)] = hn;
+        zp[0] = si; zp[4] = tj; zp[8] = sf; zp[12] = so;  // activated gates kept for BPTT
     }
+    FSMG_STAMP(4);
 }
 
 // ---------------------------------------------------------------- backward
 // grid (Hp/16, ceil(B/16)); 512 threads = 8 waves splitting K = 4Hp (packed gate columns).
-// dh_rec[b][u] = sum_pc dz_next[b][pc] * Kh[u][pc]; then the gate gradients of step t for the
-// block's 16 rows x 16 units.
-__global__ __launch_bounds__(512) void k_lstm_bwd_step(const LstmBwdArgs a) {
+// dh_rec[b][u] = sum_pc dz_{t+1}[b][pc] * Kh[u][pc]; then the gate gradients of step t for the
+// block's 16 rows x 16 units.  Same load-everything-first structure as the forward step.
+template <int N>
+__device__ __forceinline__ void bwd_chunk(const float4* __restrict__ af, const float4* __restrict__ bf, int g0,
+                                          f32x4& acc0, f32x4& acc1) {
+    float4 av[N], bv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        av[j] = af[(g0 + j) * 64];
+        bv[j] = bf[(g0 + j) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        f32x4& acc = (j & 1) ? acc1 : acc0;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc, 0, 0, 0);
+    }
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(512) void k_lstm_bwd_step(const LstmBwdArgs a, unsigned long long* prof) {
     __shared__ float red[8][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     const int u0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
     const int Hp = a.Hp, G4 = 4 * a.Hp;
+    FSMG_STAMP(0);
 
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.dz_next != nullptr) {
+    // epilogue operands (waves 0-3: thread -> (row, unit)), requested before the contraction
+    const int erow = tid >> 4, eun = tid & 15;
+    const int eb = m0 + erow, eu = u0 + eun;
+    const bool eact = (tid < 256) && (eb < a.B);
+    const long long hi = (long long)eb * Hp + eu;
+    float* gp = a.gates + (long long)eb * G4 + 16 * (eu >> 2) + (eu & 3);
+    float si = 0.f, tj = 0.f, sf = 0.f, so = 0.f, ct = 0.f, cp = 0.f, dcv = 0.f, dht = 0.f;
+    if (eact) {
+        si = gp[0]; tj = gp[4]; sf = gp[8]; so = gp[12];
+        ct = a.c_t[hi]; cp = a.c_prev[hi]; dcv = a.dc[hi]; dht = a.dh_top[hi];
+    }
+
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.dzF_next != nullptr) {
         const int ngroups = G4 >> 4;
         const int g_beg = (wave * ngroups) >> 3, g_end = ((wave + 1) * ngroups) >> 3;
-        const int row = m0 + l15;
-        const float* ap = (row < a.B) ? a.dz_next + (long long)row * G4 + 4 * q : nullptr;
-        const float* bp = a.Kh + (long long)(u0 + l15) * G4 + 4 * q;
-        for (int g = g_beg; g < g_end; ++g) {
-            const float4 av = ap ? *reinterpret_cast<const float4*>(ap + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 bv = *reinterpret_cast<const float4*>(bp + 16 * g);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
-        }
+        const float4* af = reinterpret_cast<const float4*>(a.dzF_next) + ((size_t)blockIdx.y * ngroups) * 64 + lane;
+        const float4* bf = reinterpret_cast<const float4*>(a.KhF) + ((size_t)blockIdx.x * ngroups) * 64 + lane;
+        int g = g_beg;
+        while (g + 16 <= g_end) { bwd_chunk<16>(af, bf, g, acc0, acc1); g += 16; }
+        if (g + 8 <= g_end) { bwd_chunk<8>(af, bf, g, acc0, acc1); g += 8; }
+        if (g + 4 <= g_end) { bwd_chunk<4>(af, bf, g, acc0, acc1); g += 4; }
+        if (g + 2 <= g_end) { bwd_chunk<2>(af, bf, g, acc0, acc1); g += 2; }
+        if (g < g_end) bwd_chunk<1>(af, bf, g, acc0, acc1);
     }
+    if (PROF) { __builtin_amdgcn_s_waitcnt(0); FSMG_STAMP(1); }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][4 * q + r][l15] = acc[r];
+    for (int r = 0; r < 4; ++r) red[wave][4 * q + r][l15] = acc0[r] + acc1[r];
+    FSMG_STAMP(2);
     __syncthreads();
+    FSMG_STAMP(3);
 
-    if (tid < 256) {
-        const int row = tid >> 4, un = tid & 15;
-        const int b = m0 + row, u = u0 + un;
-        if (b < a.B) {
-            float dh_rec = 0.0f;
+    if (eact) {
+        float dh_rec = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) dh_rec += red[w][row][un];
-            const long long hi = (long long)b * Hp + u;
-            float* gp = a.gates + (long long)b * G4 + 16 * (u >> 2) + (u & 3);
-            const float si = gp[0], tj = gp[4], sf = gp[8], so = gp[12];
-            const float ct = a.c_t[hi], cp = a.c_prev[hi];
-            const float tc = tanhf(ct);
-            const float dh = a.dh_top[hi] + dh_rec;
-            const float dc = a.dc[hi] + dh * so * (1.0f - tc * tc);
-            gp[0] = dc * tj * si * (1.0f - si);                 // di
-            gp[4] = dc * si * (1.0f - tj * tj);                 // dj
-            gp[8] = dc * cp * sf * (1.0f - sf);                 // df
-            gp[12] = dh * tc * so * (1.0f - so);                // do
-            a.dc[hi] = dc * sf;
+        for (int w = 0; w < 8; ++w) dh_rec += red[w][erow][eun];
+        const float tc = tanhf(ct);
+        const float dh = dht + dh_rec;
+        const float dc = dcv + dh * so * (1.0f - tc * tc);
+        const float di = dc * tj * si * (1.0f - si);
+        const float dj = dc * si * (1.0f - tj * tj);
+        const float df = dc * cp * sf * (1.0f - sf);
+        const float dg = dh * tc * so * (1.0f - so);
+        gp[0] = di; gp[4] = dj; gp[8] = df; gp[12] = dg;   // row-major dz for the weight-gradient GEMMs
+        // fragment-ordered copy for step t-1: packed column 16*(u/4) + 4*gate + u%4 -> group u/4, slot q = gate
+        float* fp = a.dzF_cur + (((size_t)blockIdx.y * (G4 >> 4) + (eu >> 2)) * 64 + erow) * 4 + (eu & 3);
+        fp[0] = di; fp[64] = dj; fp[128] = df; fp[192] = dg;
+        a.dc[hi] = dc * sf;
+    }
+    FSMG_STAMP(4);
+}
+
+// Kh [Hp][4Hp] (packed gate columns) -> the two fragment-ordered copies the step kernels stream:
+//   fwd: B[k][n = packed col], block nb = 16 cols:  KhF_fwd[nb][g][lane=16q+n][s] = Kh[16g+4q+s][16nb+n]
+//   bwd: B[k = packed col][n = unit], block ug:      KhF_bwd[ug][g][lane=16q+n][s] = Kh[16ug+n][16g+4q+s]
+__global__ void k_repack_kh(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd, int Hp) {
+    const int G4 = 4 * Hp;
+    const long long total = (long long)Hp * G4 / 4;            // float4 slots per copy
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), q = lane >> 4, n = lane & 15;
+        {   // forward copy
+            const int ng = Hp >> 4;
+            const int g = (int)((i >> 6) % ng), nb = (int)((i >> 6) / ng);
+            float4 v;
+            const float* src = Kh + (long long)(16 * g + 4 * q) * G4 + 16 * nb + n;
+            v.x = src[0]; v.y = src[G4]; v.z = src[2LL * G4]; v.w = src[3LL * G4];
+            reinterpret_cast<float4*>(fwd)[i] = v;
+        }
+        {   // backward copy
+            const int ng = G4 >> 4;
+            const int g = (int)((i >> 6) % ng), ug = (int)((i >> 6) / ng);
+            reinterpret_cast<float4*>(bwd)[i] =
+                *reinterpret_cast<const float4*>(Kh + (long long)(16 * ug + n) * G4 + 16 * g + 4 * q);
         }
     }
 }
 
 }  // namespace
 
-hipError_t launch_lstm_fwd_step(hipStream_t s, const LstmFwdArgs& a) {
-    dim3 grid((4 * a.Hp) / 16, (a.B + FWD_ROWS - 1) / FWD_ROWS);
-    hipLaunchKernelGGL(k_lstm_fwd_step, grid, dim3(256), 0, s, a);
+hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp) {
+    const long long total = (long long)Hp * 4 * Hp / 4;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_repack_kh, dim3(blocks), dim3(256), 0, s, Kh, fwd, bwd, Hp);
     return hipGetLastError();
 }
 
-hipError_t launch_lstm_bwd_step(hipStream_t s, const LstmBwdArgs& a) {
+hipError_t launch_lstm_fwd_step(hipStream_t s, const LstmFwdArgs& a, unsigned long long* prof) {
+    dim3 grid((4 * a.Hp) / 16, (a.B + 15) / 16);
+    if (prof) hipLaunchKernelGGL(k_lstm_fwd_step<true>, grid, dim3(256), 0, s, a, prof);
+    else hipLaunchKernelGGL(k_lstm_fwd_step<false>, grid, dim3(256), 0, s, a, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_lstm_bwd_step(hipStream_t s, const LstmBwdArgs& a, unsigned long long* prof) {
     dim3 grid(a.Hp / 16, (a.B + 15) / 16);
-    hipLaunchKernelGGL(k_lstm_bwd_step, grid, dim3(512), 0, s, a);
+    if (prof) hipLaunchKernelGGL(k_lstm_bwd_step<true>, grid, dim3(512), 0, s, a, prof);
+    else hipLaunchKernelGGL(k_lstm_bwd_step<false>, grid, dim3(512), 0, s, a, nullptr);
     return hipGetLastError();
 }
 

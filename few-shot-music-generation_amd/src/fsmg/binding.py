@@ -62,6 +62,7 @@ SIGNATURES = {
     'fsmg_read_losses': (C.c_int, [_P, _F32P, C.c_int32]),
     'fsmg_debug_read': (C.c_int, [_P, C.c_char_p, _F32P, C.c_int64]),
     'fsmg_debug_dims': (C.c_int, [_P, _I32P]),
+    'fsmg_debug_step_profile': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint64), C.c_int64, _I32P, _I32P]),
     'fsmg_timing_enable': (C.c_int, [_P, C.c_int32]),
     'fsmg_timing_select': (C.c_int, [_P, C.c_char_p]),
     'fsmg_timing_read': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -106,7 +107,7 @@ class FsmgModel(object):
     """One model handle == one LSTM language model resident on one MI355X."""
 
     def __init__(self, config, device=0, stream=None, state_arena=None, state_arena_bytes=0,
-                 max_sequences=0, clip_norm_mode='tf1_slices', use_graph=False):
+                 max_sequences=0, clip_norm_mode='tf1_slices', use_graph=True):
         self._lib = load_library()
         self.cfg = FsmgConfig(
             input_size=int(config['input_size']), max_len=int(config['max_len']),
@@ -287,6 +288,14 @@ class FsmgModel(object):
         out = np.empty(int(count), np.float32)
         self._ck(self._lib.fsmg_debug_read(self._h, what.encode(), _f32p(out), out.size))
         return out
+
+    def step_profile(self, which):
+        """-> uint64 [n_blocks, n_waves, 8] s_memtime stamps of one instrumented recurrent step kernel"""
+        buf = np.zeros(1 << 20, np.uint64)
+        nb, nw = C.c_int32(), C.c_int32()
+        self._ck(self._lib.fsmg_debug_step_profile(self._h, int(which), buf.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                   buf.size, C.byref(nb), C.byref(nw)))
+        return buf[:nb.value * nw.value * 8].reshape(nb.value, nw.value, 8)
 
     def timing_enable(self, on=True):
         self._ck(self._lib.fsmg_timing_enable(self._h, int(bool(on))))

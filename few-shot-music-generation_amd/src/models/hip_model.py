@@ -45,7 +45,7 @@ class HIPModel(BaseModel):
                                 state_arena=base + pad, state_arena_bytes=nbytes,
                                 max_sequences=int(config.get('max_sequences', 0)),
                                 clip_norm_mode=config.get('clip_norm_mode', 'tf1_slices'),
-                                use_graph=bool(config.get('use_graph', False)))
+                                use_graph=bool(config.get('use_graph', True)))
         gptr, gcount = self._model.grad_buffer()
         off = gptr - base
         self.grad_tensor = self._arena[off:off + 4 * gcount].view(torch.float32)

@@ -151,6 +151,11 @@ int fsmg_read_losses(fsmg_handle h, float* out, int32_t n);
 int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count);
 /* padded sizes: writes Ep, Hp, V1p, last B, T */
 int fsmg_debug_dims(fsmg_handle h, int32_t dims[5]);
+/* diagnostics: run ONE instrumented recurrent step kernel (which = 0 forward, 1 backward) at t = T/2 on the
+ * buffers of the last forward/backward (clobbers them) and return 8 s_memtime stamps per wave:
+ * [0] entry, [1] operands landed, [2] partials in LDS, [3] past the block barrier, [4] done.  cap >= n_blocks*n_waves*8 */
+int fsmg_debug_step_profile(fsmg_handle h, int32_t which, uint64_t* stamps, int64_t cap, int32_t* n_blocks,
+                            int32_t* n_waves);
 /* per-kernel-class HIP-event timing on the handle's stream (disables graph replay while on).
  * classes: "gemm_zx","lstm_fwd","gemm_logits","ce","gemm_dhout","gemm_dw","lstm_bwd",
  * "gemm_dk","gemm_dx","embed_grad","update" */

@@ -172,6 +172,33 @@ def test_device_resident_tokens_match_host_tokens():
     assert a.eval_step(qry) == b.eval_step(dq.data_ptr(), shape=(2, 1))
 
 
+def test_graph_replay_equals_eager_launches():
+    cfg = small_config(hidden_size=32, embedding_size=16, input_size=99, max_len=8, n_layers=2)
+    eps = O.synthetic_episodes(4, 3, 2, 2, cfg['max_len'], cfg['input_size'], seed=11)
+    out = []
+    for use_graph in (True, False):
+        model = new_model(cfg, use_graph=use_graph)
+        losses = [model.train_step(s, q) for s, q in eps]            # step 0 captures, 1.. replay
+        evals = [model.eval_step(q) for _, q in eps]
+        out.append((losses, evals, model.get_params()))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    for k in out[0][2]:
+        np.testing.assert_array_equal(out[0][2][k], out[1][2][k])
+
+
+def test_split_k_paths_match_oracle_at_wide_shapes():
+    """rows = 45*40 = 1800 with H=128: the dK / dH / dW GEMMs take the split-K + slab-reduce path."""
+    cfg = small_config(hidden_size=128, embedding_size=64, input_size=1500, max_len=40)
+    (sup, qry), = O.synthetic_episodes(1, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=2, realistic=True)
+    model = new_model(cfg)
+    params = f64_params(model)
+    loss, cache, grads, aux = oracle_step(params, sup, qry, cfg)
+    model.forward_backward(sup, qry)
+    assert abs(model.debug_read('tail', 16)[1] - loss) <= NLL_RTOL * abs(loss)
+    for name in grads:
+        assert rel_max(model.get_grad(name), grads[name]) < 2e-4, name
+
+
 def test_split_step_equals_fused_step():
     cfg = small_config()
     sup, qry = _episode(cfg, 2, 2, 1)
