@@ -14,7 +14,7 @@ With N > 1 every rank trains on its own episode per step and one RCCL all-reduce
 buffer (weak scaling: per-GPU work fixed); value = N * K / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (the dW = out^T * dlogits GEMM,
-k_gemm<XC,XC,NONE,DLOGITS>, one launch per step) timed with HIP events on the library's stream over a
+k_gemm<XC,XC,NONE,NONE>, one launch per step) timed with HIP events on the library's stream over a
 repeat of the timed steps; `kernels` (extra) is a per-class breakdown from a second, fully instrumented pass;
 `cpu_baseline` is the oracle's torch-CPU restatement of the same step ("port": TensorFlow cannot run here)
 on a bounded sample of the same workload.
@@ -175,7 +175,7 @@ def main():
             'config': {'workload': 'cfg-B: synthetic V=10000 (V1=10001) T=128 5-way 5-shot 4-query (B=45 sequences/episode), '
                                    'LSTM E=250 H=512 L=1, full train step (fwd+BPTT+clip+Adam), one episode per GPU per step',
                        'episodes_per_step': world, 'parallelism': 'episode-parallel x%d, 1 RCCL all-reduce/step' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_gemm<XC,XC,NONE,DLOGITS> (dW = out^T * dlogits, M=512 N=10004 K=5760)',
+            'roofline': {'bound': 'mfma', 'kernel': 'k_gemm<XC,XC,NONE,NONE> (dW = out^T * dlogits, M=512 N=10004 K=5760)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
                          'avg_launch_ms': dom_avg_ms, 'launches': dom_n, 'algorithmic_gflop_per_launch': gf[DOMINANT]},

@@ -49,10 +49,13 @@ __global__ void k_token_prep(const int* __restrict__ support, int n_support, con
 
 // ---------------------------------------------------------------- softmax cross entropy per row (K6)
 // One 256-thread block per logits row; pass 1 row max, pass 2 sum exp (second read is an L2 hit).
+// With dlogits != nullptr a third pass (the row is cache-hot) also writes the loss gradient
+// dlogits = (softmax - onehot) * inv_n for the two backward projection GEMMs, zero in the pad columns.
 __global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ logits, int ld, int n_vocab,
                                                  const int* __restrict__ tgt, float* __restrict__ lse,
-                                                 float* __restrict__ ce) {
+                                                 float* __restrict__ ce, float* __restrict__ dlogits, float inv_n) {
     __shared__ float sh[4];
+    __shared__ float s_lse;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = logits + (long long)r * ld;
     const int nv4 = n_vocab & ~3;
@@ -76,10 +79,25 @@ __global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ logit
     s = wave_sum(s);
     if (lane == 0) sh[wave] = s;
     __syncthreads();
+    const int t = tgt[r];
     if (tid == 0) {
         const float l = m + logf((sh[0] + sh[1]) + (sh[2] + sh[3]));
         lse[r] = l;
-        ce[r] = l - row[tgt[r]];
+        ce[r] = l - row[t];
+        s_lse = l;
+    }
+    if (dlogits == nullptr) return;
+    __syncthreads();
+    const float l = s_lse;
+    float* drow = dlogits + (long long)r * ld;
+    for (int v = 4 * tid; v < ld; v += 1024) {          // ld is a multiple of 4 and >= n_vocab
+        const float4 x = *reinterpret_cast<const float4*>(row + v);
+        float4 d;
+        d.x = (v + 0 < n_vocab) ? (expf(x.x - l) - (v + 0 == t ? 1.0f : 0.0f)) * inv_n : 0.0f;
+        d.y = (v + 1 < n_vocab) ? (expf(x.y - l) - (v + 1 == t ? 1.0f : 0.0f)) * inv_n : 0.0f;
+        d.z = (v + 2 < n_vocab) ? (expf(x.z - l) - (v + 2 == t ? 1.0f : 0.0f)) * inv_n : 0.0f;
+        d.w = (v + 3 < n_vocab) ? (expf(x.w - l) - (v + 3 == t ? 1.0f : 0.0f)) * inv_n : 0.0f;
+        *reinterpret_cast<float4*>(drow + v) = d;
     }
 }
 
@@ -316,9 +334,9 @@ hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, c
 }
 
 hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt,
-                          float* lse, float* ce) {
+                          float* lse, float* ce, float* dlogits, float inv_n) {
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_ce_rows, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce);
+    hipLaunchKernelGGL(k_ce_rows, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
     return hipGetLastError();
 }
 

@@ -72,7 +72,7 @@ struct fsmg_model {
     char* scratch = nullptr;
     int* d_tok = nullptr; int *X = nullptr, *Y = nullptr;
     std::vector<float*> Z, Hs, Cs;
-    float *dC = nullptr, *dH = nullptr, *logits = nullptr, *lse = nullptr, *ce = nullptr, *dXemb = nullptr;
+    float *dC = nullptr, *dH = nullptr, *logits = nullptr, *dlogits = nullptr, *lse = nullptr, *ce = nullptr, *dXemb = nullptr;
     double* partials = nullptr;
     int partials_cap = 0;
     std::vector<float*> HF;             // fragment-ordered h per layer: [T+1][ceil(B/16)*16][Hp]
@@ -313,7 +313,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     for (int l = 0; l < h->L; ++l) o_hf[l] = place(4 * (T + 1) * Bp16 * Hp);
     const int64_t o_dzf = place(4 * 2 * Bp16 * G4);
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
-    const int64_t o_lg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
+    const int64_t o_lg = place(4 * rows * h->V1p), o_dlg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
     const int64_t o_dx = place(4 * rows * h->Ep);
     h->partials_cap = sqnorm_blocks(h->n_flat) + sqnorm_blocks(rows * h->Ep) + 8;
     const int64_t o_part = place(8 * (int64_t)h->partials_cap);
@@ -347,6 +347,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     // pad rows of the fragment buffers are never written: clear once so they hold finite values
     HIPCK(h, hipMemsetAsync(s + o_hf[0], 0, (size_t)(o_dc - o_hf[0]), h->stream));
     h->dC = (float*)(s + o_dc); h->dH = (float*)(s + o_dh); h->logits = (float*)(s + o_lg);
+    h->dlogits = (float*)(s + o_dlg);
     h->lse = (float*)(s + o_lse); h->ce = (float*)(s + o_ce); h->dXemb = (float*)(s + o_dx);
     h->partials = (double*)(s + o_part);
     h->slabs = (float*)(s + o_slab); h->colsum_slabs = (float*)(s + o_cslab); h->slab_cap = slab_need;
@@ -434,7 +435,7 @@ int token_prep(fsmg_model* h, int n_sup, int n_qry) {
     return FSMG_OK;
 }
 
-int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_out) {
+int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_out, bool want_dlogits) {
     const int T = h->T, Hp = h->Hp, G4 = h->G4;
     const int64_t rows = (int64_t)T * B;
     hipStream_t s = h->stream;
@@ -480,7 +481,8 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     }
     {
         ScopedTimer tm(h, "ce");
-        HIPCK(h, launch_ce_rows(s, h->logits, h->V1p, (int)rows, h->V1, h->Y, h->lse, h->ce));
+        HIPCK(h, launch_ce_rows(s, h->logits, h->V1p, (int)rows, h->V1, h->Y, h->lse, h->ce,
+                                want_dlogits ? h->dlogits : nullptr, (float)(1.0 / ((double)rows + 1e-12))));
         HIPCK(h, launch_loss_reduce(s, h->ce, T, B, rows_per_group, ngroups, loss_out));
     }
     h->lastB = B;
@@ -491,25 +493,22 @@ int backward(fsmg_model* h, int B) {
     const int T = h->T, Hp = h->Hp, G4 = h->G4;
     const int64_t rows = (int64_t)T * B;
     hipStream_t s = h->stream;
-    const float inv_n = (float)(1.0 / ((double)rows + 1e-12));
     float* Hout = h->Hs[h->L - 1] + (size_t)B * Hp;
     HIPCK(h, hipMemsetAsync(h->G + h->off_emb, 0, sizeof(float) * (size_t)h->V1 * h->Ep, s));
     {
         ScopedTimer tm(h, "gemm_dhout");     // dH = dlogits * W^T
         GemmArgs g{};
-        g.A = h->logits; g.lda = h->V1p; g.B = h->P + h->off_w; g.ldb = h->V1p;
-        g.C = h->dH; g.ldc = Hp; g.M = (int)rows; g.N = Hp; g.K = h->V1p;
-        g.lse = h->lse; g.tgt = h->Y; g.inv_n = inv_n; g.n_vocab = h->V1; g.ksplit = 1;
-        GEMMCK(gemm(h, OP_KC, OP_KC, TR_DLOGITS, TR_NONE, g));
+        g.A = h->dlogits; g.lda = h->V1p; g.B = h->P + h->off_w; g.ldb = h->V1p;
+        g.C = h->dH; g.ldc = Hp; g.M = (int)rows; g.N = Hp; g.K = h->V1p; g.ksplit = 1;
+        GEMMCK(gemm(h, OP_KC, OP_KC, TR_NONE, TR_NONE, g));
     }
     {
         ScopedTimer tm(h, "gemm_dw");        // dW = Hout^T * dlogits, dd = colsum(dlogits)
         GemmArgs g{};
-        g.A = Hout; g.lda = Hp; g.B = h->logits; g.ldb = h->V1p;
+        g.A = Hout; g.lda = Hp; g.B = h->dlogits; g.ldb = h->V1p;
         g.C = h->G + h->off_w; g.ldc = h->V1p; g.M = Hp; g.N = h->V1p; g.K = (int)rows;
-        g.lse = h->lse; g.tgt = h->Y; g.inv_n = inv_n; g.n_vocab = h->V1;
         g.colsum = h->G + h->off_d; g.ksplit = 1;
-        GEMMCK(gemm(h, OP_XC, OP_XC, TR_NONE, TR_DLOGITS, g));
+        GEMMCK(gemm(h, OP_XC, OP_XC, TR_NONE, TR_NONE, g));
     }
     for (int l = h->L - 1; l >= 0; --l) {
         HIPCK(h, hipMemsetAsync(h->dC, 0, sizeof(float) * (size_t)B * Hp, s));
@@ -818,7 +817,7 @@ int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* 
     const int n_sup = N * K, n_qry = N * Q;
     rc = run_graphed(h, "fb:" + std::to_string(n_sup) + ":" + std::to_string(n_qry), [&]() -> int {
         int r = token_prep(h, n_sup, n_qry);
-        if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1);
+        if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1, true);
         if (r == FSMG_OK) r = backward(h, B);
         return r;
     });
@@ -879,7 +878,7 @@ int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, i
         if ((rc = stage_tokens(h, q, 0, q, B, tokens_on_device)) != FSMG_OK) return rc;
         rc = run_graphed(h, "ev:" + std::to_string(per) + ":" + std::to_string(ne), [&]() -> int {
             int r = token_prep(h, 0, B);
-            if (r == FSMG_OK) r = forward(h, B, per, ne, h->d_eval);
+            if (r == FSMG_OK) r = forward(h, B, per, ne, h->d_eval, false);
             return r;
         });
         if (rc != FSMG_OK) return rc;
@@ -964,6 +963,7 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
     };
     int l;
     if (!std::strcmp(what, "logits")) { src = h->logits; cap = rows * h->V1p; }
+    else if (!std::strcmp(what, "dlogits")) { src = h->dlogits; cap = rows * h->V1p; }
     else if (!std::strcmp(what, "lse")) { src = h->lse; cap = rows; }
     else if (!std::strcmp(what, "ce")) { src = h->ce; cap = rows; }
     else if (!std::strcmp(what, "dx")) { src = h->dXemb; cap = rows * h->Ep; }

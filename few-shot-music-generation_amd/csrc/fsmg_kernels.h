@@ -75,9 +75,10 @@ hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* b
 // and targets Y[t][b]; sets *err_flag if any id is outside [0, vocab).
 hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, const int* query, int n_query,
                              int T, int vocab, int start_word, int* X, int* Y, int* err_flag);
-// per logits row: lse and cross entropy against the target
+// per logits row: lse and cross entropy against the target; dlogits != nullptr also materialises
+// (softmax - onehot) * inv_n (pad columns zero) for the backward projection GEMMs
 hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt,
-                          float* lse, float* ce);
+                          float* lse, float* ce, float* dlogits, float inv_n);
 // out[g] = sum over t and b in group g of ce[t*B+b] / (T*rows_per_group + 1e-12); fixed order
 hipError_t launch_loss_reduce(hipStream_t s, const float* ce, int T, int B, int rows_per_group, int ngroups,
                               float* out);
