@@ -67,7 +67,7 @@ def cpu_baseline(cfg, pool, budget_s=20.0):
     from oracle import lstm_oracle as O
     from oracle.torch_ref import TorchRef
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    cores = min(avail, int(os.environ.get('FSMG_CPU_THREADS', 32)))   # 45-row GEMMs stop scaling long before 32 threads
+    cores = min(avail, int(os.environ.get('FSMG_CPU_THREADS', 16)))   # measured on the 2x EPYC 9575F host: 8/16/32/64/128 threads -> 0.49/0.57/0.45/0.24/0.09 episodes/s
     ref = TorchRef(cfg, O.glorot_init(cfg, cfg['seed'], np.float32), dtype=torch.float32, threads=cores)
     log('cpu_baseline: %d threads (of %d available), warm-up step' % (cores, avail))
     ref.train(*pool[0])                                   # warm-up

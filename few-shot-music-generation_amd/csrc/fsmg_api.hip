@@ -79,8 +79,15 @@ struct fsmg_model {
     float* dzF = nullptr;               // fragment-ordered dz ping-pong: [2][ceil(B/16)*16][4Hp]
     float* khf = nullptr;               // fragment-ordered recurrent weights: per layer fwd copy, bwd copy
     bool khf_dirty = true;              // host wrote parameters since the last repack
-    float* slabs = nullptr;             // split-K partial outputs (shared by all GEMMs, stream ordered)
+    float* slabs = nullptr;             // split-K partial outputs of the GEMMs on the main stream
     float* colsum_slabs = nullptr;
+    float* slabs2 = nullptr;            // ... and of the GEMMs on the auxiliary stream
+    float* colsum_slabs2 = nullptr;
+    hipStream_t aux = nullptr;          // low-priority stream for the projection GEMMs that overlap the recurrence
+    static constexpr int NCHUNK = 4;    // time chunks of the overlap schedule
+    hipEvent_t ev_chunk[NCHUNK] = {};   // main -> aux (forward) / aux -> main (backward): chunk ready
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = false;               // FSMG_OVERLAP=1 enables the two-stream schedule
     int64_t slab_cap = 0;
     // whole-phase hipGraphs, keyed by the shape of the call; dropped when scratch moves
     std::map<std::string, hipGraphExec_t> graphs;
@@ -296,6 +303,7 @@ void drop_graphs(fsmg_model* h);
 int ensure_scratch(fsmg_model* h, int B) {
     if (B <= h->Bcap) return FSMG_OK;
     HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->aux) HIPCK(h, hipStreamSynchronize(h->aux));
     drop_graphs(h);
     if (h->scratch) { HIPCK(h, hipFree(h->scratch)); h->scratch = nullptr; }
     const int64_t T = h->T, Hp = h->Hp, G4 = h->G4, rows = T * (int64_t)B;
@@ -327,8 +335,16 @@ int ensure_scratch(fsmg_model* h, int B) {
         need(rows, Hp, h->V1p); need(Hp, h->V1p, rows); need(Hp, G4, rows);
         need(h->Ep, G4, rows); need(rows, h->Ep, G4); need(rows, Hp, G4); need(rows, G4, h->Ep); need(rows, G4, Hp);
     }
+    // chunked dH GEMMs of the overlap schedule have their own (smaller) shapes
+    for (int c = 0; c < fsmg_model::NCHUNK; ++c) {
+        const int64_t m = ((int64_t)(c + 1) * T / fsmg_model::NCHUNK - (int64_t)c * T / fsmg_model::NCHUNK) * B;
+        const int S = pick_split(m, Hp, h->V1p);
+        if (S > 1) slab_need = std::max(slab_need, (int64_t)S * m * Hp);
+    }
     const int64_t o_slab = place(4 * std::max<int64_t>(slab_need, 64));
     const int64_t o_cslab = place(4 * (int64_t)MAX_SPLIT * std::max<int64_t>(h->V1p, G4));
+    const int64_t o_slab2 = place(4 * std::max<int64_t>(slab_need, 64));
+    const int64_t o_cslab2 = place(4 * (int64_t)MAX_SPLIT * std::max<int64_t>(h->V1p, G4));
     hipError_t e = hipMalloc((void**)&h->scratch, off);
     if (e != hipSuccess) {
         h->Bcap = 0;
@@ -351,6 +367,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     h->lse = (float*)(s + o_lse); h->ce = (float*)(s + o_ce); h->dXemb = (float*)(s + o_dx);
     h->partials = (double*)(s + o_part);
     h->slabs = (float*)(s + o_slab); h->colsum_slabs = (float*)(s + o_cslab); h->slab_cap = slab_need;
+    h->slabs2 = (float*)(s + o_slab2); h->colsum_slabs2 = (float*)(s + o_cslab2);
     h->Bcap = B;
     return FSMG_OK;
 }
@@ -361,10 +378,15 @@ void drop_graphs(fsmg_model* h) {
     h->graphs.clear();
 }
 
+// A stream plus the split-K slab buffers its GEMMs may use.
+struct Lane { hipStream_t s; float* slabs; float* colsum_slabs; };
+inline Lane main_lane(fsmg_model* h) { return Lane{h->stream, h->slabs, h->colsum_slabs}; }
+inline Lane aux_lane(fsmg_model* h) { return Lane{h->aux, h->slabs2, h->colsum_slabs2}; }
+
 // C (contiguous, ldc == N) = op(A) * op(B) with the K range split over pick_split() slabs that are
 // summed in a fixed order (deterministic); colsum likewise.
-int gemm(fsmg_model* h, int amode, int bmode, int atr, int btr, GemmArgs g) {
-    hipStream_t s = h->stream;
+int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, int atr, int btr, GemmArgs g) {
+    hipStream_t s = ln.s;
     const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K) : 1;
     if (S <= 1 || (int64_t)S * g.M * g.N > h->slab_cap) {
         g.ksplit = 1;
@@ -373,11 +395,11 @@ int gemm(fsmg_model* h, int amode, int bmode, int atr, int btr, GemmArgs g) {
     }
     float* C = g.C; float* colsum = g.colsum;
     const int64_t mn = (int64_t)g.M * g.N;
-    g.C = h->slabs; g.c_slab = mn; g.ksplit = S;
-    if (colsum) { g.colsum = h->colsum_slabs; g.colsum_slab = g.N; }
+    g.C = ln.slabs; g.c_slab = mn; g.ksplit = S;
+    if (colsum) { g.colsum = ln.colsum_slabs; g.colsum_slab = g.N; }
     HIPCK(h, launch_gemm(s, amode, bmode, atr, btr, g));
-    HIPCK(h, launch_reduce_slabs(s, h->slabs, mn, S, C, mn));
-    if (colsum) HIPCK(h, launch_reduce_slabs(s, h->colsum_slabs, g.N, S, colsum, g.N));
+    HIPCK(h, launch_reduce_slabs(s, ln.slabs, mn, S, C, mn));
+    if (colsum) HIPCK(h, launch_reduce_slabs(s, ln.colsum_slabs, g.N, S, colsum, g.N));
     return FSMG_OK;
 }
 #define GEMMCK(call) do { int rc_ = (call); if (rc_ != FSMG_OK) return rc_; } while (0)
@@ -435,12 +457,46 @@ int token_prep(fsmg_model* h, int n_sup, int n_qry) {
     return FSMG_OK;
 }
 
+// Two-stream schedule.  The recurrent chains are latency bound (one small kernel per time step), the
+// vocabulary-projection GEMMs are throughput bound, and per time chunk they are independent:
+//   forward : logits + cross entropy of chunk c need h_t only for t in chunk c
+//   backward: the BPTT steps of chunk c need dH only for t in chunk c; dW needs no BPTT result at all
+// so the projection work runs on a low-priority auxiliary stream, forked / joined with events (inside
+// the captured graph these become parallel branches).  Event timing (eager, one class at a time)
+// and the default (FSMG_OVERLAP unset) use the single-stream order.
+inline bool use_overlap(const fsmg_model* h) { return h->overlap && !h->timing && h->aux != nullptr && h->T >= fsmg_model::NCHUNK; }
+
+int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t rows_total, bool want_dlogits) {
+    const int Hp = h->Hp;
+    const int64_t r0 = (int64_t)t0 * B, m = (int64_t)(t1 - t0) * B;
+    {
+        ScopedTimer tm(h, "gemm_logits");
+        GemmArgs g{};
+        g.A = h->Hs[h->L - 1] + (size_t)B * Hp + (size_t)r0 * Hp; g.lda = Hp;
+        g.B = h->P + h->off_w; g.ldb = h->V1p;
+        g.C = h->logits + (size_t)r0 * h->V1p; g.ldc = h->V1p; g.M = (int)m; g.N = h->V1p; g.K = Hp;
+        g.bias = h->P + h->off_d; g.ksplit = 1;
+        GEMMCK(gemm(h, ln, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
+    }
+    {
+        ScopedTimer tm(h, "ce");
+        HIPCK(h, launch_ce_rows(ln.s, h->logits + (size_t)r0 * h->V1p, h->V1p, (int)m, h->V1, h->Y + r0, h->lse + r0,
+                                h->ce + r0, want_dlogits ? h->dlogits + (size_t)r0 * h->V1p : nullptr,
+                                (float)(1.0 / ((double)rows_total + 1e-12))));
+    }
+    return FSMG_OK;
+}
+
 int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_out, bool want_dlogits) {
     const int T = h->T, Hp = h->Hp, G4 = h->G4;
     const int64_t rows = (int64_t)T * B;
+    const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
+    const bool ov = use_overlap(h);
+    const int nch = ov ? fsmg_model::NCHUNK : 1;
     for (int l = 0; l < h->L; ++l) {
         const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
+        const bool top = l == h->L - 1;
         HIPCK(h, hipMemsetAsync(h->Hs[l], 0, sizeof(float) * (size_t)B * Hp, s));
         HIPCK(h, hipMemsetAsync(h->HF[l], 0, sizeof(float) * Bp16 * Hp, s));
         HIPCK(h, hipMemsetAsync(h->Cs[l], 0, sizeof(float) * (size_t)B * Hp, s));
@@ -452,69 +508,95 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             g.B = h->P + h->off_kx[l]; g.ldb = G4;
             g.C = h->Z[l]; g.ldc = G4; g.M = (int)rows; g.N = G4;
             g.bias = h->P + h->off_b[l]; g.ksplit = 1;
-            GEMMCK(gemm(h, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
+            GEMMCK(gemm(h, mainl, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
         }
-        {
-            ScopedTimer tm(h, "lstm_fwd");
-            for (int t = 0; t < T; ++t) {
-                LstmFwdArgs a{};
-                a.KhF = h->khf + (size_t)(2 * l) * Hp * G4;
-                a.hF_prev = h->HF[l] + (size_t)t * Bp16 * Hp;
-                a.hF_next = h->HF[l] + (size_t)(t + 1) * Bp16 * Hp;
-                a.z = h->Z[l] + (size_t)t * B * G4;
-                a.c_prev = h->Cs[l] + (size_t)t * B * Hp;
-                a.c_next = h->Cs[l] + (size_t)(t + 1) * B * Hp;
-                a.h_next = h->Hs[l] + (size_t)(t + 1) * B * Hp;
-                a.B = B; a.Hp = Hp;
-                HIPCK(h, launch_lstm_fwd_step(s, a));
+        for (int c = 0; c < nch; ++c) {
+            const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
+            {
+                ScopedTimer tm(h, "lstm_fwd");
+                for (int t = t0; t < t1; ++t) {
+                    LstmFwdArgs a{};
+                    a.KhF = h->khf + (size_t)(2 * l) * Hp * G4;
+                    a.hF_prev = h->HF[l] + (size_t)t * Bp16 * Hp;
+                    a.hF_next = h->HF[l] + (size_t)(t + 1) * Bp16 * Hp;
+                    a.z = h->Z[l] + (size_t)t * B * G4;
+                    a.c_prev = h->Cs[l] + (size_t)t * B * Hp;
+                    a.c_next = h->Cs[l] + (size_t)(t + 1) * B * Hp;
+                    a.h_next = h->Hs[l] + (size_t)(t + 1) * B * Hp;
+                    a.B = B; a.Hp = Hp;
+                    HIPCK(h, launch_lstm_fwd_step(s, a));
+                }
+            }
+            if (top && ov) {      // projection + CE of this chunk on the auxiliary stream
+                HIPCK(h, hipEventRecord(h->ev_chunk[c], s));
+                HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_chunk[c], 0));
+                GEMMCK(logits_and_ce(h, aux_lane(h), B, t0, t1, rows, want_dlogits));
             }
         }
     }
-    {
-        ScopedTimer tm(h, "gemm_logits");
-        GemmArgs g{};
-        g.A = h->Hs[h->L - 1] + (size_t)B * Hp; g.lda = Hp;
-        g.B = h->P + h->off_w; g.ldb = h->V1p;
-        g.C = h->logits; g.ldc = h->V1p; g.M = (int)rows; g.N = h->V1p; g.K = Hp;
-        g.bias = h->P + h->off_d; g.ksplit = 1;
-        GEMMCK(gemm(h, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
+    if (ov) {
+        HIPCK(h, hipEventRecord(h->ev_join, h->aux));
+        HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));
+    } else {
+        GEMMCK(logits_and_ce(h, mainl, B, 0, T, rows, want_dlogits));
     }
     {
         ScopedTimer tm(h, "ce");
-        HIPCK(h, launch_ce_rows(s, h->logits, h->V1p, (int)rows, h->V1, h->Y, h->lse, h->ce,
-                                want_dlogits ? h->dlogits : nullptr, (float)(1.0 / ((double)rows + 1e-12))));
         HIPCK(h, launch_loss_reduce(s, h->ce, T, B, rows_per_group, ngroups, loss_out));
     }
     h->lastB = B;
     return FSMG_OK;
 }
 
+int dhout_chunk(fsmg_model* h, const Lane& ln, int B, int t0, int t1) {
+    ScopedTimer tm(h, "gemm_dhout");     // dH = dlogits * W^T for the rows of time steps [t0, t1)
+    const int64_t r0 = (int64_t)t0 * B, m = (int64_t)(t1 - t0) * B;
+    GemmArgs g{};
+    g.A = h->dlogits + (size_t)r0 * h->V1p; g.lda = h->V1p; g.B = h->P + h->off_w; g.ldb = h->V1p;
+    g.C = h->dH + (size_t)r0 * h->Hp; g.ldc = h->Hp; g.M = (int)m; g.N = h->Hp; g.K = h->V1p; g.ksplit = 1;
+    return gemm(h, ln, OP_KC, OP_KC, TR_NONE, TR_NONE, g);
+}
+
+int dw_gemm(fsmg_model* h, const Lane& ln, int B) {
+    ScopedTimer tm(h, "gemm_dw");        // dW = Hout^T * dlogits, dd = colsum(dlogits)
+    GemmArgs g{};
+    g.A = h->Hs[h->L - 1] + (size_t)B * h->Hp; g.lda = h->Hp; g.B = h->dlogits; g.ldb = h->V1p;
+    g.C = h->G + h->off_w; g.ldc = h->V1p; g.M = h->Hp; g.N = h->V1p; g.K = (int)((int64_t)h->T * B);
+    g.colsum = h->G + h->off_d; g.ksplit = 1;
+    return gemm(h, ln, OP_XC, OP_XC, TR_NONE, TR_NONE, g);
+}
+
 int backward(fsmg_model* h, int B) {
     const int T = h->T, Hp = h->Hp, G4 = h->G4;
     const int64_t rows = (int64_t)T * B;
+    const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
-    float* Hout = h->Hs[h->L - 1] + (size_t)B * Hp;
+    const bool ov = use_overlap(h);
+    const int nch = ov ? fsmg_model::NCHUNK : 1;
     HIPCK(h, hipMemsetAsync(h->G + h->off_emb, 0, sizeof(float) * (size_t)h->V1 * h->Ep, s));
-    {
-        ScopedTimer tm(h, "gemm_dhout");     // dH = dlogits * W^T
-        GemmArgs g{};
-        g.A = h->dlogits; g.lda = h->V1p; g.B = h->P + h->off_w; g.ldb = h->V1p;
-        g.C = h->dH; g.ldc = Hp; g.M = (int)rows; g.N = Hp; g.K = h->V1p; g.ksplit = 1;
-        GEMMCK(gemm(h, OP_KC, OP_KC, TR_NONE, TR_NONE, g));
-    }
-    {
-        ScopedTimer tm(h, "gemm_dw");        // dW = Hout^T * dlogits, dd = colsum(dlogits)
-        GemmArgs g{};
-        g.A = Hout; g.lda = Hp; g.B = h->dlogits; g.ldb = h->V1p;
-        g.C = h->G + h->off_w; g.ldc = h->V1p; g.M = Hp; g.N = h->V1p; g.K = (int)rows;
-        g.colsum = h->G + h->off_d; g.ksplit = 1;
-        GEMMCK(gemm(h, OP_XC, OP_XC, TR_NONE, TR_NONE, g));
+    if (ov) {
+        // aux: dH chunks in the order BPTT consumes them (last chunk first), then dW
+        HIPCK(h, hipEventRecord(h->ev_fork, s));
+        HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+        for (int c = nch - 1; c >= 0; --c) {
+            const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
+            GEMMCK(dhout_chunk(h, aux_lane(h), B, t0, t1));
+            HIPCK(h, hipEventRecord(h->ev_chunk[c], h->aux));
+        }
+        GEMMCK(dw_gemm(h, aux_lane(h), B));
+        HIPCK(h, hipEventRecord(h->ev_join, h->aux));
+    } else {
+        GEMMCK(dhout_chunk(h, mainl, B, 0, T));
+        GEMMCK(dw_gemm(h, mainl, B));
     }
     for (int l = h->L - 1; l >= 0; --l) {
+        const bool top = l == h->L - 1;
         HIPCK(h, hipMemsetAsync(h->dC, 0, sizeof(float) * (size_t)B * Hp, s));
-        {
+        for (int c = nch - 1; c >= 0; --c) {
+            const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
+            if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[c], 0));
             ScopedTimer tm(h, "lstm_bwd");
-            for (int t = T - 1; t >= 0; --t) {
+            for (int t = t1 - 1; t >= t0; --t) {
                 LstmBwdArgs a{};
                 const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
                 a.KhF = h->khf + (size_t)(2 * l + 1) * Hp * G4;
@@ -536,13 +618,13 @@ int backward(fsmg_model* h, int B) {
             g.A = h->Hs[l]; g.lda = Hp; g.B = h->Z[l]; g.ldb = G4;
             g.C = h->G + h->off_kh[l]; g.ldc = G4; g.M = Hp; g.N = G4; g.K = (int)rows;
             g.colsum = h->G + h->off_b[l]; g.ksplit = 1;
-            GEMMCK(gemm(h, OP_XC, OP_XC, TR_NONE, TR_NONE, g));
+            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, TR_NONE, TR_NONE, g));
             GemmArgs k{};                     // dKx = in^T * dZ
             if (l == 0) { k.A = h->P + h->off_emb; k.lda = h->Ep; k.gather = h->X; }
             else { k.A = h->Hs[l - 1] + (size_t)B * Hp; k.lda = Hp; }
             k.B = h->Z[l]; k.ldb = G4; k.C = h->G + h->off_kx[l]; k.ldc = G4;
             k.M = in_p; k.N = G4; k.K = (int)rows; k.ksplit = 1;
-            GEMMCK(gemm(h, OP_XC, OP_XC, TR_NONE, TR_NONE, k));
+            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, TR_NONE, TR_NONE, k));
         }
         {
             ScopedTimer tm(h, "gemm_dx");     // d_in = dZ * Kx^T
@@ -550,7 +632,7 @@ int backward(fsmg_model* h, int B) {
             g.A = h->Z[l]; g.lda = G4; g.B = h->P + h->off_kx[l]; g.ldb = G4;
             g.C = (l == 0) ? h->dXemb : h->dH; g.ldc = in_p;
             g.M = (int)rows; g.N = in_p; g.K = G4; g.ksplit = 1;
-            GEMMCK(gemm(h, OP_KC, OP_KC, TR_NONE, TR_NONE, g));
+            GEMMCK(gemm(h, mainl, OP_KC, OP_KC, TR_NONE, TR_NONE, g));
         }
     }
     {
@@ -560,6 +642,7 @@ int backward(fsmg_model* h, int B) {
         HIPCK(h, launch_sqnorm_partials(s, h->dXemb, rows * h->Ep, h->partials));
         HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0));
     }
+    if (ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));     // dW / dd landed
     h->have_grads = true;
     return FSMG_OK;
 }
@@ -661,6 +744,19 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(FSMG_ERR_HIP, "hipStreamCreate failed");
         h->own_stream = true;
     }
+    {
+        // measured on MI355X at cfg-B (profiles/): the two-stream schedule is bit-identical but ~7 % SLOWER
+        // (co-resident GEMM traffic lengthens the recurrent hand-off latency), so it is opt-in
+        const char* env = std::getenv("FSMG_OVERLAP");
+        h->overlap = (env && env[0] == '1');
+        int least = 0, greatest = 0;
+        hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, least) != hipSuccess) return bail(FSMG_ERR_HIP, "aux stream create failed");
+        for (int c = 0; c < fsmg_model::NCHUNK; ++c)
+            if (hipEventCreateWithFlags(&h->ev_chunk[c], hipEventDisableTiming) != hipSuccess) return bail(FSMG_ERR_HIP, "event create failed");
+        if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return bail(FSMG_ERR_HIP, "event create failed");
+    }
     const int64_t sb = state_bytes_for(h->n_flat);
     if (cfg->state_arena) {
         if (cfg->state_arena_bytes < (uint64_t)sb || ((uintptr_t)cfg->state_arena & 255u))
@@ -701,6 +797,7 @@ int fsmg_destroy(fsmg_handle h) {
     if (!h) return FSMG_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->aux) hipStreamSynchronize(h->aux);
     drain_timers(h);
     drop_graphs(h);
     if (h->scratch) hipFree(h->scratch);
@@ -709,6 +806,10 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->khf) hipFree(h->khf);
     if (h->d_eval) hipFree(h->d_eval);
     if (h->own_state && h->state) hipFree(h->state);
+    for (int c = 0; c < fsmg_model::NCHUNK; ++c) if (h->ev_chunk[c]) hipEventDestroy(h->ev_chunk[c]);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->aux) hipStreamDestroy(h->aux);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return FSMG_OK;

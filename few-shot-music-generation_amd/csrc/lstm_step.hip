@@ -61,8 +61,9 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ af, const f
         prof[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime()
 
 template <bool PROF>
-__global__ __launch_bounds__(256) void k_lstm_fwd_step(const LstmFwdArgs a, unsigned long long* prof) {
+__global__ __launch_bounds__(256, 4) void k_lstm_fwd_step(const LstmFwdArgs a, unsigned long long* prof) {
     __shared__ float red[4][16][17];
+    __builtin_amdgcn_s_setprio(3);       // latency-critical chain: win issue arbitration against co-resident GEMM waves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     const int nb = blockIdx.x;           // unit block: units 4nb..4nb+3, packed cols 16nb..16nb+15
@@ -151,8 +152,9 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ af, const f
 }
 
 template <bool PROF>
-__global__ __launch_bounds__(512) void k_lstm_bwd_step(const LstmBwdArgs a, unsigned long long* prof) {
+__global__ __launch_bounds__(512, 4) void k_lstm_bwd_step(const LstmBwdArgs a, unsigned long long* prof) {
     __shared__ float red[8][16][17];
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     const int u0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
@@ -178,8 +180,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_step(const LstmBwdArgs a, unsi
         const float4* af = reinterpret_cast<const float4*>(a.dzF_next) + ((size_t)blockIdx.y * ngroups) * 64 + lane;
         const float4* bf = reinterpret_cast<const float4*>(a.KhF) + ((size_t)blockIdx.x * ngroups) * 64 + lane;
         int g = g_beg;
-        while (g + 16 <= g_end) { bwd_chunk<16>(af, bf, g, acc0, acc1); g += 16; }
-        if (g + 8 <= g_end) { bwd_chunk<8>(af, bf, g, acc0, acc1); g += 8; }
+        while (g + 8 <= g_end) { bwd_chunk<8>(af, bf, g, acc0, acc1); g += 8; }
         if (g + 4 <= g_end) { bwd_chunk<4>(af, bf, g, acc0, acc1); g += 4; }
         if (g + 2 <= g_end) { bwd_chunk<2>(af, bf, g, acc0, acc1); g += 2; }
         if (g < g_end) bwd_chunk<1>(af, bf, g, acc0, acc1);

@@ -1,0 +1,110 @@
+"""Episode-parallel path on CPU: world_size-2 gloo processes.
+
+The HIP engine cannot run here, so the engine slot of fsmg.dist.EpisodeParallel is filled by a CPU stand-in
+built on the oracle (test infrastructure) that exposes the same three members (forward_backward,
+grad_tensor, apply_update) with the same flat-gradient + tail-scalars contract as libfsmg.  What is under
+test is the product's host logic: the episode sharding, the ONE all-reduce per step, grad_scale = 1/world,
+and that 2 ranks x 1 episode equal 1 rank on the 2 concatenated episodes.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import small_config
+from oracle import lstm_oracle as O
+
+CFG = small_config(hidden_size=12, embedding_size=6, input_size=40, max_len=6, max_grad_norm=0.5)
+N, K, Q = 2, 2, 1
+STEPS = 3
+
+
+class OracleEngine(object):
+    """CPU stand-in with libfsmg's engine contract: flat grad tensor whose tail holds [slices_sq, loss]."""
+    TAIL = 16
+
+    def __init__(self, cfg, params):
+        self.cfg = cfg
+        self.params = {k: v.copy() for k, v in params.items()}
+        self.opt = O.new_opt_state(self.params)
+        self.names = [n for n, _ in O.param_shapes(cfg)]
+        self.sizes = [self.params[n].size for n in self.names]
+        self.grad_tensor = torch.zeros(sum(self.sizes) + self.TAIL, dtype=torch.float64)
+
+    def forward_backward(self, support, query, **kw):
+        X, Y = O.train_xy(support, query, self.cfg['input_size'])
+        loss, cache = O.forward(self.params, X, Y, self.cfg)
+        grads, aux = O.backward(self.params, cache, self.cfg)
+        flat = np.concatenate([grads[n].ravel() for n in self.names] + [np.zeros(self.TAIL)])
+        flat[-self.TAIL] = aux['embedding_slices_sq']
+        flat[-self.TAIL + 1] = loss
+        self.grad_tensor.copy_(torch.from_numpy(flat))
+
+    def apply_update(self, grad_scale=1.0, want_loss=True):
+        flat = self.grad_tensor.numpy() * 1.0
+        grads, off = {}, 0
+        for n, sz in zip(self.names, self.sizes):
+            grads[n] = (flat[off:off + sz] * grad_scale).reshape(self.params[n].shape)
+            off += sz
+        aux = dict(embedding_slices_sq=flat[-self.TAIL] * grad_scale * grad_scale)
+        O.apply_update(self.params, grads, aux, self.opt, self.cfg, 'tf1_slices')
+        return float(flat[-self.TAIL + 1] * grad_scale)
+
+
+def _episodes():
+    return O.synthetic_episodes(2 * STEPS, N, K, Q, CFG['max_len'], CFG['input_size'], seed=3)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    'few-shot-music-generation_amd', 'src'))
+    from fsmg.dist import EpisodeParallel
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    eng = OracleEngine(CFG, O.glorot_init(CFG, 5, np.float64))
+    par = EpisodeParallel(eng)
+    assert (par.rank, par.world) == (rank, world)
+    eps = _episodes()
+    losses = [par.train_step(*eps[s * world + rank]) for s in range(STEPS)]   # rank r takes episode s*R + r
+    mean_val = par.mean_scalar(float(rank))
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), losses=np.array(losses), mean_val=mean_val, **eng.params)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
+    port = 29000 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), 'rank0.npz'))
+    r1 = np.load(os.path.join(str(tmp_path), 'rank1.npz'))
+    # replicas stay identical and see the same (mean) loss
+    np.testing.assert_array_equal(r0['losses'], r1['losses'])
+    assert r0['mean_val'] == r1['mean_val'] == 0.5
+    # single process on the 2-episode batch per step: loss = mean over all rows == mean of the two episode losses
+    params = O.glorot_init(CFG, 5, np.float64)
+    opt = O.new_opt_state(params)
+    eps = _episodes()
+    for s in range(STEPS):
+        (s0, q0), (s1, q1) = eps[2 * s], eps[2 * s + 1]
+        sup, qry = np.concatenate([s0, s1]), np.concatenate([q0, q1])
+        want = O.train_step(params, opt, sup, qry, CFG)
+        assert abs(r0['losses'][s] - want) <= 1e-12 * abs(want)
+    for k, v in params.items():
+        np.testing.assert_allclose(r0[k], v, rtol=1e-10, atol=1e-14, err_msg=k)
+        np.testing.assert_array_equal(r0[k], r1[k])
+
+
+def test_single_process_group_is_a_passthrough():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    'few-shot-music-generation_amd', 'src'))
+    from fsmg.dist import EpisodeParallel
+    eng = OracleEngine(CFG, O.glorot_init(CFG, 5, np.float64))
+    par = EpisodeParallel(eng)
+    assert par.world == 1 and par.mean_scalar(3.0) == 3.0
+    sup, qry = _episodes()[0]
+    params = O.glorot_init(CFG, 5, np.float64)
+    opt = O.new_opt_state(params)
+    assert abs(par.train_step(sup, qry) - O.train_step(params, opt, sup, qry, CFG)) < 1e-12

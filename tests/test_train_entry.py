@@ -1,0 +1,99 @@
+"""train.train end to end: flags, YAML merge, loop cadence, log lines, checkpoints, sample dump.
+CPU: with a fake plugin.  GPU: with the real LSTMBaseline plugin on the golden lyrics fixture."""
+import os
+import shutil
+import sys
+
+import pytest
+import yaml
+
+import train.train as T
+
+K, Q, MAXLEN = 5, 4, 32
+
+
+def _write_configs(tmp_path, golden_dir, model_cfg):
+    root = tmp_path / 'g1_lyrics'
+    shutil.copytree(os.path.join(golden_dir, 'g1_lyrics'), root)
+    paths = {}
+    docs = {
+        'data': dict(dataset='lyrics', dataset_path=str(root), splits=['train', 'val', 'test'], max_len=MAXLEN),
+        'task': dict(query_size=Q, support_size=K, seed=1234),
+        'model': model_cfg,
+    }
+    for name, doc in docs.items():
+        paths[name] = str(tmp_path / (name + '.yaml'))
+        with open(paths[name], 'w') as f:
+            yaml.safe_dump(doc, f)
+    return paths
+
+
+LOOP = dict(n_train=4, print_every_n=2, val_every_n=2.0, n_val=3, n_test=2, n_samples=2, batch_size=2)
+
+
+def test_main_with_fake_plugin(tmp_path, golden_dir, capsys):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    cfg = dict(LOOP, name='fake', model_module_name='fake_model', model_class_name='FakeModel')
+    p = _write_configs(tmp_path, golden_dir, cfg)
+    ck = str(tmp_path / 'ck')
+    T.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--checkpt_dir', ck])
+    out = capsys.readouterr().out
+    assert 'Num unique words: 300' in out
+    assert 'Iter: 0, val-nll: 2.500e+00' in out
+    assert 'Iter: 2, val-nll: 2.500e+00' in out and 'Iter: 4, val-nll: 2.500e+00' in out
+    assert 'Iter: 2, loss: 7.500e+00' in out            # mean(10/1, 10/2)
+    assert 'Iter: 4, loss: 2.917e+00' in out            # mean(10/3, 10/4)
+    for line in ('Train Avg NLL: 2.500e+00', 'Validation Avg NLL: 2.500e+00', 'Test Avg NLL: 2.500e+00'):
+        assert line in out
+    from fake_model import FakeModel
+    kinds = [c[0] for c in FakeModel.calls]
+    assert kinds.count('train') == 4 and kinds.count('save') == 2 and kinds.count('eval') == 3 * 3 + 3 * 2
+    assert FakeModel.calls[0] == ('init', 300) and FakeModel.calls[1] == ('recover_or_init', '')
+    assert ('train', (2, K, MAXLEN), (2, Q, MAXLEN)) in FakeModel.calls
+    for i in range(2):
+        d = os.path.join(ck, 'samples', 'sample_%d' % i)
+        assert sorted(os.listdir(d)) == ['model_sample.txt'] + ['support_%d.txt' % j for j in range(K)]
+        assert open(os.path.join(d, 'model_sample.txt')).read().split()[0].startswith('w')
+    # re-running into the same checkpt_dir must not crash at the sampling phase (Q10)
+    T.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--checkpt_dir', ck])
+
+
+def test_config_merge_order_and_missing_vocab(tmp_path, golden_dir):
+    cfg = dict(LOOP, name='fake', model_module_name='fake_model', model_class_name='FakeModel', max_len=MAXLEN, seed=7)
+    p = _write_configs(tmp_path, golden_dir, cfg)
+    args = T.build_parser().parse_args(['--data', p['data'], '--task', p['task'], '--model', p['model']])
+    merged = T.load_config(args)
+    assert merged['seed'] == 7                       # model yaml wins over task yaml
+    assert merged['checkpt_dir'] == '' and os.path.isabs(merged['dataset_path'])
+    assert vars(T.build_parser().parse_args([])) == dict(data='', model='', task='', checkpt_dir='', init_dir='')
+
+
+def test_unigram_plugin_stays_selectable(tmp_path, golden_dir, capsys):
+    cfg = dict(LOOP, name='unigram_model', model_module_name='models.unigram_model', model_class_name='UnigramModel')
+    cfg['batch_size'] = 1
+    p = _write_configs(tmp_path, golden_dir, cfg)
+    T.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--checkpt_dir', str(tmp_path / 'u')])
+    out = capsys.readouterr().out
+    assert 'Test Avg NLL' in out and 'Iter: 4, loss:' in out
+
+
+@pytest.mark.gpu
+def test_main_with_lstm_baseline_on_gpu(tmp_path, golden_dir, capsys):
+    cfg = dict(LOOP, name='lstm_baseline', model_module_name='models.lstm_baseline', model_class_name='LSTMBaseline',
+               n_train=6, print_every_n=3, val_every_n=3.0, n_decay=10000, lr=5e-3, max_grad_norm=5,
+               embedding_size=250, hidden_size=200, n_layers=1)
+    p = _write_configs(tmp_path, golden_dir, cfg)
+    ck = str(tmp_path / 'ck')
+    T.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--checkpt_dir', ck])
+    out = capsys.readouterr().out
+    lines = [l for l in out.splitlines() if l.startswith('Iter: ') or 'Avg NLL' in l]
+    assert lines[0].startswith('Iter: 0, val-nll: 5.7')          # ~ln(301) = 5.707 for untrained weights
+    assert any(l.startswith('Iter: 6, loss: ') for l in lines) and any(l.startswith('Test Avg NLL') for l in lines)
+    first = float(lines[0].split('val-nll: ')[1]); last = float([l for l in lines if 'val-nll' in l][-1].split('val-nll: ')[1])
+    assert last < first                                            # six Adam steps already lower the val NLL
+    assert os.path.isfile(os.path.join(ck, 'lstm_baseline', 'lstm_baseline-6.npz'))
+    assert os.path.isfile(os.path.join(ck, 'samples', 'sample_1', 'model_sample.txt'))
+    # resume from the checkpoint directory
+    T.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--checkpt_dir', str(tmp_path / 'ck2'),
+            '--init_dir', ck])
+    assert 'recovering lstm_baseline from' in capsys.readouterr().out
