@@ -236,21 +236,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(const GemmArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  MFMA 32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): a lane holds
+    // single floats of 16 rows.  Each wave transposes its 64x64 sub-tile through its own slice of the (now
+    // idle) pipeline LDS, 32 rows at a time, and stores 16-byte row segments: 16 store instructions per lane
+    // instead of 64 (the store tail of a short-K GEMM is issue bound).
     float* C = g.C + (long long)z * g.c_slab;
+    constexpr int EP_LD = 68;                                  // 64 + 4: rows stay 16-byte aligned
+    float* ep = smem + wave * (32 * EP_LD);                    // 4 waves x 8.5 KiB <= the 66 KiB pipeline buffers
+    const int ncol0 = n0 + wn * 64;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-        if (col >= g.N) continue;
-        const float bv = (g.bias != nullptr && z == 0) ? g.bias[col] : 0.0f;
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (row < g.M) C[(long long)row * g.ldc + col] = acc[i][j][r] + bv;
+            for (int r = 0; r < 16; ++r)
+                ep[((r & 3) + 8 * (r >> 2) + 4 * khalf) * EP_LD + j * 32 + l31] = acc[i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): own LDS writes landed (wave-private slice)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int rl = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+            const int row = m0 + wm * 64 + i * 32 + rl, col = ncol0 + c4;
+            float4 v = *reinterpret_cast<const float4*>(ep + rl * EP_LD + c4);
+            if (row < g.M && col < g.N) {                      // N, ldc are multiples of 4: whole float4 in or out
+                if (g.bias != nullptr && z == 0) {
+                    const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                *reinterpret_cast<float4*>(C + (long long)row * g.ldc + col) = v;
             }
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // reads done before the slice is overwritten
     }
     if (do_colsum && n0 + tid < g.N) g.colsum[(long long)z * g.colsum_slab + n0 + tid] = csum;
 }
