@@ -27,7 +27,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+#ifndef FSMG_FWD_NW
+#define FSMG_FWD_NW 4
+#endif
+#ifndef FSMG_BWD_NW
+#define FSMG_BWD_NW 8
+#endif
+constexpr int FWD_NW = FSMG_FWD_NW;   // waves per forward-step block (split K = Hp)
+constexpr int BWD_NW = FSMG_BWD_NW;   // waves per backward-step block (split K = 4Hp)
+
+// Gate nonlinearities on v_exp_f32 (exp2 of a pre-scaled argument, ~1 ulp) instead of the libm call chains:
+// absolute error <= ~1.5e-7 on outputs in [-1, 1], far inside the 1e-4 NLL bound; the small-|x| branch of
+// tanh is a Taylor polynomial so tanh(x) ~ x keeps full relative accuracy where 1 - 2/(1+e^2x) cancels.
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    const float x2 = x * x;
+    const float poly = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.05396825f + x2 * 0.02186949f))));
+    const float big = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
+    return fabsf(x) < 0.25f ? poly : big;
+}
 
 // ---------------------------------------------------------------- forward
 // grid (4Hp/16, ceil(B/16)); 256 threads = 4 waves, wave w owns a quarter of the K = Hp range.
@@ -60,9 +78,9 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ af, const f
     if (PROF && lane == 0)                                                                              \
         prof[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime()
 
-template <bool PROF>
-__global__ __launch_bounds__(256, 4) void k_lstm_fwd_step(const LstmFwdArgs a, unsigned long long* prof) {
-    __shared__ float red[4][16][17];
+template <bool PROF, int NW>
+__global__ __launch_bounds__(64 * NW, NW) void k_lstm_fwd_step(const LstmFwdArgs a, unsigned long long* prof) {
+    __shared__ float red[NW][16][17];
     __builtin_amdgcn_s_setprio(3);       // latency-critical chain: win issue arbitration against co-resident GEMM waves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
@@ -86,7 +104,7 @@ __global__ __launch_bounds__(256, 4) void k_lstm_fwd_step(const LstmFwdArgs a, u
     }
 
     const int ngroups = Hp >> 4;
-    const int g_beg = (wave * ngroups) >> 2, g_end = ((wave + 1) * ngroups) >> 2;
+    const int g_beg = (wave * ngroups) / NW, g_end = ((wave + 1) * ngroups) / NW;
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
     // fragment-ordered operands: [tile][group][lane] float4 (pad rows of the last M tile feed discarded outputs)
     const float4* af = reinterpret_cast<const float4*>(a.hF_prev) + ((size_t)blockIdx.y * ngroups) * 64 + lane;
@@ -110,14 +128,17 @@ __global__ __launch_bounds__(256, 4) void k_lstm_fwd_step(const LstmFwdArgs a, u
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
             const int c = 4 * gi + euu;
-            zg[gi] = zin[gi] + ((red[0][erow][c] + red[1][erow][c]) + (red[2][erow][c] + red[3][erow][c]));
+            float zs = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) zs += red[w][erow][c];
+            zg[gi] = zin[gi] + zs;
         }
         const float si = sigmoidf_(zg[0]);
-        const float tj = tanhf(zg[1]);
+        const float tj = tanhf_(zg[1]);
         const float sf = sigmoidf_(zg[2] + 1.0f);          // forget_bias = 1 added at run time
         const float so = sigmoidf_(zg[3]);
         const float cn = cp * sf + si * tj;
-        const float hn = tanhf(cn) * so;
+        const float hn = tanhf_(cn) * so;
         a.c_next[(long long)eb * Hp + eu] = cn;
         a.h_next[(long long)eb * Hp + eu] = hn;
         // fragment-ordered copy for the next step's A operand: group eu/16, slot q = (eu%16)/4, sub-step eu%4
@@ -151,9 +172,9 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ af, const f
     }
 }
 
-template <bool PROF>
-__global__ __launch_bounds__(512, 4) void k_lstm_bwd_step(const LstmBwdArgs a, unsigned long long* prof) {
-    __shared__ float red[8][16][17];
+template <bool PROF, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void k_lstm_bwd_step(const LstmBwdArgs a, unsigned long long* prof) {
+    __shared__ float red[NW][16][17];
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
@@ -176,7 +197,7 @@ __global__ __launch_bounds__(512, 4) void k_lstm_bwd_step(const LstmBwdArgs a, u
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.dzF_next != nullptr) {
         const int ngroups = G4 >> 4;
-        const int g_beg = (wave * ngroups) >> 3, g_end = ((wave + 1) * ngroups) >> 3;
+        const int g_beg = (wave * ngroups) / NW, g_end = ((wave + 1) * ngroups) / NW;
         const float4* af = reinterpret_cast<const float4*>(a.dzF_next) + ((size_t)blockIdx.y * ngroups) * 64 + lane;
         const float4* bf = reinterpret_cast<const float4*>(a.KhF) + ((size_t)blockIdx.x * ngroups) * 64 + lane;
         int g = g_beg;
@@ -195,8 +216,8 @@ __global__ __launch_bounds__(512, 4) void k_lstm_bwd_step(const LstmBwdArgs a, u
     if (eact) {
         float dh_rec = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) dh_rec += red[w][erow][eun];
-        const float tc = tanhf(ct);
+        for (int w = 0; w < NW; ++w) dh_rec += red[w][erow][eun];
+        const float tc = tanhf_(ct);
         const float dh = dht + dh_rec;
         const float dc = dcv + dh * so * (1.0f - tc * tc);
         const float di = dc * tj * si * (1.0f - si);
@@ -249,15 +270,15 @@ hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* b
 
 hipError_t launch_lstm_fwd_step(hipStream_t s, const LstmFwdArgs& a, unsigned long long* prof) {
     dim3 grid((4 * a.Hp) / 16, (a.B + 15) / 16);
-    if (prof) hipLaunchKernelGGL(k_lstm_fwd_step<true>, grid, dim3(256), 0, s, a, prof);
-    else hipLaunchKernelGGL(k_lstm_fwd_step<false>, grid, dim3(256), 0, s, a, nullptr);
+    if (prof) hipLaunchKernelGGL((k_lstm_fwd_step<true, FWD_NW>), grid, dim3(64 * FWD_NW), 0, s, a, prof);
+    else hipLaunchKernelGGL((k_lstm_fwd_step<false, FWD_NW>), grid, dim3(64 * FWD_NW), 0, s, a, nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_lstm_bwd_step(hipStream_t s, const LstmBwdArgs& a, unsigned long long* prof) {
     dim3 grid(a.Hp / 16, (a.B + 15) / 16);
-    if (prof) hipLaunchKernelGGL(k_lstm_bwd_step<true>, grid, dim3(512), 0, s, a, prof);
-    else hipLaunchKernelGGL(k_lstm_bwd_step<false>, grid, dim3(512), 0, s, a, nullptr);
+    if (prof) hipLaunchKernelGGL((k_lstm_bwd_step<true, BWD_NW>), grid, dim3(64 * BWD_NW), 0, s, a, prof);
+    else hipLaunchKernelGGL((k_lstm_bwd_step<false, BWD_NW>), grid, dim3(64 * BWD_NW), 0, s, a, nullptr);
     return hipGetLastError();
 }
 
