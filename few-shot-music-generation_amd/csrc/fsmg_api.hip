@@ -279,7 +279,7 @@ int download_tensor(fsmg_model* h, const float* flat, const char* name, float* h
 // ------------------------------------------------------------------ split-K policy
 // A 128x128-tile GEMM with few output tiles leaves most of the 256 CUs (2 resident blocks each)
 // idle; splitting K multiplies the block count.  Cost model: MFMA time at ~100 TF/s divided by the
-// slot efficiency of tiles*S blocks over 512 slots, plus S slabs of C written and read back.
+// slot efficiency of tiles*S blocks over the resident-block slots, plus S slabs of C written and read back.
 constexpr int MAX_SPLIT = 16;
 int pick_split(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
@@ -288,8 +288,8 @@ int pick_split(int64_t M, int64_t N, int64_t K) {
     int best = 1; double best_t = 1e30;
     for (int S = 1; S <= MAX_SPLIT; ++S) {
         if (S > 1 && K / S < 256) break;
-        const int64_t blocks = tiles * S;
-        const double eff = (double)blocks / (double)(((blocks + 511) / 512) * 512);
+        const int64_t blocks = tiles * S, slots = gemm_block_slots();
+        const double eff = (double)blocks / (double)(((blocks + slots - 1) / slots) * slots);
         const double t = t_mfma / eff + (S > 1 ? S * t_slab : 0.0);
         if (t < best_t - 1e-12) { best_t = t; best = S; }
     }

@@ -27,7 +27,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+#ifndef FSMG_GEMM_BK
+#define FSMG_GEMM_BK 16
+#endif
+// BK = 16: 34 KiB LDS and <=116 VGPRs per block -> 4 resident blocks (16 waves) per CU, which covers the
+// per-tile barrier and the prologue/epilogue bubbles better than 2 blocks of BK = 32 (measured +5..15 % per GEMM)
+constexpr int BM = 128, BN = 128, BK = FSMG_GEMM_BK;   // BK in {16, 32}
+constexpr int NLD = BK / 8;                            // 16-byte loads per thread per operand tile
+constexpr int KQ = BK / 4;                             // float4 slots along k in a KC tile row
 constexpr int LD_KC = 129;
 constexpr int LD_XC = 132;
 constexpr int NTHREADS = 256;
@@ -47,15 +54,15 @@ __device__ __forceinline__ float dl_elem(float logit, float lse, int tgt, int v,
 // ---- KC source: tile [128 x][32 k], k contiguous.  thread -> rows x = tid/8 + 32*i, k quad kq = tid%8
 template <int TR>
 struct KcLoader {
-    const float* rowp[4];
-    float lse[4]; int tgt[4];
+    const float* rowp[NLD];
+    float lse[NLD]; int tgt[NLD];
     int kq;
     __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather,
                                          const DlCtx& dl, int tid) {
-        kq = tid & 7;
+        kq = tid % KQ;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int x = x0 + (tid >> 3) + 32 * i;
+        for (int i = 0; i < NLD; ++i) {
+            int x = x0 + (tid / KQ) + (NTHREADS / KQ) * i;
             bool ok = x < X;
             long long row = ok ? (gather ? (long long)gather[x] : (long long)x) : 0;
             rowp[i] = ok ? src + row * ld : nullptr;
@@ -65,10 +72,10 @@ struct KcLoader {
             }
         }
     }
-    __device__ __forceinline__ void load(float4 (&r)[4], int k0, int kend, const DlCtx& dl) const {
+    __device__ __forceinline__ void load(float4 (&r)[NLD], int k0, int kend, const DlCtx& dl) const {
         int k = k0 + 4 * kq;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rowp[i] != nullptr && k < kend) {
                 v = *reinterpret_cast<const float4*>(rowp[i] + k);
@@ -82,14 +89,14 @@ struct KcLoader {
             r[i] = v;
         }
     }
-    __device__ __forceinline__ void store(float* lds, const float4 (&r)[4], int tid) const {
-        float* base = lds + (4 * kq) * LD_KC + (tid >> 3);
+    __device__ __forceinline__ void store(float* lds, const float4 (&r)[NLD], int tid) const {
+        float* base = lds + (4 * kq) * LD_KC + (tid / KQ);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            base[0 * LD_KC + 32 * i] = r[i].x;
-            base[1 * LD_KC + 32 * i] = r[i].y;
-            base[2 * LD_KC + 32 * i] = r[i].z;
-            base[3 * LD_KC + 32 * i] = r[i].w;
+        for (int i = 0; i < NLD; ++i) {
+            base[0 * LD_KC + (NTHREADS / KQ) * i] = r[i].x;
+            base[1 * LD_KC + (NTHREADS / KQ) * i] = r[i].y;
+            base[2 * LD_KC + (NTHREADS / KQ) * i] = r[i].z;
+            base[3 * LD_KC + (NTHREADS / KQ) * i] = r[i].w;
         }
     }
 };
@@ -107,9 +114,9 @@ struct XcLoader {
         x = x0 + 4 * (tid & 31);
         colp = (x < X) ? src + x : nullptr;
     }
-    __device__ __forceinline__ void load(float4 (&r)[4], int k0, int kend, const DlCtx& dl, int tid) const {
+    __device__ __forceinline__ void load(float4 (&r)[NLD], int k0, int kend, const DlCtx& dl, int tid) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             int k = k0 + (tid >> 5) + 8 * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (colp != nullptr && k < kend) {
@@ -127,30 +134,31 @@ struct XcLoader {
             r[i] = v;
         }
     }
-    __device__ __forceinline__ void store(float* lds, const float4 (&r)[4], int tid) const {
+    __device__ __forceinline__ void store(float* lds, const float4 (&r)[NLD], int tid) const {
         float* base = lds + (tid >> 5) * LD_XC + 4 * (tid & 31);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(base + 8 * i * LD_XC) = r[i];
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<float4*>(base + 8 * i * LD_XC) = r[i];
     }
 };
 
 template <int MODE, int TR> struct Loader;
 template <int TR> struct Loader<OP_KC, TR> : KcLoader<TR> {
-    __device__ __forceinline__ void fetch(float4 (&r)[4], int k0, int kend, const DlCtx& dl, int) const {
+    __device__ __forceinline__ void fetch(float4 (&r)[NLD], int k0, int kend, const DlCtx& dl, int) const {
         this->load(r, k0, kend, dl);
     }
 };
 template <int TR> struct Loader<OP_XC, TR> : XcLoader<TR> {
-    __device__ __forceinline__ void fetch(float4 (&r)[4], int k0, int kend, const DlCtx& dl, int tid) const {
+    __device__ __forceinline__ void fetch(float4 (&r)[NLD], int k0, int kend, const DlCtx& dl, int tid) const {
         this->load(r, k0, kend, dl, tid);
     }
 };
 
 template <int AMODE, int BMODE, int ATR, int BTR>
-__global__ __launch_bounds__(NTHREADS, 2) void k_gemm(const GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS, BK == 16 ? 4 : 2) void k_gemm(const GemmArgs g) {
     constexpr int LDA = TileLd<AMODE>::v, LDB = TileLd<BMODE>::v;
     constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
-    __shared__ __attribute__((aligned(16))) float smem[2 * ASZ + 2 * BSZ];
+    constexpr int PIPE = 2 * ASZ + 2 * BSZ, EPI = 4 * 32 * 68;
+    __shared__ __attribute__((aligned(16))) float smem[PIPE > EPI ? PIPE : EPI];
     float* As = smem;
     float* Bs = smem + 2 * ASZ;
 
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(const GemmArgs g) {
     const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0 && tid < BN;
     float csum = 0.0f;
 
-    float4 ra[4], rb[4];
+    float4 ra[NLD], rb[NLD];
     if (nk > 0) {
         la.fetch(ra, kb, ke, dl, tid);
         lb.fetch(rb, kb, ke, dl, tid);
@@ -290,6 +298,8 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, long long stride
 }
 
 }  // namespace
+
+int gemm_block_slots() { return 256 * (BK == 16 ? 4 : 2); }
 
 hipError_t launch_gemm(hipStream_t s, int amode, int bmode, int atr, int btr, const GemmArgs& g) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;

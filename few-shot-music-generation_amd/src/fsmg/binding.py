@@ -83,6 +83,13 @@ def load_library():
         if not os.path.isfile(LIB):
             raise FsmgError(-2, 'libfsmg.so not built (%s); run `python -c "import __graft_entry__ as g; g.build()"` '
                                 'or `make -C few-shot-music-generation_amd/csrc` -- there is no CPU fallback' % LIB)
+        # PyTorch-ROCm ships its own libamdhip64; whichever HIP runtime is loaded first serves the whole
+        # process.  Load torch's first (when torch is installed) so that torch.cuda / RCCL and libfsmg share
+        # one runtime regardless of import order -- the reverse order leaves torch with "No HIP GPUs".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
