@@ -84,10 +84,12 @@ struct fsmg_model {
     float* slabs2 = nullptr;            // ... and of the GEMMs on the auxiliary stream
     float* colsum_slabs2 = nullptr;
     hipStream_t aux = nullptr;          // low-priority stream for the projection GEMMs that overlap the recurrence
-    static constexpr int NCHUNK = 4;    // time chunks of the overlap schedule
+    static constexpr int NCHUNK = 16;   // max time chunks of the overlap schedule
+    int nchunk = 8;                     // chunks in use (FSMG_NCHUNK)
+    int aux_blocks_per_cu = 3;          // occupancy cap of the overlapped GEMMs (FSMG_AUX_BLOCKS); swept: 8 x 3 is best at cfg-B
     hipEvent_t ev_chunk[NCHUNK] = {};   // main -> aux (forward) / aux -> main (backward): chunk ready
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool overlap = false;               // FSMG_OVERLAP=1 enables the two-stream schedule
+    bool overlap = true;                // FSMG_OVERLAP=0 disables the two-stream schedule
     int64_t slab_cap = 0;
     // whole-phase hipGraphs, keyed by the shape of the call; dropped when scratch moves
     std::map<std::string, hipGraphExec_t> graphs;
@@ -281,14 +283,15 @@ int download_tensor(fsmg_model* h, const float* flat, const char* name, float* h
 // idle; splitting K multiplies the block count.  Cost model: MFMA time at ~100 TF/s divided by the
 // slot efficiency of tiles*S blocks over the resident-block slots, plus S slabs of C written and read back.
 constexpr int MAX_SPLIT = 16;
-int pick_split(int64_t M, int64_t N, int64_t K) {
+int pick_split(int64_t M, int64_t N, int64_t K, int64_t slots = 0) {
+    if (slots <= 0) slots = gemm_block_slots();
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const double t_mfma = 2.0 * M * N * K / 100e12;
     const double t_slab = 2.0 * M * N * 4.0 / 4e12;
     int best = 1; double best_t = 1e30;
     for (int S = 1; S <= MAX_SPLIT; ++S) {
         if (S > 1 && K / S < 256) break;
-        const int64_t blocks = tiles * S, slots = gemm_block_slots();
+        const int64_t blocks = tiles * S;
         const double eff = (double)blocks / (double)(((blocks + slots - 1) / slots) * slots);
         const double t = t_mfma / eff + (S > 1 ? S * t_slab : 0.0);
         if (t < best_t - 1e-12) { best_t = t; best = S; }
@@ -329,17 +332,23 @@ int ensure_scratch(fsmg_model* h, int B) {
     int64_t slab_need = 0;
     {
         auto need = [&](int64_t M, int64_t N, int64_t K) {
-            const int S = pick_split(M, N, K);
-            if (S > 1) slab_need = std::max(slab_need, (int64_t)S * M * N);
+            for (int64_t slots : {(int64_t)256 * h->aux_blocks_per_cu, (int64_t)gemm_block_slots()}) {
+                const int S = pick_split(M, N, K, slots);
+                if (S > 1) slab_need = std::max(slab_need, (int64_t)S * M * N);
+            }
         };
         need(rows, Hp, h->V1p); need(Hp, h->V1p, rows); need(Hp, G4, rows);
         need(h->Ep, G4, rows); need(rows, h->Ep, G4); need(rows, Hp, G4); need(rows, G4, h->Ep); need(rows, G4, Hp);
     }
     // chunked dH GEMMs of the overlap schedule have their own (smaller) shapes
-    for (int c = 0; c < fsmg_model::NCHUNK; ++c) {
-        const int64_t m = ((int64_t)(c + 1) * T / fsmg_model::NCHUNK - (int64_t)c * T / fsmg_model::NCHUNK) * B;
-        const int S = pick_split(m, Hp, h->V1p);
-        if (S > 1) slab_need = std::max(slab_need, (int64_t)S * m * Hp);
+    for (int c = 0; c < h->nchunk; ++c) {
+        const int64_t m = ((int64_t)(c + 1) * T / h->nchunk - (int64_t)c * T / h->nchunk) * B;
+        for (int64_t slots : {(int64_t)256 * h->aux_blocks_per_cu, (int64_t)gemm_block_slots()}) {
+            const int S = pick_split(m, Hp, h->V1p, slots);
+            if (S > 1) slab_need = std::max(slab_need, (int64_t)S * m * Hp);
+            const int S2 = pick_split(m, h->V1p, Hp, slots);
+            if (S2 > 1) slab_need = std::max(slab_need, (int64_t)S2 * m * h->V1p);
+        }
     }
     const int64_t o_slab = place(4 * std::max<int64_t>(slab_need, 64));
     const int64_t o_cslab = place(4 * (int64_t)MAX_SPLIT * std::max<int64_t>(h->V1p, G4));
@@ -379,25 +388,25 @@ void drop_graphs(fsmg_model* h) {
 }
 
 // A stream plus the split-K slab buffers its GEMMs may use.
-struct Lane { hipStream_t s; float* slabs; float* colsum_slabs; };
-inline Lane main_lane(fsmg_model* h) { return Lane{h->stream, h->slabs, h->colsum_slabs}; }
-inline Lane aux_lane(fsmg_model* h) { return Lane{h->aux, h->slabs2, h->colsum_slabs2}; }
+struct Lane { hipStream_t s; float* slabs; float* colsum_slabs; int lds_pad; int slots; };
+inline Lane main_lane(fsmg_model* h) { return Lane{h->stream, h->slabs, h->colsum_slabs, 0, gemm_block_slots()}; }
+inline Lane aux_lane(fsmg_model* h) { return Lane{h->aux, h->slabs2, h->colsum_slabs2, gemm_lds_pad_for(h->aux_blocks_per_cu), 256 * h->aux_blocks_per_cu}; }
 
 // C (contiguous, ldc == N) = op(A) * op(B) with the K range split over pick_split() slabs that are
 // summed in a fixed order (deterministic); colsum likewise.
 int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, int atr, int btr, GemmArgs g) {
     hipStream_t s = ln.s;
-    const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K) : 1;
+    const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K, ln.slots) : 1;
     if (S <= 1 || (int64_t)S * g.M * g.N > h->slab_cap) {
         g.ksplit = 1;
-        HIPCK(h, launch_gemm(s, amode, bmode, atr, btr, g));
+        HIPCK(h, launch_gemm(s, amode, bmode, atr, btr, g, ln.lds_pad));
         return FSMG_OK;
     }
     float* C = g.C; float* colsum = g.colsum;
     const int64_t mn = (int64_t)g.M * g.N;
     g.C = ln.slabs; g.c_slab = mn; g.ksplit = S;
     if (colsum) { g.colsum = ln.colsum_slabs; g.colsum_slab = g.N; }
-    HIPCK(h, launch_gemm(s, amode, bmode, atr, btr, g));
+    HIPCK(h, launch_gemm(s, amode, bmode, atr, btr, g, ln.lds_pad));
     HIPCK(h, launch_reduce_slabs(s, ln.slabs, mn, S, C, mn));
     if (colsum) HIPCK(h, launch_reduce_slabs(s, ln.colsum_slabs, g.N, S, colsum, g.N));
     return FSMG_OK;
@@ -410,7 +419,9 @@ int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, int atr, int btr, 
 // needs eager launches, so graphs are bypassed while it is on.
 template <class F>
 int run_graphed(fsmg_model* h, const std::string& key, F&& body) {
-    if (!h->cfg.use_graph || h->timing) return body();
+    // hipGraph (ROCm 7.2) runs captured cross-stream branches one after the other, so the two-stream
+    // schedule only overlaps with eager launches
+    if (!h->cfg.use_graph || h->timing || h->overlap) return body();
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -463,8 +474,8 @@ int token_prep(fsmg_model* h, int n_sup, int n_qry) {
 //   backward: the BPTT steps of chunk c need dH only for t in chunk c; dW needs no BPTT result at all
 // so the projection work runs on a low-priority auxiliary stream, forked / joined with events (inside
 // the captured graph these become parallel branches).  Event timing (eager, one class at a time)
-// and the default (FSMG_OVERLAP unset) use the single-stream order.
-inline bool use_overlap(const fsmg_model* h) { return h->overlap && !h->timing && h->aux != nullptr && h->T >= fsmg_model::NCHUNK; }
+// and FSMG_OVERLAP=0 use the single-stream order.
+inline bool use_overlap(const fsmg_model* h) { return h->overlap && !h->timing && h->aux != nullptr && h->T >= h->nchunk; }
 
 int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t rows_total, bool want_dlogits) {
     const int Hp = h->Hp;
@@ -493,7 +504,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
-    const int nch = ov ? fsmg_model::NCHUNK : 1;
+    const int nch = ov ? h->nchunk : 1;
     for (int l = 0; l < h->L; ++l) {
         const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
         const bool top = l == h->L - 1;
@@ -572,7 +583,7 @@ int backward(fsmg_model* h, int B) {
     const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
-    const int nch = ov ? fsmg_model::NCHUNK : 1;
+    const int nch = ov ? h->nchunk : 1;
     HIPCK(h, hipMemsetAsync(h->G + h->off_emb, 0, sizeof(float) * (size_t)h->V1 * h->Ep, s));
     if (ov) {
         // aux: dH chunks in the order BPTT consumes them (last chunk first), then dW
@@ -745,10 +756,13 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         h->own_stream = true;
     }
     {
-        // measured on MI355X at cfg-B (profiles/): the two-stream schedule is bit-identical but ~7 % SLOWER
-        // (co-resident GEMM traffic lengthens the recurrent hand-off latency), so it is opt-in
+        if (const char* eg = std::getenv("FSMG_GRAPH")) h->cfg.use_graph = (eg[0] != '0');   // debugging override
+        // two-stream schedule: on by default (measured +11 % at cfg-B with the overlapped GEMMs capped at three
+        // blocks per CU); FSMG_OVERLAP=0 selects the single-stream order (which is replayed from hipGraphs)
         const char* env = std::getenv("FSMG_OVERLAP");
-        h->overlap = (env && env[0] == '1');
+        h->overlap = !(env && env[0] == '0');
+        if (const char* e = std::getenv("FSMG_NCHUNK")) h->nchunk = std::max(1, std::min((int)fsmg_model::NCHUNK, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) h->aux_blocks_per_cu = std::max(1, std::min(4, std::atoi(e)));
         int least = 0, greatest = 0;
         hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, least) != hipSuccess) return bail(FSMG_ERR_HIP, "aux stream create failed");

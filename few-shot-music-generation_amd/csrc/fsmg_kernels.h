@@ -35,7 +35,9 @@ struct GemmArgs {
 };
 // amode/bmode in {OP_KC, OP_XC}; atr/btr in {TR_NONE, TR_DLOGITS}. Supported combinations:
 // (KC,XC,*,NONE) (XC,XC,NONE,*) (KC,KC,*,NONE)
-hipError_t launch_gemm(hipStream_t s, int amode, int bmode, int atr, int btr, const GemmArgs& g);
+hipError_t launch_gemm(hipStream_t s, int amode, int bmode, int atr, int btr, const GemmArgs& g, int lds_pad = 0);
+// dynamic-LDS padding that caps a GEMM at `blocks_per_cu` resident blocks per CU
+int gemm_lds_pad_for(int blocks_per_cu);
 // resident 128x128 blocks the chip holds at once (256 CUs x blocks per CU): the split-K policy's slot count
 int gemm_block_slots();
 // out[i] = sum_z slabs[z][i]  (fixed order -> deterministic split-K)

@@ -279,10 +279,11 @@ __global__ __launch_bounds__(NTHREADS, BK == 16 ? 4 : 2) void k_gemm(const GemmA
 }
 
 template <int AMODE, int BMODE, int ATR, int BTR>
-hipError_t launch_t(hipStream_t s, const GemmArgs& g) {
+hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     dim3 grid(tilesM * tilesN, g.ksplit > 1 ? g.ksplit : 1);
-    hipLaunchKernelGGL((k_gemm<AMODE, BMODE, ATR, BTR>), grid, dim3(NTHREADS), 0, s, g);
+    // lds_pad: unused dynamic LDS that only lowers the number of co-resident blocks per CU
+    hipLaunchKernelGGL((k_gemm<AMODE, BMODE, ATR, BTR>), grid, dim3(NTHREADS), lds_pad, s, g);
     return hipGetLastError();
 }
 
@@ -300,20 +301,29 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, long long stride
 }  // namespace
 
 int gemm_block_slots() { return 256 * (BK == 16 ? 4 : 2); }
+// dynamic-LDS padding that caps the resident blocks per CU (160 KiB LDS): leaves room for the recurrent-step
+// kernels' waves and registers when a GEMM runs beside them on the auxiliary stream
+int gemm_lds_pad_for(int blocks_per_cu) {
+    constexpr int own = (BK == 16) ? 34816 : 67584;                 // static LDS of one block
+    const int max_blocks = (BK == 16) ? 4 : 2;
+    if (blocks_per_cu >= max_blocks) return 0;
+    const int budget = (160 * 1024) / blocks_per_cu;                // LDS share that admits exactly this many
+    return budget - own - 1024 > 0 ? budget - own - 1024 : 0;
+}
 
-hipError_t launch_gemm(hipStream_t s, int amode, int bmode, int atr, int btr, const GemmArgs& g) {
+hipError_t launch_gemm(hipStream_t s, int amode, int bmode, int atr, int btr, const GemmArgs& g, int lds_pad) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (amode == OP_KC && bmode == OP_XC && btr == TR_NONE) {
-        return atr == TR_NONE ? launch_t<OP_KC, OP_XC, TR_NONE, TR_NONE>(s, g)
-                              : launch_t<OP_KC, OP_XC, TR_DLOGITS, TR_NONE>(s, g);
+        return atr == TR_NONE ? launch_t<OP_KC, OP_XC, TR_NONE, TR_NONE>(s, g, lds_pad)
+                              : launch_t<OP_KC, OP_XC, TR_DLOGITS, TR_NONE>(s, g, lds_pad);
     }
     if (amode == OP_XC && bmode == OP_XC && atr == TR_NONE) {
-        return btr == TR_NONE ? launch_t<OP_XC, OP_XC, TR_NONE, TR_NONE>(s, g)
-                              : launch_t<OP_XC, OP_XC, TR_NONE, TR_DLOGITS>(s, g);
+        return btr == TR_NONE ? launch_t<OP_XC, OP_XC, TR_NONE, TR_NONE>(s, g, lds_pad)
+                              : launch_t<OP_XC, OP_XC, TR_NONE, TR_DLOGITS>(s, g, lds_pad);
     }
     if (amode == OP_KC && bmode == OP_KC && btr == TR_NONE) {
-        return atr == TR_NONE ? launch_t<OP_KC, OP_KC, TR_NONE, TR_NONE>(s, g)
-                              : launch_t<OP_KC, OP_KC, TR_DLOGITS, TR_NONE>(s, g);
+        return atr == TR_NONE ? launch_t<OP_KC, OP_KC, TR_NONE, TR_NONE>(s, g, lds_pad)
+                              : launch_t<OP_KC, OP_KC, TR_DLOGITS, TR_NONE>(s, g, lds_pad);
     }
     return hipErrorInvalidValue;
 }

@@ -172,18 +172,21 @@ def test_device_resident_tokens_match_host_tokens():
     assert a.eval_step(qry) == b.eval_step(dq.data_ptr(), shape=(2, 1))
 
 
-def test_graph_replay_equals_eager_launches():
+def test_all_schedules_are_bit_identical(monkeypatch):
+    """two-stream overlap (default, eager) == single stream replayed from hipGraphs == single stream eager"""
     cfg = small_config(hidden_size=32, embedding_size=16, input_size=99, max_len=8, n_layers=2)
     eps = O.synthetic_episodes(4, 3, 2, 2, cfg['max_len'], cfg['input_size'], seed=11)
     out = []
-    for use_graph in (True, False):
+    for overlap, use_graph in (('1', True), ('0', True), ('0', False)):
+        monkeypatch.setenv('FSMG_OVERLAP', overlap)
         model = new_model(cfg, use_graph=use_graph)
-        losses = [model.train_step(s, q) for s, q in eps]            # step 0 captures, 1.. replay
+        losses = [model.train_step(s, q) for s, q in eps]            # graph mode: step 0 captures, 1.. replay
         evals = [model.eval_step(q) for _, q in eps]
         out.append((losses, evals, model.get_params()))
-    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
-    for k in out[0][2]:
-        np.testing.assert_array_equal(out[0][2][k], out[1][2][k])
+    for other in out[1:]:
+        assert out[0][0] == other[0] and out[0][1] == other[1]
+        for k in out[0][2]:
+            np.testing.assert_array_equal(out[0][2][k], other[2][k])
 
 
 def test_split_k_paths_match_oracle_at_wide_shapes():
