@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ logit
         d.y = (v + 1 < n_vocab) ? (expf(x.y - l) - (v + 1 == t ? 1.0f : 0.0f)) * inv_n : 0.0f;
         d.z = (v + 2 < n_vocab) ? (expf(x.z - l) - (v + 2 == t ? 1.0f : 0.0f)) * inv_n : 0.0f;
         d.w = (v + 3 < n_vocab) ? (expf(x.w - l) - (v + 3 == t ? 1.0f : 0.0f)) * inv_n : 0.0f;
-        *reinterpret_cast<float4*>(drow + v) = d;
+        __builtin_nontemporal_store(d.x, drow + v); __builtin_nontemporal_store(d.y, drow + v + 1);
+        __builtin_nontemporal_store(d.z, drow + v + 2); __builtin_nontemporal_store(d.w, drow + v + 3);
     }
 }
 

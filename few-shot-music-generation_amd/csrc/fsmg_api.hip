@@ -486,7 +486,7 @@ int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t 
         g.A = h->Hs[h->L - 1] + (size_t)B * Hp + (size_t)r0 * Hp; g.lda = Hp;
         g.B = h->P + h->off_w; g.ldb = h->V1p;
         g.C = h->logits + (size_t)r0 * h->V1p; g.ldc = h->V1p; g.M = (int)m; g.N = h->V1p; g.K = Hp;
-        g.bias = h->P + h->off_d; g.ksplit = 1;
+        g.bias = h->P + h->off_d; g.ksplit = 1; g.nt_store = 1;
         GEMMCK(gemm(h, ln, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
     }
     {

@@ -32,6 +32,7 @@ struct GemmArgs {
     int ksplit;             // >= 1; slab z covers a K range, C/colsum slab stride below
     long long c_slab;       // elements between consecutive K-split slabs of C
     long long colsum_slab;
+    int nt_store;           // 1: C is written with non-temporal stores (streaming, read back much later)
 };
 // amode/bmode in {OP_KC, OP_XC}; atr/btr in {TR_NONE, TR_DLOGITS}. Supported combinations:
 // (KC,XC,*,NONE) (XC,XC,NONE,*) (KC,KC,*,NONE)

@@ -270,7 +270,13 @@ __global__ __launch_bounds__(NTHREADS, BK == 16 ? 4 : 2) void k_gemm(const GemmA
                     const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 }
-                *reinterpret_cast<float4*>(C + (long long)row * g.ldc + col) = v;
+                float4* dst = reinterpret_cast<float4*>(C + (long long)row * g.ldc + col);
+                if (g.nt_store) {       // write-once streaming output (logits): keep it out of the way of L2-resident data
+                    __builtin_nontemporal_store(v.x, &dst->x); __builtin_nontemporal_store(v.y, &dst->y);
+                    __builtin_nontemporal_store(v.z, &dst->z); __builtin_nontemporal_store(v.w, &dst->w);
+                } else {
+                    *dst = v;
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                    // reads done before the slice is overwritten

@@ -295,3 +295,33 @@ def test_plugin_api_checkpoint_resume(tmp_path):
     assert a.eval_many([ep, ep]) == [a.eval(ep)] * 2
     assert os.path.isfile(os.path.join(str(tmp_path), 'lstm_baseline', 'lstm_baseline-3.npz'))
     assert len(a.sample(sup[0], 5)) == 5 and l1[0] > 0
+
+
+# ------------------------------------------------------------------ full-size configurations (BASELINE.json configs)
+FULL = {
+    'cfg-B': (dict(input_size=10000, max_len=128, embedding_size=250, hidden_size=512, n_layers=1), 5, 5, 4),
+    'cfg-C': (dict(input_size=4708, max_len=50, embedding_size=250, hidden_size=1024, n_layers=2), 5, 5, 4),
+    'cfg-D': (dict(input_size=10000, max_len=128, embedding_size=250, hidden_size=512, n_layers=1), 20, 1, 4),
+}
+
+
+@pytest.mark.parametrize('name', sorted(FULL))
+def test_full_size_properties(name):
+    """At BASELINE.json's full sizes the fp64 oracle is too slow for a trajectory, so check size-independent
+    properties: untrained NLL ~ ln(V1); eval of the query set == the same rows inside eval_batch; training on
+    one episode repeatedly lowers its loss monotonically at first; loss is finite and run-to-run bit-stable;
+    and ONE oracle eval (forward only, fp64) pins the full-size forward to 1e-4."""
+    over, N, K, Q = FULL[name]
+    cfg = small_config(**over)
+    (sup, qry), (sup2, qry2) = O.synthetic_episodes(2, N, K, Q, cfg['max_len'], cfg['input_size'], seed=21)
+    model = new_model(cfg)
+    nll0 = model.eval_step(qry)
+    assert abs(nll0 - np.log(cfg['input_size'] + 1)) < 0.02
+    want = O.eval_step(f64_params(model), qry, cfg)
+    assert abs(nll0 - want) <= NLL_RTOL * abs(want)
+    both = model.eval_batch(np.stack([qry, qry2]))
+    assert both[0] == np.float32(nll0) and both[1] == np.float32(model.eval_step(qry2))
+    losses = [model.train_step(sup, qry) for _ in range(4)]
+    assert np.all(np.isfinite(losses)) and losses[0] > losses[1] > losses[2] > losses[3]
+    again = new_model(cfg)
+    assert [again.train_step(sup, qry) for _ in range(4)] == losses
