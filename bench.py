@@ -43,6 +43,16 @@ CLASSES = ['gemm_zx', 'lstm_fwd', 'gemm_logits', 'ce', 'gemm_dhout', 'gemm_dw', 
            'gemm_dx', 'embed_grad', 'update']
 
 
+def hbm_traffic():
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
+    correction + WRITE_SIZE), recorded under profiles/ -- counters cannot be read from inside this process"""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_dw_gemm_hbm_traffic.json')) as f:
+            return json.load(f)['traffic_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def algorithmic_gflop(cfg, B):
     """per-class algorithmic FLOPs of one train episode: 2*M*N*K of the unpadded shapes"""
     T, E, H, V1 = cfg['max_len'], cfg['embedding_size'], cfg['hidden_size'], cfg['input_size'] + 1
@@ -177,11 +187,24 @@ def main():
                        'episodes_per_step': world, 'parallelism': 'episode-parallel x%d, 1 RCCL all-reduce/step' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_gemm<XC,XC,NONE,NONE> (dW = out^T * dlogits, M=512 N=10004 K=5760)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': hbm_traffic(),
                          'avg_launch_ms': dom_avg_ms, 'launches': dom_n, 'algorithmic_gflop_per_launch': gf[DOMINANT]},
             'step_mfma_frac': (total_gflop / (1e3 * elapsed / max(args.steps, 1))) / PEAK_F32_MFMA_TFLOPS,
             'final_loss': float(losses[-1]), 'first_loss': float(losses[0]),
         }
+    if rank == 0:
+        # the other half of BASELINE.json's metric: the validation path (query-only forward, batched 16 episodes
+        # per call like train.evaluate does); inputs resident in HBM, NLLs read back per call
+        n_ev, reps = 16, 5
+        qptr = d_qry.data_ptr()
+        eng.eval_batch(qptr, shape=(n_ev, N_WAY, Q_QUERY))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for r in range(reps):
+            nll = eng.eval_batch(qptr + r * n_ev * qry_stride, shape=(n_ev, N_WAY, Q_QUERY))
+        torch.cuda.synchronize()
+        out['eval'] = {'episodes_per_s': n_ev * reps / (time.perf_counter() - t0), 'batch_episodes': n_ev,
+                       'mean_val_nll': float(np.mean(nll)), 'unit': 'eval episodes/s (query-only forward, 20 sequences/episode)'}
     if rank == 0 and world == 1 and not args.no_breakdown:
         # second, fully instrumented pass: every kernel class bracketed by HIP events (extra information)
         eng.timing_select(None)

@@ -9,6 +9,7 @@ import sys
 def short(name):
     name = re.sub(r'fsmg::\(anonymous namespace\)::', '', name)
     name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'\(fsmg::\w+Args(, unsigned long long\*)?\)', '', name)
     return name if len(name) <= 110 else name[:107] + '...'
 
 
@@ -16,8 +17,10 @@ def main(path):
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     name_col = 'name' if 'name' in cols else [c for c in cols if 'name' in c][0]
-    rows = db.execute("select %s, count(*), sum(end - start), avg(end - start), min(end - start), max(end - start) "
-                      "from kernels group by %s order by 3 desc" % (name_col, name_col)).fetchall()
+    # grouped by kernel AND grid so the shapes of one templated kernel (e.g. the dW / dKh / dKx GEMMs) stay apart
+    rows = db.execute("select %s || '  [grid ' || grid_x || 'x' || grid_y || ', wg ' || workgroup_x || ']', count(*), "
+                      "sum(end - start), avg(end - start), min(end - start), max(end - start) "
+                      "from kernels group by %s, grid_x, grid_y order by 3 desc" % (name_col, name_col)).fetchall()
     total = float(sum(r[2] for r in rows)) or 1.0
     print('%-110s %8s %12s %11s %11s %11s %6s' % ('kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', '%'))
     for n, c, s, a, mn, mx in rows:
