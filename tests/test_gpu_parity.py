@@ -325,3 +325,34 @@ def test_full_size_properties(name):
     assert np.all(np.isfinite(losses)) and losses[0] > losses[1] > losses[2] > losses[3]
     again = new_model(cfg)
     assert [again.train_step(sup, qry) for _ in range(4)] == losses
+
+
+def test_nccl_allreduce_runs_on_the_gradient_tensor_and_model_stream():
+    """Single-rank RCCL group: the real flat gradient tensor (a view into the torch-allocated state arena) goes
+    through dist.all_reduce on the model's stream, and the split step (forward_backward -> all_reduce ->
+    apply_update(1/world)) equals the fused step."""
+    import torch
+    import torch.distributed as dist
+    from data.episode import Episode
+    from fsmg.dist import EpisodeParallel
+    from models.lstm_baseline import LSTMBaseline
+    cfg = small_config()
+    sup, qry = _episode(cfg, 2, 2, 1)
+    ref = LSTMBaseline(dict(cfg)); ref.recover_or_init('')
+    want = [ref.train(Episode(sup, qry)) for _ in range(3)]
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 300))
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        m = LSTMBaseline(dict(cfg)); m.recover_or_init('')        # broadcasts the arena over RCCL (no-op for 1 rank)
+        assert m.grad_tensor.is_cuda and m.grad_tensor.dtype == torch.float32
+        got = []
+        for _ in range(3):
+            m.forward_backward(sup, qry)
+            with m.stream_context():
+                dist.all_reduce(m.grad_tensor, op=dist.ReduceOp.SUM)
+            got.append(m.apply_update(1.0))
+        assert got == want
+        assert EpisodeParallel(m).world == 1
+    finally:
+        dist.destroy_process_group()
