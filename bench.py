@@ -36,6 +36,12 @@ import numpy as np   # noqa: E402
 CFG_B = dict(name='lstm_baseline', seed=1234, input_size=10000, max_len=128, embedding_size=250,
              hidden_size=512, n_layers=1, lr=5e-3, max_grad_norm=5, n_decay=10000)
 N_WAY, K_SHOT, Q_QUERY = 5, 5, 4
+# other BASELINE.json configurations (parity-test cases; selectable for diagnostics, never the headline)
+OTHER = {
+    'cfg-C': (dict(name='lstm_baseline', seed=1234, input_size=4708, max_len=50, embedding_size=250, hidden_size=1024,
+                   n_layers=2, lr=5e-3, max_grad_norm=5, n_decay=10000), 5, 5, 4),
+    'cfg-D': (dict(CFG_B), 20, 1, 4),
+}
 POOL = 256
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 DOMINANT = 'gemm_dw'
@@ -55,11 +61,11 @@ def hbm_traffic():
 
 def algorithmic_gflop(cfg, B):
     """per-class algorithmic FLOPs of one train episode: 2*M*N*K of the unpadded shapes"""
-    T, E, H, V1 = cfg['max_len'], cfg['embedding_size'], cfg['hidden_size'], cfg['input_size'] + 1
+    T, E, H, V1, L = cfg['max_len'], cfg['embedding_size'], cfg['hidden_size'], cfg['input_size'] + 1, cfg['n_layers']
     n = B * T
-    g = {'gemm_zx': 2 * n * E * 4 * H, 'lstm_fwd': 2 * n * H * 4 * H, 'gemm_logits': 2 * n * H * V1,
-         'gemm_dhout': 2 * n * H * V1, 'gemm_dw': 2 * n * H * V1, 'lstm_bwd': 2 * n * H * 4 * H,
-         'gemm_dk': 2 * n * (E + H) * 4 * H, 'gemm_dx': 2 * n * E * 4 * H}
+    g = {'gemm_zx': 2 * n * (E + (L - 1) * H) * 4 * H, 'lstm_fwd': 2 * n * H * 4 * H * L, 'gemm_logits': 2 * n * H * V1,
+         'gemm_dhout': 2 * n * H * V1, 'gemm_dw': 2 * n * H * V1, 'lstm_bwd': 2 * n * H * 4 * H * L,
+         'gemm_dk': 2 * n * (E + H + (L - 1) * 2 * H) * 4 * H, 'gemm_dx': 2 * n * (E + (L - 1) * H) * 4 * H}
     return {k: v / 1e9 for k, v in g.items()}
 
 
@@ -101,6 +107,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
+    ap.add_argument('--config', default='cfg-B', choices=['cfg-B', 'cfg-C', 'cfg-D'])
     args = ap.parse_args()
 
     import torch
@@ -114,7 +121,11 @@ def main():
         raise SystemExit('launched with WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
-    cfg = dict(CFG_B, device=local)
+    global N_WAY, K_SHOT, Q_QUERY
+    base = CFG_B
+    if args.config != 'cfg-B':
+        base, N_WAY, K_SHOT, Q_QUERY = OTHER[args.config]
+    cfg = dict(base, device=local)
     B = N_WAY * (K_SHOT + Q_QUERY)
 
     pool_host = O.synthetic_episodes(POOL, N_WAY, K_SHOT, Q_QUERY, cfg['max_len'], cfg['input_size'],
@@ -182,7 +193,7 @@ def main():
             'value': value, 'unit': 'episodes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'cfg-B: synthetic V=10000 (V1=10001) T=128 5-way 5-shot 4-query (B=45 sequences/episode), '
+            'config': {'workload': (args.config + ' (diagnostic run, not the headline workload) -- ' if args.config != 'cfg-B' else '') + 'cfg-B: synthetic V=10000 (V1=10001) T=128 5-way 5-shot 4-query (B=45 sequences/episode), '
                                    'LSTM E=250 H=512 L=1, full train step (fwd+BPTT+clip+Adam), one episode per GPU per step',
                        'episodes_per_step': world, 'parallelism': 'episode-parallel x%d, 1 RCCL all-reduce/step' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_gemm<XC,XC,NONE,NONE> (dW = out^T * dlogits, M=512 N=10004 K=5760)',
@@ -228,7 +239,7 @@ def main():
         out['kernels'] = kernels
         log('breakdown done')
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(CFG_B, pool_host)
+        out['cpu_baseline'] = cpu_baseline(base, pool_host)
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:

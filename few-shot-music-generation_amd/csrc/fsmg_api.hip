@@ -757,10 +757,11 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     }
     {
         if (const char* eg = std::getenv("FSMG_GRAPH")) h->cfg.use_graph = (eg[0] != '0');   // debugging override
-        // two-stream schedule: on by default (measured +11 % at cfg-B with the overlapped GEMMs capped at three
-        // blocks per CU); FSMG_OVERLAP=0 selects the single-stream order (which is replayed from hipGraphs)
+        // two-stream schedule: pays when the vocabulary projection dominates the recurrence (measured: +13 % at
+        // cfg-B/D where V1/(4H*L) = 4.9; -7 % at cfg-C where it is 0.6), so by default it is chosen from the
+        // shapes; FSMG_OVERLAP=0/1 forces the single-stream (hipGraph-replayed) / two-stream (eager) order
         const char* env = std::getenv("FSMG_OVERLAP");
-        h->overlap = !(env && env[0] == '0');
+        h->overlap = env ? (env[0] != '0') : ((int64_t)h->V1 >= 8LL * h->H * h->L);
         if (const char* e = std::getenv("FSMG_NCHUNK")) h->nchunk = std::max(1, std::min((int)fsmg_model::NCHUNK, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) h->aux_blocks_per_cu = std::max(1, std::min(4, std::atoi(e)));
         int least = 0, greatest = 0;
