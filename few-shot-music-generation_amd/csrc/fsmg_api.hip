@@ -978,9 +978,12 @@ int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, i
     if (rc != FSMG_OK) return rc;
     const int per = N * Q;
     if (per <= 0) return fail(h, FSMG_ERR_INVALID, "empty query set");
-    if ((rc = ensure_scratch(h, per)) != FSMG_OK) return rc;
+    // validation episodes are independent: batch up to EVAL_EPISODES of them per pass so that the recurrent
+    // chain (one launch per time step regardless of the row count) is amortised over many rows
+    constexpr int EVAL_EPISODES = 16;
+    if ((rc = ensure_scratch(h, per * std::min<int>(n_episodes, EVAL_EPISODES))) != FSMG_OK) return rc;
     if ((rc = ensure_khf(h)) != FSMG_OK) return rc;
-    const int chunk_eps = h->Bcap / per;
+    const int chunk_eps = std::min<int>(h->Bcap / per, 64);
     if (h->eval_cap < chunk_eps) {
         HIPCK(h, hipStreamSynchronize(h->stream));
         if (h->d_eval) hipFree(h->d_eval);
