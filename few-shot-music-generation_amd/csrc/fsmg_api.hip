@@ -89,6 +89,7 @@ struct fsmg_model {
     int aux_blocks_per_cu = 3;          // occupancy cap of the overlapped GEMMs (FSMG_AUX_BLOCKS); swept: 8 x 3 is best at cfg-B
     hipEvent_t ev_chunk[NCHUNK] = {};   // main -> aux (forward) / aux -> main (backward): chunk ready
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_bucket[2] = {};       // [0] softmax gradients final, [1] backward complete
     bool overlap = true;                // FSMG_OVERLAP=0 disables the two-stream schedule
     int64_t slab_cap = 0;
     // whole-phase hipGraphs, keyed by the shape of the call; dropped when scratch moves
@@ -596,6 +597,7 @@ int backward(fsmg_model* h, int B) {
         }
         GEMMCK(dw_gemm(h, aux_lane(h), B));
         HIPCK(h, hipEventRecord(h->ev_join, h->aux));
+        HIPCK(h, hipEventRecord(h->ev_bucket[0], h->aux));
     } else {
         GEMMCK(dhout_chunk(h, mainl, B, 0, T));
         GEMMCK(dw_gemm(h, mainl, B));
@@ -769,7 +771,9 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, least) != hipSuccess) return bail(FSMG_ERR_HIP, "aux stream create failed");
         for (int c = 0; c < fsmg_model::NCHUNK; ++c)
             if (hipEventCreateWithFlags(&h->ev_chunk[c], hipEventDisableTiming) != hipSuccess) return bail(FSMG_ERR_HIP, "event create failed");
-        if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        if (hipEventCreateWithFlags(&h->ev_bucket[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_bucket[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return bail(FSMG_ERR_HIP, "event create failed");
     }
     const int64_t sb = state_bytes_for(h->n_flat);
@@ -822,6 +826,8 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->d_eval) hipFree(h->d_eval);
     if (h->own_state && h->state) hipFree(h->state);
     for (int c = 0; c < fsmg_model::NCHUNK; ++c) if (h->ev_chunk[c]) hipEventDestroy(h->ev_chunk[c]);
+    if (h->ev_bucket[0]) hipEventDestroy(h->ev_bucket[0]);
+    if (h->ev_bucket[1]) hipEventDestroy(h->ev_bucket[1]);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->aux) hipStreamDestroy(h->aux);
@@ -938,6 +944,10 @@ int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* 
         return r;
     });
     if (rc != FSMG_OK) return rc;
+    // bucket readiness for an overlapped gradient exchange: with the two-stream (eager) schedule bucket 0 was
+    // recorded right behind the dW GEMM on the aux stream; a replayed graph finishes as a whole
+    if (!use_overlap(h)) HIPCK(h, hipEventRecord(h->ev_bucket[0], h->stream));
+    HIPCK(h, hipEventRecord(h->ev_bucket[1], h->stream));
     h->lastB = B;
     h->have_grads = true;
     return FSMG_OK;
@@ -947,6 +957,22 @@ int fsmg_grad_buffer(fsmg_handle h, void** device_ptr, int64_t* count) {
     if (!h || !device_ptr || !count) return FSMG_ERR_INVALID;
     *device_ptr = h->G;
     *count = h->n_flat + FSMG_GRAD_TAIL;
+    return FSMG_OK;
+}
+
+int fsmg_grad_bucket(fsmg_handle h, int32_t bucket, void** device_ptr, int64_t* count) {
+    if (!h || !device_ptr || !count || bucket < 0 || bucket >= FSMG_NUM_BUCKETS) return FSMG_ERR_INVALID;
+    if (bucket == 0) { *device_ptr = h->G + h->off_w; *count = h->n_flat - h->off_w; }
+    else if (bucket == 1) { *device_ptr = h->G; *count = h->off_w; }
+    else { *device_ptr = h->G + h->n_flat; *count = FSMG_GRAD_TAIL; }
+    return FSMG_OK;
+}
+
+int fsmg_stream_wait_bucket(fsmg_handle h, void* stream, int32_t bucket) {
+    if (!h || bucket < 0 || bucket >= FSMG_NUM_BUCKETS) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    if (!h->have_grads) return fail(h, FSMG_ERR_STATE, "no backward pass is pending");
+    HIPCK(h, hipStreamWaitEvent((hipStream_t)stream, h->ev_bucket[bucket == 0 ? 0 : 1], 0));
     return FSMG_OK;
 }
 

@@ -55,6 +55,8 @@ SIGNATURES = {
     'fsmg_train_step': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F32P]),
     'fsmg_forward_backward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'fsmg_grad_buffer': (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    'fsmg_grad_bucket': (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    'fsmg_stream_wait_bucket': (C.c_int, [_P, _P, C.c_int32]),
     'fsmg_apply_update': (C.c_int, [_P, C.c_float, _F32P]),
     'fsmg_eval_step': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _F32P]),
     'fsmg_eval_batch': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F32P]),
@@ -241,6 +243,14 @@ class FsmgModel(object):
         ptr, count = _P(), C.c_int64()
         self._ck(self._lib.fsmg_grad_buffer(self._h, C.byref(ptr), C.byref(count)))
         return ptr.value, count.value
+
+    def grad_bucket(self, bucket):
+        ptr, count = _P(), C.c_int64()
+        self._ck(self._lib.fsmg_grad_bucket(self._h, int(bucket), C.byref(ptr), C.byref(count)))
+        return ptr.value, count.value
+
+    def stream_wait_bucket(self, stream_handle, bucket):
+        self._ck(self._lib.fsmg_stream_wait_bucket(self._h, C.c_void_p(stream_handle), int(bucket)))
 
     def apply_update(self, grad_scale=1.0, want_loss=True):
         loss = C.c_float()

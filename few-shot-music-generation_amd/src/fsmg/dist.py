@@ -34,6 +34,8 @@ class EpisodeParallel(object):
     def __init__(self, engine, group=None):
         self.engine = engine
         self.group = group
+        import os
+        self.bucketed = os.environ.get('FSMG_DP_BUCKETS', '1') != '0'      # 0: one all-reduce after backward
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -49,7 +51,18 @@ class EpisodeParallel(object):
 
     def train_step(self, support, query, want_loss=True, **kw):
         self.engine.forward_backward(support, query, **kw)
-        if self.world > 1:
+        buckets = getattr(self.engine, 'grad_buckets', None)
+        if self.world > 1 and buckets is not None and self.bucketed:
+            # overlapped exchange: each bucket is reduced on the communication stream as soon as it is final
+            # (bucket 0 = softmax gradients, ready while BPTT / the weight-gradient GEMMs still run)
+            works = []
+            for b, tensor in enumerate(buckets):
+                with self.engine.comm_context(b):
+                    works.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            with self.engine.stream_context():
+                for w in works:
+                    w.wait()                 # the compute stream waits for the collectives, the host does not
+        elif self.world > 1:
             ctx = getattr(self.engine, 'stream_context', None)
             if ctx is not None:
                 with ctx():                  # same stream as the HIP kernels: no host sync needed

@@ -49,6 +49,12 @@ class HIPModel(BaseModel):
         gptr, gcount = self._model.grad_buffer()
         off = gptr - base
         self.grad_tensor = self._arena[off:off + 4 * gcount].view(torch.float32)
+        # the same memory as three buckets (softmax grads | everything else | tail scalars) for the overlapped exchange
+        self.grad_buckets = []
+        for b in range(3):
+            bptr, bcount = self._model.grad_bucket(b)
+            self.grad_buckets.append(self._arena[bptr - base:bptr - base + 4 * bcount].view(torch.float32))
+        self._comm_stream = torch.cuda.Stream(device=self._device)
         self._initialised = False
         self._train_calls = 0
         self._eval_calls = 0
@@ -70,6 +76,11 @@ class HIPModel(BaseModel):
 
     def stream_context(self):
         return self._torch.cuda.stream(self._stream)
+
+    def comm_context(self, bucket):
+        """context of the communication stream, after making it wait until `bucket` of the pending backward is final"""
+        self._model.stream_wait_bucket(self._comm_stream.cuda_stream, bucket)
+        return self._torch.cuda.stream(self._comm_stream)
 
     def _log_scalar(self, tag, value, step):
         # the reference writes TensorBoard summaries (lstm_baseline.py:106-111,126-131); no TB here -> JSONL

@@ -126,6 +126,14 @@ int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* 
 #define FSMG_GRAD_TAIL 16
 int fsmg_grad_buffer(fsmg_handle h, void** device_ptr, int64_t* count);
 int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss);
+/* Bucketed form of the gradient exchange, so that communication overlaps the rest of the backward pass:
+ *   bucket 0 = softmax_w + softmax_b gradients (final as soon as the dW GEMM retires, 56 % of the bytes at cfg-B)
+ *   bucket 1 = every other gradient, bucket 2 = the FSMG_GRAD_TAIL scalars (both final when backward ends).
+ * fsmg_grad_bucket returns the device range of a bucket; fsmg_stream_wait_bucket makes `stream` (the caller's
+ * communication hipStream_t) wait until that bucket of the LAST fsmg_forward_backward is final. */
+#define FSMG_NUM_BUCKETS 3
+int fsmg_grad_bucket(fsmg_handle h, int32_t bucket, void** device_ptr, int64_t* count);
+int fsmg_stream_wait_bucket(fsmg_handle h, void* stream, int32_t bucket);
 
 /* replaces LSTMBaseline.eval (src/models/lstm_baseline.py:115-133): query-only mean NLL,
  * no state change. */

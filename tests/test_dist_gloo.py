@@ -34,6 +34,21 @@ class OracleEngine(object):
         self.names = [n for n, _ in O.param_shapes(cfg)]
         self.sizes = [self.params[n].size for n in self.names]
         self.grad_tensor = torch.zeros(sum(self.sizes) + self.TAIL, dtype=torch.float64)
+        # same bucket contract as the HIP model: [softmax_w + softmax_b | everything else | tail scalars]
+        n_soft = self.sizes[-1] + self.sizes[-2]
+        n_all = sum(self.sizes)
+        self.grad_buckets = [self.grad_tensor[n_all - n_soft:n_all], self.grad_tensor[:n_all - n_soft],
+                             self.grad_tensor[n_all:]]
+        self.waited = []
+
+    def comm_context(self, bucket):
+        import contextlib
+        self.waited.append(bucket)
+        return contextlib.nullcontext()
+
+    def stream_context(self):
+        import contextlib
+        return contextlib.nullcontext()
 
     def forward_backward(self, support, query, **kw):
         X, Y = O.train_xy(support, query, self.cfg['input_size'])
@@ -59,7 +74,8 @@ def _episodes():
     return O.synthetic_episodes(2 * STEPS, N, K, Q, CFG['max_len'], CFG['input_size'], seed=3)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, bucketed='1'):
+    os.environ['FSMG_DP_BUCKETS'] = bucketed
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                     'few-shot-music-generation_amd', 'src'))
     from fsmg.dist import EpisodeParallel
@@ -71,13 +87,15 @@ def _worker(rank, world, port, out_dir):
     eps = _episodes()
     losses = [par.train_step(*eps[s * world + rank]) for s in range(STEPS)]   # rank r takes episode s*R + r
     mean_val = par.mean_scalar(float(rank))
+    assert eng.waited == ([0, 1, 2] * STEPS if bucketed == '1' else [])
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), losses=np.array(losses), mean_val=mean_val, **eng.params)
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
-    port = 29000 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize('bucketed', ['1', '0'])
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, bucketed):
+    port = 29000 + (os.getpid() + int(bucketed) * 7) % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path), bucketed), nprocs=2, join=True)
     r0 = np.load(os.path.join(str(tmp_path), 'rank0.npz'))
     r1 = np.load(os.path.join(str(tmp_path), 'rank1.npz'))
     # replicas stay identical and see the same (mean) loss

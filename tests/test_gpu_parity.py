@@ -347,12 +347,22 @@ def test_nccl_allreduce_runs_on_the_gradient_tensor_and_model_stream():
         m = LSTMBaseline(dict(cfg)); m.recover_or_init('')        # broadcasts the arena over RCCL (no-op for 1 rank)
         assert m.grad_tensor.is_cuda and m.grad_tensor.dtype == torch.float32
         got = []
-        for _ in range(3):
+        for step in range(3):
             m.forward_backward(sup, qry)
-            with m.stream_context():
-                dist.all_reduce(m.grad_tensor, op=dist.ReduceOp.SUM)
+            if step == 0:                       # single collective on the compute stream
+                with m.stream_context():
+                    dist.all_reduce(m.grad_tensor, op=dist.ReduceOp.SUM)
+            else:                               # bucketed, asynchronous, on the communication stream
+                works = []
+                for b, t in enumerate(m.grad_buckets):
+                    with m.comm_context(b):
+                        works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+                with m.stream_context():
+                    for w in works:
+                        w.wait()
             got.append(m.apply_update(1.0))
         assert got == want
+        assert sum(t.numel() for t in m.grad_buckets) == m.grad_tensor.numel()
         assert EpisodeParallel(m).world == 1
     finally:
         dist.destroy_process_group()
