@@ -97,3 +97,34 @@ def test_main_with_lstm_baseline_on_gpu(tmp_path, golden_dir, capsys):
     T.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--checkpt_dir', str(tmp_path / 'ck2'),
             '--init_dir', ck])
     assert 'recovering lstm_baseline from' in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_test_seed_entry_matches_oracle_trajectory(tmp_path, golden_dir, capsys):
+    """train.test_seed (reference src/train/test_seed.py): the 10th train loss on the golden lyrics fixture equals
+    the fp64 oracle's, started from the same parameters (the plugin's seeded init read back through the ABI)."""
+    import numpy as np
+    import train.test_seed as TS
+    from data.episode import load_sampler_from_config
+    from models.lstm_baseline import LSTMBaseline
+    from oracle import lstm_oracle as O
+    cfg = dict(LOOP, name='lstm_baseline', model_module_name='models.lstm_baseline', model_class_name='LSTMBaseline',
+               n_decay=10000, lr=5e-3, max_grad_norm=5, embedding_size=64, hidden_size=48, n_layers=1, batch_size=5)
+    p = _write_configs(tmp_path, golden_dir, cfg)
+    # oracle side: same sampler stream, same initial parameters
+    full = {}
+    for k in ('data', 'task', 'model'):
+        full.update(yaml.safe_load(open(p[k])))
+    full['split'] = 'train'
+    sampler = load_sampler_from_config(dict(full))
+    full['input_size'] = sampler.get_num_unique_words()
+    probe = LSTMBaseline(dict(full)); probe.recover_or_init('')
+    params = {k: v.astype(np.float64) for k, v in probe.engine.get_params().items()}
+    opt = O.new_opt_state(params)
+    want = None
+    for _ in range(TS.N_UPDATES):
+        ep = sampler.get_episode()
+        want = O.train_step(params, opt, ep.support, ep.query, full)
+    assert TS.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--expect', '%.9f' % want]) == 0
+    assert 'loss after 10 updates' in capsys.readouterr().out
+    assert TS.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--expect', '%.9f' % (want + 0.5)]) == 1
