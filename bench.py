@@ -41,6 +41,10 @@ OTHER = {
     'cfg-C': (dict(name='lstm_baseline', seed=1234, input_size=4708, max_len=50, embedding_size=250, hidden_size=1024,
                    n_layers=2, lr=5e-3, max_grad_norm=5, n_decay=10000), 5, 5, 4),
     'cfg-D': (dict(CFG_B), 20, 1, 4),
+    # cfg-B with 4 / 8 episodes per Adam step on ONE GPU (rows batched: 20-way / 40-way x (5+4) = 180 / 360 sequences);
+    # same update rule as episode-parallel training over 4 / 8 ranks.  `value` then counts steps, not episodes.
+    'cfg-Bx4': (dict(CFG_B), 20, 5, 4),
+    'cfg-Bx8': (dict(CFG_B), 40, 5, 4),
 }
 POOL = 256
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -107,7 +111,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
-    ap.add_argument('--config', default='cfg-B', choices=['cfg-B', 'cfg-C', 'cfg-D'])
+    ap.add_argument('--config', default='cfg-B', choices=['cfg-B', 'cfg-C', 'cfg-D', 'cfg-Bx4', 'cfg-Bx8'])
     args = ap.parse_args()
 
     import torch
