@@ -286,7 +286,8 @@ int download_tensor(fsmg_model* h, const float* flat, const char* name, float* h
 constexpr int MAX_SPLIT = 16;
 int pick_split(int64_t M, int64_t N, int64_t K, int64_t slots = 0) {
     if (slots <= 0) slots = gemm_block_slots();
-    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int64_t tm = gemm_tile_m();
+    const int64_t tiles = ((M + tm - 1) / tm) * ((N + 127) / 128);
     const double t_mfma = 2.0 * M * N * K / 100e12;
     const double t_slab = 2.0 * M * N * 4.0 / 4e12;
     int best = 1; double best_t = 1e30;

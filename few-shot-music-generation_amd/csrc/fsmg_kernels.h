@@ -41,6 +41,7 @@ hipError_t launch_gemm(hipStream_t s, int amode, int bmode, int atr, int btr, co
 int gemm_lds_pad_for(int blocks_per_cu);
 // resident 128x128 blocks the chip holds at once (256 CUs x blocks per CU): the split-K policy's slot count
 int gemm_block_slots();
+int gemm_tile_m();   // rows of a block tile (128 or 256)
 // out[i] = sum_z slabs[z][i]  (fixed order -> deterministic split-K)
 hipError_t launch_reduce_slabs(hipStream_t s, const float* slabs, long long slab_stride, int nslab,
                                float* out, long long n);

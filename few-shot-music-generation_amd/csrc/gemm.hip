@@ -32,14 +32,18 @@ namespace {
 #endif
 // BK = 16: 34 KiB LDS and <=116 VGPRs per block -> 4 resident blocks (16 waves) per CU, which covers the
 // per-tile barrier and the prologue/epilogue bubbles better than 2 blocks of BK = 32 (measured +5..15 % per GEMM)
-constexpr int BM = 128, BN = 128, BK = FSMG_GEMM_BK;   // BK in {16, 32}
-constexpr int NLD = BK / 8;                            // 16-byte loads per thread per operand tile
+#ifndef FSMG_GEMM_BM
+#define FSMG_GEMM_BM 128
+#endif
+constexpr int BM = FSMG_GEMM_BM, BN = 128, BK = FSMG_GEMM_BK;   // BM in {128, 256}, BK in {16, 32}
+constexpr int NTHREADS = 2 * BM;                       // one wave64 per 64x64 sub-tile: (BM/64) x 2 waves
+constexpr int NWAVES = NTHREADS / 64;
 constexpr int KQ = BK / 4;                             // float4 slots along k in a KC tile row
-constexpr int LD_KC = 129;
-constexpr int LD_XC = 132;
-constexpr int NTHREADS = 256;
-
-template <int MODE> struct TileLd { static constexpr int v = (MODE == OP_KC) ? LD_KC : LD_XC; };
+// 16-byte loads per thread for an operand tile of XW rows/columns
+template <int XW> struct Nld { static constexpr int v = XW * BK / 4 / NTHREADS; };
+// LDS row strides: KC tiles are scattered with ds_write_b32 (stride = 1 mod 32 -> conflict free), XC tiles are
+// copied with ds_write_b128 (stride a multiple of 4 floats)
+template <int MODE, int XW> struct TileLd { static constexpr int v = (MODE == OP_KC) ? XW + 1 : XW + 4; };
 
 struct DlCtx {
     const float* lse; const int* tgt; float inv_n; int n_vocab;
@@ -52,8 +56,9 @@ __device__ __forceinline__ float dl_elem(float logit, float lse, int tgt, int v,
 }
 
 // ---- KC source: tile [128 x][32 k], k contiguous.  thread -> rows x = tid/8 + 32*i, k quad kq = tid%8
-template <int TR>
+template <int TR, int XW>
 struct KcLoader {
+    static constexpr int NLD = Nld<XW>::v, LD = XW + 1;
     const float* rowp[NLD];
     float lse[NLD]; int tgt[NLD];
     int kq;
@@ -90,20 +95,21 @@ struct KcLoader {
         }
     }
     __device__ __forceinline__ void store(float* lds, const float4 (&r)[NLD], int tid) const {
-        float* base = lds + (4 * kq) * LD_KC + (tid / KQ);
+        float* base = lds + (4 * kq) * LD + (tid / KQ);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            base[0 * LD_KC + (NTHREADS / KQ) * i] = r[i].x;
-            base[1 * LD_KC + (NTHREADS / KQ) * i] = r[i].y;
-            base[2 * LD_KC + (NTHREADS / KQ) * i] = r[i].z;
-            base[3 * LD_KC + (NTHREADS / KQ) * i] = r[i].w;
+            base[0 * LD + (NTHREADS / KQ) * i] = r[i].x;
+            base[1 * LD + (NTHREADS / KQ) * i] = r[i].y;
+            base[2 * LD + (NTHREADS / KQ) * i] = r[i].z;
+            base[3 * LD + (NTHREADS / KQ) * i] = r[i].w;
         }
     }
 };
 
 // ---- XC source: tile [32 k][128 x], x contiguous.  thread -> k rows tid/32 + 8*i, x quad xq = tid%32
-template <int TR>
+template <int TR, int XW>
 struct XcLoader {
+    static constexpr int NLD = Nld<XW>::v, LD = XW + 4, XQ = XW / 4, KSTEP = NTHREADS / XQ;
     const float* colp;   // src + x  (nullptr if x beyond X)
     const int* gather;
     int ld, x;
@@ -111,13 +117,13 @@ struct XcLoader {
                                          const DlCtx&, int tid) {
         ld = ld_;
         gather = gather_;
-        x = x0 + 4 * (tid & 31);
+        x = x0 + 4 * (tid % XQ);
         colp = (x < X) ? src + x : nullptr;
     }
     __device__ __forceinline__ void load(float4 (&r)[NLD], int k0, int kend, const DlCtx& dl, int tid) const {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            int k = k0 + (tid >> 5) + 8 * i;
+            int k = k0 + (tid / XQ) + KSTEP * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (colp != nullptr && k < kend) {
                 long long row = gather ? (long long)gather[k] : (long long)k;
@@ -135,29 +141,29 @@ struct XcLoader {
         }
     }
     __device__ __forceinline__ void store(float* lds, const float4 (&r)[NLD], int tid) const {
-        float* base = lds + (tid >> 5) * LD_XC + 4 * (tid & 31);
+        float* base = lds + (tid / XQ) * LD + 4 * (tid % XQ);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) *reinterpret_cast<float4*>(base + 8 * i * LD_XC) = r[i];
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<float4*>(base + KSTEP * i * LD) = r[i];
     }
 };
 
-template <int MODE, int TR> struct Loader;
-template <int TR> struct Loader<OP_KC, TR> : KcLoader<TR> {
-    __device__ __forceinline__ void fetch(float4 (&r)[NLD], int k0, int kend, const DlCtx& dl, int) const {
+template <int MODE, int TR, int XW> struct Loader;
+template <int TR, int XW> struct Loader<OP_KC, TR, XW> : KcLoader<TR, XW> {
+    __device__ __forceinline__ void fetch(float4 (&r)[Nld<XW>::v], int k0, int kend, const DlCtx& dl, int) const {
         this->load(r, k0, kend, dl);
     }
 };
-template <int TR> struct Loader<OP_XC, TR> : XcLoader<TR> {
-    __device__ __forceinline__ void fetch(float4 (&r)[NLD], int k0, int kend, const DlCtx& dl, int tid) const {
+template <int TR, int XW> struct Loader<OP_XC, TR, XW> : XcLoader<TR, XW> {
+    __device__ __forceinline__ void fetch(float4 (&r)[Nld<XW>::v], int k0, int kend, const DlCtx& dl, int tid) const {
         this->load(r, k0, kend, dl, tid);
     }
 };
 
 template <int AMODE, int BMODE, int ATR, int BTR>
-__global__ __launch_bounds__(NTHREADS, BK == 16 ? 4 : 2) void k_gemm(const GemmArgs g) {
-    constexpr int LDA = TileLd<AMODE>::v, LDB = TileLd<BMODE>::v;
+__global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void k_gemm(const GemmArgs g) {
+    constexpr int LDA = TileLd<AMODE, BM>::v, LDB = TileLd<BMODE, BN>::v;
     constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
-    constexpr int PIPE = 2 * ASZ + 2 * BSZ, EPI = 4 * 32 * 68;
+    constexpr int PIPE = 2 * ASZ + 2 * BSZ, EPI = NWAVES * 32 * 68;
     __shared__ __attribute__((aligned(16))) float smem[PIPE > EPI ? PIPE : EPI];
     float* As = smem;
     float* Bs = smem + 2 * ASZ;
@@ -189,8 +195,8 @@ __global__ __launch_bounds__(NTHREADS, BK == 16 ? 4 : 2) void k_gemm(const GemmA
     const int nk = (ke > kb) ? (ke - kb + BK - 1) / BK : 0;
 
     DlCtx dl{g.lse, g.tgt, g.inv_n, g.n_vocab};
-    Loader<AMODE, ATR> la;
-    Loader<BMODE, BTR> lb;
+    Loader<AMODE, ATR, BM> la;
+    Loader<BMODE, BTR, BN> lb;
     la.init(g.A, g.lda, g.M, m0, g.gather, dl, tid);
     lb.init(g.B, g.ldb, g.N, n0, nullptr, dl, tid);
 
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(NTHREADS, BK == 16 ? 4 : 2) void k_gemm(const GemmA
     const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0 && tid < BN;
     float csum = 0.0f;
 
-    float4 ra[NLD], rb[NLD];
+    float4 ra[Nld<BM>::v], rb[Nld<BN>::v];
     if (nk > 0) {
         la.fetch(ra, kb, ke, dl, tid);
         lb.fetch(rb, kb, ke, dl, tid);
@@ -306,12 +312,13 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, long long stride
 
 }  // namespace
 
-int gemm_block_slots() { return 256 * (BK == 16 ? 4 : 2); }
+int gemm_block_slots() { return 256 * ((BK == 16 ? 4 : 2) * 256 / NTHREADS); }
+int gemm_tile_m() { return BM; }
 // dynamic-LDS padding that caps the resident blocks per CU (160 KiB LDS): leaves room for the recurrent-step
 // kernels' waves and registers when a GEMM runs beside them on the auxiliary stream
 int gemm_lds_pad_for(int blocks_per_cu) {
-    constexpr int own = (BK == 16) ? 34816 : 67584;                 // static LDS of one block
-    const int max_blocks = (BK == 16) ? 4 : 2;
+    constexpr int own = (BK == 16) ? NWAVES * 32 * 68 * 4 : 67584;  // static LDS of one block
+    const int max_blocks = (BK == 16 ? 4 : 2) * 256 / NTHREADS;
     if (blocks_per_cu >= max_blocks) return 0;
     const int budget = (160 * 1024) / blocks_per_cu;                // LDS share that admits exactly this many
     return budget - own - 1024 > 0 ? budget - own - 1024 : 0;
