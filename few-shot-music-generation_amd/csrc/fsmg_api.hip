@@ -95,7 +95,7 @@ struct fsmg_model {
     // whole-phase hipGraphs, keyed by the shape of the call; dropped when scratch moves
     std::map<std::string, hipGraphExec_t> graphs;
     // decode
-    float* dec = nullptr; int* dec_tok = nullptr;
+    float* dec = nullptr;
 
     int lastB = 0;
     bool have_grads = false;
@@ -396,19 +396,19 @@ inline Lane aux_lane(fsmg_model* h) { return Lane{h->aux, h->slabs2, h->colsum_s
 
 // C (contiguous, ldc == N) = op(A) * op(B) with the K range split over pick_split() slabs that are
 // summed in a fixed order (deterministic); colsum likewise.
-int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, int atr, int btr, GemmArgs g) {
+int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g) {
     hipStream_t s = ln.s;
     const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K, ln.slots) : 1;
     if (S <= 1 || (int64_t)S * g.M * g.N > h->slab_cap) {
         g.ksplit = 1;
-        HIPCK(h, launch_gemm(s, amode, bmode, atr, btr, g, ln.lds_pad));
+        HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
         return FSMG_OK;
     }
     float* C = g.C; float* colsum = g.colsum;
     const int64_t mn = (int64_t)g.M * g.N;
     g.C = ln.slabs; g.c_slab = mn; g.ksplit = S;
     if (colsum) { g.colsum = ln.colsum_slabs; g.colsum_slab = g.N; }
-    HIPCK(h, launch_gemm(s, amode, bmode, atr, btr, g, ln.lds_pad));
+    HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
     HIPCK(h, launch_reduce_slabs(s, ln.slabs, mn, S, C, mn));
     if (colsum) HIPCK(h, launch_reduce_slabs(s, ln.colsum_slabs, g.N, S, colsum, g.N));
     return FSMG_OK;
@@ -489,7 +489,7 @@ int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t 
         g.B = h->P + h->off_w; g.ldb = h->V1p;
         g.C = h->logits + (size_t)r0 * h->V1p; g.ldc = h->V1p; g.M = (int)m; g.N = h->V1p; g.K = Hp;
         g.bias = h->P + h->off_d; g.ksplit = 1; g.nt_store = 1;
-        GEMMCK(gemm(h, ln, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
+        GEMMCK(gemm(h, ln, OP_KC, OP_XC, g));
     }
     {
         ScopedTimer tm(h, "ce");
@@ -521,7 +521,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             g.B = h->P + h->off_kx[l]; g.ldb = G4;
             g.C = h->Z[l]; g.ldc = G4; g.M = (int)rows; g.N = G4;
             g.bias = h->P + h->off_b[l]; g.ksplit = 1;
-            GEMMCK(gemm(h, mainl, OP_KC, OP_XC, TR_NONE, TR_NONE, g));
+            GEMMCK(gemm(h, mainl, OP_KC, OP_XC, g));
         }
         for (int c = 0; c < nch; ++c) {
             const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
@@ -567,7 +567,7 @@ int dhout_chunk(fsmg_model* h, const Lane& ln, int B, int t0, int t1) {
     GemmArgs g{};
     g.A = h->dlogits + (size_t)r0 * h->V1p; g.lda = h->V1p; g.B = h->P + h->off_w; g.ldb = h->V1p;
     g.C = h->dH + (size_t)r0 * h->Hp; g.ldc = h->Hp; g.M = (int)m; g.N = h->Hp; g.K = h->V1p; g.ksplit = 1;
-    return gemm(h, ln, OP_KC, OP_KC, TR_NONE, TR_NONE, g);
+    return gemm(h, ln, OP_KC, OP_KC, g);
 }
 
 int dw_gemm(fsmg_model* h, const Lane& ln, int B) {
@@ -576,7 +576,7 @@ int dw_gemm(fsmg_model* h, const Lane& ln, int B) {
     g.A = h->Hs[h->L - 1] + (size_t)B * h->Hp; g.lda = h->Hp; g.B = h->dlogits; g.ldb = h->V1p;
     g.C = h->G + h->off_w; g.ldc = h->V1p; g.M = h->Hp; g.N = h->V1p; g.K = (int)((int64_t)h->T * B);
     g.colsum = h->G + h->off_d; g.ksplit = 1;
-    return gemm(h, ln, OP_XC, OP_XC, TR_NONE, TR_NONE, g);
+    return gemm(h, ln, OP_XC, OP_XC, g);
 }
 
 int backward(fsmg_model* h, int B) {
@@ -632,13 +632,13 @@ int backward(fsmg_model* h, int B) {
             g.A = h->Hs[l]; g.lda = Hp; g.B = h->Z[l]; g.ldb = G4;
             g.C = h->G + h->off_kh[l]; g.ldc = G4; g.M = Hp; g.N = G4; g.K = (int)rows;
             g.colsum = h->G + h->off_b[l]; g.ksplit = 1;
-            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, TR_NONE, TR_NONE, g));
+            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, g));
             GemmArgs k{};                     // dKx = in^T * dZ
             if (l == 0) { k.A = h->P + h->off_emb; k.lda = h->Ep; k.gather = h->X; }
             else { k.A = h->Hs[l - 1] + (size_t)B * Hp; k.lda = Hp; }
             k.B = h->Z[l]; k.ldb = G4; k.C = h->G + h->off_kx[l]; k.ldc = G4;
             k.M = in_p; k.N = G4; k.K = (int)rows; k.ksplit = 1;
-            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, TR_NONE, TR_NONE, k));
+            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, k));
         }
         {
             ScopedTimer tm(h, "gemm_dx");     // d_in = dZ * Kx^T
@@ -646,7 +646,7 @@ int backward(fsmg_model* h, int B) {
             g.A = h->Z[l]; g.lda = G4; g.B = h->P + h->off_kx[l]; g.ldb = G4;
             g.C = (l == 0) ? h->dXemb : h->dH; g.ldc = in_p;
             g.M = (int)rows; g.N = in_p; g.K = G4; g.ksplit = 1;
-            GEMMCK(gemm(h, mainl, OP_KC, OP_KC, TR_NONE, TR_NONE, g));
+            GEMMCK(gemm(h, mainl, OP_KC, OP_KC, g));
         }
     }
     {
@@ -802,7 +802,6 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         const size_t nblk = (h->V1 + 255) / 256;
         const size_t fl = (size_t)h->L * 3 * h->Hp + 2 * nblk + 64;
         if (hipMalloc((void**)&h->dec, sizeof(float) * fl + 256) != hipSuccess) return bail(FSMG_ERR_NOMEM, "hipMalloc(decode) failed");
-        h->dec_tok = (int*)(h->dec + fl);
     }
     if (hipMalloc((void**)&h->khf, sizeof(float) * (size_t)h->L * 2 * h->Hp * h->G4) != hipSuccess)
         return bail(FSMG_ERR_NOMEM, "hipMalloc(fragment weights) failed");

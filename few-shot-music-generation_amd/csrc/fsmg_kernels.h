@@ -12,11 +12,6 @@ namespace fsmg {
 //   KC: the K index is contiguous  (A stored [M][K] / B stored [N][K])
 //   XC: the non-K index is contiguous (A stored [K][M] / B stored [K][N])
 enum { OP_KC = 0, OP_XC = 1 };
-// Operand element transforms fused into the global->LDS staging:
-//   TR_DLOGITS: element (row r, vocab col v) of the stored LOGITS is read as
-//               dlogits = (exp(logit - lse[r]) - [v == tgt[r]]) * inv_n, 0 for v >= n_vocab
-enum { TR_NONE = 0, TR_DLOGITS = 1 };
-
 struct GemmArgs {
     const float* A; int lda;
     const float* B; int ldb;
@@ -24,19 +19,14 @@ struct GemmArgs {
     int M, N, K;
     const float* bias;      // optional [N], added in the epilogue
     const int* gather;      // optional row gather for A: KC -> M-rows, XC -> K-rows index into A
-    const float* lse;       // TR_DLOGITS: per logits-row log-sum-exp
-    const int* tgt;         // TR_DLOGITS: per logits-row target id
-    float inv_n;            // TR_DLOGITS: 1/(rows + 1e-12)
-    int n_vocab;            // TR_DLOGITS: number of real vocabulary columns (V1)
     float* colsum;          // optional [N]: column sums of op(B) over K (XC B only), written by M-tile 0
     int ksplit;             // >= 1; slab z covers a K range, C/colsum slab stride below
     long long c_slab;       // elements between consecutive K-split slabs of C
     long long colsum_slab;
     int nt_store;           // 1: C is written with non-temporal stores (streaming, read back much later)
 };
-// amode/bmode in {OP_KC, OP_XC}; atr/btr in {TR_NONE, TR_DLOGITS}. Supported combinations:
-// (KC,XC,*,NONE) (XC,XC,NONE,*) (KC,KC,*,NONE)
-hipError_t launch_gemm(hipStream_t s, int amode, int bmode, int atr, int btr, const GemmArgs& g, int lds_pad = 0);
+// amode/bmode in {OP_KC, OP_XC}. Supported combinations: (KC,XC) (XC,XC) (KC,KC)
+hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, int lds_pad = 0);
 // dynamic-LDS padding that caps a GEMM at `blocks_per_cu` resident blocks per CU
 int gemm_lds_pad_for(int blocks_per_cu);
 // resident 128x128 blocks the chip holds at once (256 CUs x blocks per CU): the split-K policy's slot count

@@ -2,9 +2,10 @@
 //
 // One kernel template serves every dense contraction of the LSTM-baseline step
 // (DESIGN.md "Kernels"): the hoisted input projection with the embedding gather fused
-// into the A-operand load, the vocabulary projection, and their backward pairs with the
-// softmax-gradient transform (exp(logit - lse) - onehot) fused into the operand load so
-// dlogits is never materialised.
+// into the A-operand load, the vocabulary projection, and their backward pairs (dlogits is
+// materialised once by the cross-entropy kernel: an earlier version recomputed
+// exp(logit - lse) - onehot inside the operand loads of two GEMMs, 4x per element, and was
+// slower).
 //
 // Tiling: 128x128 block tile, BK = 32, 256 threads = 4 wave64 as 2x2, each wave owns a
 // 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs).  Both operands are staged
@@ -45,25 +46,13 @@ template <int XW> struct Nld { static constexpr int v = XW * BK / 4 / NTHREADS; 
 // copied with ds_write_b128 (stride a multiple of 4 floats)
 template <int MODE, int XW> struct TileLd { static constexpr int v = (MODE == OP_KC) ? XW + 1 : XW + 4; };
 
-struct DlCtx {
-    const float* lse; const int* tgt; float inv_n; int n_vocab;
-};
-
-__device__ __forceinline__ float dl_elem(float logit, float lse, int tgt, int v, const DlCtx& c) {
-    float p = __expf(logit - lse);
-    p = (v == tgt) ? p - 1.0f : p;
-    return (v < c.n_vocab) ? p * c.inv_n : 0.0f;
-}
-
 // ---- KC source: tile [128 x][32 k], k contiguous.  thread -> rows x = tid/8 + 32*i, k quad kq = tid%8
-template <int TR, int XW>
+template <int XW>
 struct KcLoader {
     static constexpr int NLD = Nld<XW>::v, LD = XW + 1;
     const float* rowp[NLD];
-    float lse[NLD]; int tgt[NLD];
     int kq;
-    __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather,
-                                         const DlCtx& dl, int tid) {
+    __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather, int tid) {
         kq = tid % KQ;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -71,26 +60,14 @@ struct KcLoader {
             bool ok = x < X;
             long long row = ok ? (gather ? (long long)gather[x] : (long long)x) : 0;
             rowp[i] = ok ? src + row * ld : nullptr;
-            if (TR == TR_DLOGITS) {
-                lse[i] = ok ? dl.lse[x] : 0.0f;
-                tgt[i] = ok ? dl.tgt[x] : -1;
-            }
         }
     }
-    __device__ __forceinline__ void load(float4 (&r)[NLD], int k0, int kend, const DlCtx& dl) const {
+    __device__ __forceinline__ void load(float4 (&r)[NLD], int k0, int kend) const {
         int k = k0 + 4 * kq;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rowp[i] != nullptr && k < kend) {
-                v = *reinterpret_cast<const float4*>(rowp[i] + k);
-                if (TR == TR_DLOGITS) {
-                    v.x = dl_elem(v.x, lse[i], tgt[i], k + 0, dl);
-                    v.y = dl_elem(v.y, lse[i], tgt[i], k + 1, dl);
-                    v.z = dl_elem(v.z, lse[i], tgt[i], k + 2, dl);
-                    v.w = dl_elem(v.w, lse[i], tgt[i], k + 3, dl);
-                }
-            }
+            if (rowp[i] != nullptr && k < kend) v = *reinterpret_cast<const float4*>(rowp[i] + k);
             r[i] = v;
         }
     }
@@ -107,20 +84,19 @@ struct KcLoader {
 };
 
 // ---- XC source: tile [32 k][128 x], x contiguous.  thread -> k rows tid/32 + 8*i, x quad xq = tid%32
-template <int TR, int XW>
+template <int XW>
 struct XcLoader {
     static constexpr int NLD = Nld<XW>::v, LD = XW + 4, XQ = XW / 4, KSTEP = NTHREADS / XQ;
     const float* colp;   // src + x  (nullptr if x beyond X)
     const int* gather;
     int ld, x;
-    __device__ __forceinline__ void init(const float* src, int ld_, int X, int x0, const int* gather_,
-                                         const DlCtx&, int tid) {
+    __device__ __forceinline__ void init(const float* src, int ld_, int X, int x0, const int* gather_, int tid) {
         ld = ld_;
         gather = gather_;
         x = x0 + 4 * (tid % XQ);
         colp = (x < X) ? src + x : nullptr;
     }
-    __device__ __forceinline__ void load(float4 (&r)[NLD], int k0, int kend, const DlCtx& dl, int tid) const {
+    __device__ __forceinline__ void load(float4 (&r)[NLD], int k0, int kend, int tid) const {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             int k = k0 + (tid / XQ) + KSTEP * i;
@@ -128,14 +104,6 @@ struct XcLoader {
             if (colp != nullptr && k < kend) {
                 long long row = gather ? (long long)gather[k] : (long long)k;
                 v = *reinterpret_cast<const float4*>(colp + row * ld);
-                if (TR == TR_DLOGITS) {
-                    float l = dl.lse[k];
-                    int t = dl.tgt[k];
-                    v.x = dl_elem(v.x, l, t, x + 0, dl);
-                    v.y = dl_elem(v.y, l, t, x + 1, dl);
-                    v.z = dl_elem(v.z, l, t, x + 2, dl);
-                    v.w = dl_elem(v.w, l, t, x + 3, dl);
-                }
             }
             r[i] = v;
         }
@@ -147,19 +115,15 @@ struct XcLoader {
     }
 };
 
-template <int MODE, int TR, int XW> struct Loader;
-template <int TR, int XW> struct Loader<OP_KC, TR, XW> : KcLoader<TR, XW> {
-    __device__ __forceinline__ void fetch(float4 (&r)[Nld<XW>::v], int k0, int kend, const DlCtx& dl, int) const {
-        this->load(r, k0, kend, dl);
-    }
+template <int MODE, int XW> struct Loader;
+template <int XW> struct Loader<OP_KC, XW> : KcLoader<XW> {
+    __device__ __forceinline__ void fetch(float4 (&r)[Nld<XW>::v], int k0, int kend, int) const { this->load(r, k0, kend); }
 };
-template <int TR, int XW> struct Loader<OP_XC, TR, XW> : XcLoader<TR, XW> {
-    __device__ __forceinline__ void fetch(float4 (&r)[Nld<XW>::v], int k0, int kend, const DlCtx& dl, int tid) const {
-        this->load(r, k0, kend, dl, tid);
-    }
+template <int XW> struct Loader<OP_XC, XW> : XcLoader<XW> {
+    __device__ __forceinline__ void fetch(float4 (&r)[Nld<XW>::v], int k0, int kend, int tid) const { this->load(r, k0, kend, tid); }
 };
 
-template <int AMODE, int BMODE, int ATR, int BTR>
+template <int AMODE, int BMODE>
 __global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void k_gemm(const GemmArgs g) {
     constexpr int LDA = TileLd<AMODE, BM>::v, LDB = TileLd<BMODE, BN>::v;
     constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
@@ -194,11 +158,10 @@ __global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void 
     }
     const int nk = (ke > kb) ? (ke - kb + BK - 1) / BK : 0;
 
-    DlCtx dl{g.lse, g.tgt, g.inv_n, g.n_vocab};
-    Loader<AMODE, ATR, BM> la;
-    Loader<BMODE, BTR, BN> lb;
-    la.init(g.A, g.lda, g.M, m0, g.gather, dl, tid);
-    lb.init(g.B, g.ldb, g.N, n0, nullptr, dl, tid);
+    Loader<AMODE, BM> la;
+    Loader<BMODE, BN> lb;
+    la.init(g.A, g.lda, g.M, m0, g.gather, tid);
+    lb.init(g.B, g.ldb, g.N, n0, nullptr, tid);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -213,8 +176,8 @@ __global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void 
 
     float4 ra[Nld<BM>::v], rb[Nld<BN>::v];
     if (nk > 0) {
-        la.fetch(ra, kb, ke, dl, tid);
-        lb.fetch(rb, kb, ke, dl, tid);
+        la.fetch(ra, kb, ke, tid);
+        lb.fetch(rb, kb, ke, tid);
         la.store(As, ra, tid);
         lb.store(Bs, rb, tid);
     }
@@ -224,8 +187,8 @@ __global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void 
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) {
-            la.fetch(ra, kb + (kt + 1) * BK, ke, dl, tid);
-            lb.fetch(rb, kb + (kt + 1) * BK, ke, dl, tid);
+            la.fetch(ra, kb + (kt + 1) * BK, ke, tid);
+            lb.fetch(rb, kb + (kt + 1) * BK, ke, tid);
         }
         const float* a_base = As + cur * ASZ + khalf * LDA + wm * 64 + l31;
         const float* b_base = Bs + cur * BSZ + khalf * LDB + wn * 64 + l31;
@@ -290,12 +253,12 @@ __global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void 
     if (do_colsum && n0 + tid < g.N) g.colsum[(long long)z * g.colsum_slab + n0 + tid] = csum;
 }
 
-template <int AMODE, int BMODE, int ATR, int BTR>
+template <int AMODE, int BMODE>
 hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     dim3 grid(tilesM * tilesN, g.ksplit > 1 ? g.ksplit : 1);
     // lds_pad: unused dynamic LDS that only lowers the number of co-resident blocks per CU
-    hipLaunchKernelGGL((k_gemm<AMODE, BMODE, ATR, BTR>), grid, dim3(NTHREADS), lds_pad, s, g);
+    hipLaunchKernelGGL((k_gemm<AMODE, BMODE>), grid, dim3(NTHREADS), lds_pad, s, g);
     return hipGetLastError();
 }
 
@@ -324,20 +287,11 @@ int gemm_lds_pad_for(int blocks_per_cu) {
     return budget - own - 1024 > 0 ? budget - own - 1024 : 0;
 }
 
-hipError_t launch_gemm(hipStream_t s, int amode, int bmode, int atr, int btr, const GemmArgs& g, int lds_pad) {
+hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, int lds_pad) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
-    if (amode == OP_KC && bmode == OP_XC && btr == TR_NONE) {
-        return atr == TR_NONE ? launch_t<OP_KC, OP_XC, TR_NONE, TR_NONE>(s, g, lds_pad)
-                              : launch_t<OP_KC, OP_XC, TR_DLOGITS, TR_NONE>(s, g, lds_pad);
-    }
-    if (amode == OP_XC && bmode == OP_XC && atr == TR_NONE) {
-        return btr == TR_NONE ? launch_t<OP_XC, OP_XC, TR_NONE, TR_NONE>(s, g, lds_pad)
-                              : launch_t<OP_XC, OP_XC, TR_NONE, TR_DLOGITS>(s, g, lds_pad);
-    }
-    if (amode == OP_KC && bmode == OP_KC && btr == TR_NONE) {
-        return atr == TR_NONE ? launch_t<OP_KC, OP_KC, TR_NONE, TR_NONE>(s, g, lds_pad)
-                              : launch_t<OP_KC, OP_KC, TR_DLOGITS, TR_NONE>(s, g, lds_pad);
-    }
+    if (amode == OP_KC && bmode == OP_XC) return launch_t<OP_KC, OP_XC>(s, g, lds_pad);
+    if (amode == OP_XC && bmode == OP_XC) return launch_t<OP_XC, OP_XC>(s, g, lds_pad);
+    if (amode == OP_KC && bmode == OP_KC) return launch_t<OP_KC, OP_KC>(s, g, lds_pad);
     return hipErrorInvalidValue;
 }
 

@@ -27,3 +27,11 @@ def small_config(**over):
                hidden_size=16, n_layers=1, lr=5e-3, max_grad_norm=5, n_decay=10000)
     cfg.update(over)
     return cfg
+
+
+def free_port():
+    """a TCP port that is free right now on 127.0.0.1 (for torch.distributed rendezvous in tests)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]

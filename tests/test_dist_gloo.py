@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import small_config
+from conftest import free_port, small_config
 from oracle import lstm_oracle as O
 
 CFG = small_config(hidden_size=12, embedding_size=6, input_size=40, max_len=6, max_grad_norm=0.5)
@@ -94,7 +94,7 @@ def _worker(rank, world, port, out_dir, bucketed='1'):
 
 @pytest.mark.parametrize('bucketed', ['1', '0'])
 def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, bucketed):
-    port = 29000 + (os.getpid() + int(bucketed) * 7) % 2000
+    port = free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path), bucketed), nprocs=2, join=True)
     r0 = np.load(os.path.join(str(tmp_path), 'rank0.npz'))
     r1 = np.load(os.path.join(str(tmp_path), 'rank1.npz'))

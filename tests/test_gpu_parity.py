@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import small_config
+from conftest import free_port, small_config
 from gpu_utils import f64_params, new_model, oracle_step, read_states, rel_max, time_major
 from oracle import lstm_oracle as O
 
@@ -340,8 +340,8 @@ def test_nccl_allreduce_runs_on_the_gradient_tensor_and_model_stream():
     sup, qry = _episode(cfg, 2, 2, 1)
     ref = LSTMBaseline(dict(cfg)); ref.recover_or_init('')
     want = [ref.train(Episode(sup, qry)) for _ in range(3)]
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 300))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(free_port())
     dist.init_process_group('nccl', rank=0, world_size=1)
     try:
         m = LSTMBaseline(dict(cfg)); m.recover_or_init('')        # broadcasts the arena over RCCL (no-op for 1 rank)
