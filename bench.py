@@ -53,6 +53,13 @@ CLASSES = ['gemm_zx', 'lstm_fwd', 'gemm_logits', 'ce', 'gemm_dhout', 'gemm_dw', 
            'gemm_dx', 'embed_grad', 'update']
 
 
+def synthetic_episodes(n_episodes, N, K, Q, T, vocab, seed):
+    """SURVEY.md 8(d) throughput input: token ids i.i.d. uniform on [0, vocab) from RandomState(seed)"""
+    rng = np.random.RandomState(seed)
+    return [(rng.randint(0, vocab, size=(N, K, T)).astype(np.int32), rng.randint(0, vocab, size=(N, Q, T)).astype(np.int32))
+            for _ in range(n_episodes)]
+
+
 def hbm_traffic():
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
     correction + WRITE_SIZE), recorded under profiles/ -- counters cannot be read from inside this process"""
@@ -118,7 +125,6 @@ def main():
     import torch.distributed as dist
     from fsmg.dist import EpisodeParallel, init_from_env
     from models.lstm_baseline import LSTMBaseline
-    from oracle import lstm_oracle as O            # synthetic workload generator + cpu_baseline leg only
 
     rank, world = init_from_env('nccl')
     if world != args.gpus:
@@ -132,8 +138,7 @@ def main():
     cfg = dict(base, device=local)
     B = N_WAY * (K_SHOT + Q_QUERY)
 
-    pool_host = O.synthetic_episodes(POOL, N_WAY, K_SHOT, Q_QUERY, cfg['max_len'], cfg['input_size'],
-                                     seed=1234 + rank)
+    pool_host = synthetic_episodes(POOL, N_WAY, K_SHOT, Q_QUERY, cfg['max_len'], cfg['input_size'], seed=1234 + rank)
     d_sup = torch.from_numpy(np.stack([s for s, _ in pool_host])).cuda()
     d_qry = torch.from_numpy(np.stack([q for _, q in pool_host])).cuda()
     sup_stride, qry_stride = d_sup[0].numel() * 4, d_qry[0].numel() * 4

@@ -6,10 +6,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'few-shot-music-
 import numpy as np
 import bench
 from fsmg.binding import FsmgModel
-from oracle import lstm_oracle as O
 cfg = dict(bench.CFG_B)
 m = FsmgModel(cfg, use_graph=False); m.init_params(1)
-(sup, qry), = O.synthetic_episodes(1, 5, 5, 4, cfg['max_len'], cfg['input_size'])
+(sup, qry), = bench.synthetic_episodes(1, 5, 5, 4, cfg['max_len'], cfg['input_size'], 1234)
 for which, name in ((0, 'fwd'), (1, 'bwd')):
     m.forward_backward(sup, qry)
     st = m.step_profile(which).astype(np.int64)

@@ -7,10 +7,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'few-shot-music-
 import numpy as np
 import bench
 from fsmg.binding import FsmgModel
-from oracle import lstm_oracle as O
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 for name, (cfg, N, K, Q) in (('cfg-B', (dict(bench.CFG_B), 5, 5, 4)), ('cfg-C', bench.OTHER['cfg-C'])):
-    eps = O.synthetic_episodes(3, N, K, Q, cfg['max_len'], cfg['input_size'], seed=5)
+    eps = bench.synthetic_episodes(3, N, K, Q, cfg['max_len'], cfg['input_size'], 5)
     ref = None
     bad = 0
     for r in range(reps):
