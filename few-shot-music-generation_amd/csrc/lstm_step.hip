@@ -148,6 +148,112 @@ __global__ __launch_bounds__(64 * NW, NW) void k_lstm_fwd_step(const LstmFwdArgs
     FSMG_STAMP(4);
 }
 
+
+// ---------------------------------------------------------------- forward, many rows (validation batches, wide episodes)
+// With R row tiles every (column group, row tile) block of the kernel above re-fetches fragments that its
+// neighbours fetch too: R x the weights, 4Hp/16 x the activations (164 MB of L2->CU traffic per step at 320
+// rows).  Here a block owns a CT x RT patch of output tiles and reuses each fragment CT (activations) or RT
+// (weights) times from registers.  grid (4Hp/16/CT, ceil(tiles/RT)); same K split over the waves, same epilogue.
+template <int N, int CT, int RT>
+__device__ __forceinline__ void fwd_patch_chunk(const float4* const (&af)[RT], const float4* const (&bf)[CT], int g0,
+                                                f32x4 (&acc)[RT][CT]) {
+    float4 av[RT][N], bv[CT][N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+#pragma unroll
+        for (int ri = 0; ri < RT; ++ri) av[ri][j] = af[ri][(g0 + j) * 64];
+#pragma unroll
+        for (int ci = 0; ci < CT; ++ci) bv[ci][j] = bf[ci][(g0 + j) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+#pragma unroll
+        for (int ri = 0; ri < RT; ++ri)
+#pragma unroll
+            for (int ci = 0; ci < CT; ++ci) {
+                acc[ri][ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ri][j].x, bv[ci][j].x, acc[ri][ci], 0, 0, 0);
+                acc[ri][ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ri][j].y, bv[ci][j].y, acc[ri][ci], 0, 0, 0);
+                acc[ri][ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ri][j].z, bv[ci][j].z, acc[ri][ci], 0, 0, 0);
+                acc[ri][ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ri][j].w, bv[ci][j].w, acc[ri][ci], 0, 0, 0);
+            }
+    }
+}
+
+template <int NW, int CT, int RT>
+__global__ __launch_bounds__(64 * NW, NW) void k_lstm_fwd_patch(const LstmFwdArgs a) {
+    constexpr int PAIRS = RT * 16 * CT * 4;                 // (row, unit) pairs of the patch, one epilogue thread each
+    static_assert(PAIRS <= 64 * NW, "one epilogue thread per (row, unit)");
+    __shared__ float red[NW][RT * 16][CT * 16 + 1];
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int Hp = a.Hp, G4 = 4 * a.Hp, ngroups = Hp >> 4;
+    const int ntiles = (a.B + 15) >> 4;
+    const int nb0 = blockIdx.x * CT, mt0 = blockIdx.y * RT;
+
+    const int prow = tid / (CT * 4), pu = tid % (CT * 4);
+    const int eb = mt0 * 16 + prow, enb = nb0 + (pu >> 2), euu = pu & 3, eu = 4 * enb + euu;
+    const bool eact = (tid < PAIRS) && (eb < a.B);
+    float zin[4] = {0.f, 0.f, 0.f, 0.f};
+    float cp = 0.f;
+    float* zp = a.z + (long long)eb * G4 + 16 * enb + euu;
+    if (eact) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) zin[gi] = zp[4 * gi];
+        cp = a.c_prev[(long long)eb * Hp + eu];
+    }
+
+    const int g_beg = (wave * ngroups) / NW, g_end = ((wave + 1) * ngroups) / NW;
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int ri = 0; ri < RT; ++ri)
+#pragma unroll
+        for (int ci = 0; ci < CT; ++ci) acc[ri][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float4* af[RT];
+    const float4* bf[CT];
+#pragma unroll
+    for (int ri = 0; ri < RT; ++ri)           // a row tile past the batch is clamped: its outputs are never stored
+        af[ri] = reinterpret_cast<const float4*>(a.hF_prev) + ((size_t)min(mt0 + ri, ntiles - 1) * ngroups) * 64 + lane;
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci)
+        bf[ci] = reinterpret_cast<const float4*>(a.KhF) + ((size_t)(nb0 + ci) * ngroups) * 64 + lane;
+
+    int g = g_beg;
+    while (g + 4 <= g_end) { fwd_patch_chunk<4, CT, RT>(af, bf, g, acc); g += 4; }
+    if (g + 2 <= g_end) { fwd_patch_chunk<2, CT, RT>(af, bf, g, acc); g += 2; }
+    if (g < g_end) fwd_patch_chunk<1, CT, RT>(af, bf, g, acc);
+#pragma unroll
+    for (int ri = 0; ri < RT; ++ri)
+#pragma unroll
+        for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][ri * 16 + 4 * q + r][ci * 16 + l15] = acc[ri][ci][r];
+    __syncthreads();
+
+    if (eact) {
+        float zg[4];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const int c = (pu >> 2) * 16 + 4 * gi + euu;
+            float zs = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) zs += red[w][prow][c];
+            zg[gi] = zin[gi] + zs;
+        }
+        const float si = sigmoidf_(zg[0]);
+        const float tj = tanhf_(zg[1]);
+        const float sf = sigmoidf_(zg[2] + 1.0f);
+        const float so = sigmoidf_(zg[3]);
+        const float cn = cp * sf + si * tj;
+        const float hn = tanhf_(cn) * so;
+        a.c_next[(long long)eb * Hp + eu] = cn;
+        a.h_next[(long long)eb * Hp + eu] = hn;
+        a.hF_next[(((size_t)(eb >> 4) * ngroups + (eu >> 4)) * 64 + 4 * (eu & 12) + (eb & 15)) * 4 + (eu & 3)] = hn;
+        zp[0] = si; zp[4] = tj; zp[8] = sf; zp[12] = so;
+    }
+}
+
 // ---------------------------------------------------------------- backward
 // grid (Hp/16, ceil(B/16)); 512 threads = 8 waves splitting K = 4Hp (packed gate columns).
 // dh_rec[b][u] = sum_pc dz_{t+1}[b][pc] * Kh[u][pc]; then the gate gradients of step t for the
@@ -269,7 +375,12 @@ hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* b
 }
 
 hipError_t launch_lstm_fwd_step(hipStream_t s, const LstmFwdArgs& a, unsigned long long* prof) {
-    dim3 grid((4 * a.Hp) / 16, (a.B + 15) / 16);
+    const int ncg = (4 * a.Hp) / 16, ntiles = (a.B + 15) / 16;
+    if (prof == nullptr && ntiles >= 4 && (ncg & 1) == 0) {       // many rows: 2 x 2 patches of output tiles per block
+        hipLaunchKernelGGL((k_lstm_fwd_patch<4, 2, 2>), dim3(ncg / 2, (ntiles + 1) / 2), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    dim3 grid(ncg, ntiles);
     if (prof) hipLaunchKernelGGL((k_lstm_fwd_step<true, FWD_NW>), grid, dim3(64 * FWD_NW), 0, s, a, prof);
     else hipLaunchKernelGGL((k_lstm_fwd_step<false, FWD_NW>), grid, dim3(64 * FWD_NW), 0, s, a, nullptr);
     return hipGetLastError();
