@@ -366,3 +366,26 @@ def test_nccl_allreduce_runs_on_the_gradient_tensor_and_model_stream():
         assert EpisodeParallel(m).world == 1
     finally:
         dist.destroy_process_group()
+
+
+def test_full_size_cfg_b_gradients_match_oracle():
+    """One full cfg-B train episode (B=45, T=128, V1=10001, H=512): loss and EVERY gradient tensor vs the fp64
+    oracle (230 GFLOP in numpy; a few seconds on the GPU box's host cores), realistic Zipf/padded tokens."""
+    over, N, K, Q = FULL['cfg-B']
+    cfg = small_config(**over)
+    (sup, qry), = O.synthetic_episodes(1, N, K, Q, cfg['max_len'], cfg['input_size'], seed=8, realistic=True)
+    model = new_model(cfg)
+    params = f64_params(model)
+    loss, cache, grads, aux = oracle_step(params, sup, qry, cfg)
+    model.forward_backward(sup, qry)
+    tail = model.debug_read('tail', 16)
+    assert abs(tail[1] - loss) <= NLL_RTOL * abs(loss)
+    assert abs(tail[0] - aux['embedding_slices_sq']) <= 1e-4 * aux['embedding_slices_sq']
+    for name in grads:
+        assert rel_max(model.get_grad(name), grads[name]) < 2e-4, name
+    got = model.apply_update(1.0)
+    opt = O.new_opt_state(params)
+    O.apply_update(params, grads, aux, opt, cfg)
+    for name, ref in params.items():
+        assert rel_max(model.get_param(name), ref) < 1e-4, name      # one Adam step on 9.2 M parameters (update is sign-like: sensitive where |g| ~ eps)
+    assert abs(got - loss) <= NLL_RTOL * abs(loss)
