@@ -102,6 +102,24 @@ __global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ logit
     }
 }
 
+// One wave per row: combine the per-slice (max, sum exp) partials written by the projection GEMM's epilogue.
+__global__ __launch_bounds__(256) void k_ce_combine(const float2* __restrict__ part, int nparts,
+                                                    const float* __restrict__ tgt_logit, int rows, float* __restrict__ ce) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float2* p = part + (long long)row * nparts;
+    float m = -INFINITY;
+    for (int i = lane; i < nparts; i += 64) m = fmaxf(m, p[i].x);
+    m = wave_max(m);
+    float s = 0.0f;
+    for (int i = lane; i < nparts; i += 64) {
+        const float2 v = p[i];
+        if (v.x > -INFINITY) s += v.y * expf(v.x - m);
+    }
+    s = wave_sum(s);
+    if (lane == 0) ce[row] = m + logf(s) - tgt_logit[row];
+}
+
 // out[g] = sum_{t, b in group g} ce[t*B+b] / (T*rpg + 1e-12), double accumulation, fixed order.
 __global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ ce, int T, int B, int rpg,
                                                      float* __restrict__ out) {
@@ -338,6 +356,12 @@ hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, 
                           float* lse, float* ce, float* dlogits, float inv_n) {
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_ce_rows, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+    return hipGetLastError();
+}
+
+hipError_t launch_ce_combine(hipStream_t s, const float2* part, int nparts, const float* tgt_logit, int rows, float* ce) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ce_combine, dim3((rows + 3) / 4), dim3(256), 0, s, part, nparts, tgt_logit, rows, ce);
     return hipGetLastError();
 }
 

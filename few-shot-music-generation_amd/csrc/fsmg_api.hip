@@ -72,6 +72,7 @@ struct fsmg_model {
     char* scratch = nullptr;
     int* d_tok = nullptr; int *X = nullptr, *Y = nullptr;
     std::vector<float*> Z, Hs, Cs;
+    float2* ce_part = nullptr; float* tgt_logit = nullptr; int ce_nparts = 0;
     float *dC = nullptr, *dH = nullptr, *logits = nullptr, *dlogits = nullptr, *lse = nullptr, *ce = nullptr, *dXemb = nullptr;
     double* partials = nullptr;
     int partials_cap = 0;
@@ -328,6 +329,8 @@ int ensure_scratch(fsmg_model* h, int B) {
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
     const int64_t o_lg = place(4 * rows * h->V1p), o_dlg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
     const int64_t o_dx = place(4 * rows * h->Ep);
+    const int nparts = 2 * ((h->V1p + 127) / 128);
+    const int64_t o_cep = place(8 * rows * nparts), o_tl = place(4 * rows);
     h->partials_cap = sqnorm_blocks(h->n_flat) + sqnorm_blocks(rows * h->Ep) + 8;
     const int64_t o_part = place(8 * (int64_t)h->partials_cap);
     // split-K slabs: the largest S*M*N over the backward GEMMs of this shape
@@ -377,6 +380,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     h->dlogits = (float*)(s + o_dlg);
     h->lse = (float*)(s + o_lse); h->ce = (float*)(s + o_ce); h->dXemb = (float*)(s + o_dx);
     h->partials = (double*)(s + o_part);
+    h->ce_part = (float2*)(s + o_cep); h->tgt_logit = (float*)(s + o_tl); h->ce_nparts = nparts;
     h->slabs = (float*)(s + o_slab); h->colsum_slabs = (float*)(s + o_cslab); h->slab_cap = slab_need;
     h->slabs2 = (float*)(s + o_slab2); h->colsum_slabs2 = (float*)(s + o_cslab2);
     h->Bcap = B;
@@ -482,19 +486,30 @@ inline bool use_overlap(const fsmg_model* h) { return h->overlap && !h->timing &
 int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t rows_total, bool want_dlogits) {
     const int Hp = h->Hp;
     const int64_t r0 = (int64_t)t0 * B, m = (int64_t)(t1 - t0) * B;
+    GemmArgs g{};
+    g.A = h->Hs[h->L - 1] + (size_t)B * Hp + (size_t)r0 * Hp; g.lda = Hp;
+    g.B = h->P + h->off_w; g.ldb = h->V1p;
+    g.C = h->logits + (size_t)r0 * h->V1p; g.ldc = h->V1p; g.M = (int)m; g.N = h->V1p; g.K = Hp;
+    g.bias = h->P + h->off_d; g.ksplit = 1; g.nt_store = 1;
+    if (!want_dlogits) {
+        // validation: no backward pass will read the logits, so they are never written; the GEMM epilogue emits
+        // per-row softmax partials and a small kernel finishes the cross entropy
+        ScopedTimer tm(h, "gemm_logits");
+        g.ce_part = h->ce_part + (size_t)r0 * h->ce_nparts; g.ce_tgt = h->Y + r0; g.ce_tgt_logit = h->tgt_logit + r0;
+        g.ce_nvocab = h->V1;
+        HIPCK(h, launch_gemm(ln.s, OP_KC, OP_XC, g, ln.lds_pad));          // K = Hp: never split
+        HIPCK(h, launch_ce_combine(ln.s, h->ce_part + (size_t)r0 * h->ce_nparts, h->ce_nparts,
+                                   h->tgt_logit + r0, (int)m, h->ce + r0));
+        return FSMG_OK;
+    }
     {
         ScopedTimer tm(h, "gemm_logits");
-        GemmArgs g{};
-        g.A = h->Hs[h->L - 1] + (size_t)B * Hp + (size_t)r0 * Hp; g.lda = Hp;
-        g.B = h->P + h->off_w; g.ldb = h->V1p;
-        g.C = h->logits + (size_t)r0 * h->V1p; g.ldc = h->V1p; g.M = (int)m; g.N = h->V1p; g.K = Hp;
-        g.bias = h->P + h->off_d; g.ksplit = 1; g.nt_store = 1;
         GEMMCK(gemm(h, ln, OP_KC, OP_XC, g));
     }
     {
         ScopedTimer tm(h, "ce");
         HIPCK(h, launch_ce_rows(ln.s, h->logits + (size_t)r0 * h->V1p, h->V1p, (int)m, h->V1, h->Y + r0, h->lse + r0,
-                                h->ce + r0, want_dlogits ? h->dlogits + (size_t)r0 * h->V1p : nullptr,
+                                h->ce + r0, h->dlogits + (size_t)r0 * h->V1p,
                                 (float)(1.0 / ((double)rows_total + 1e-12))));
     }
     return FSMG_OK;

@@ -23,6 +23,10 @@ struct GemmArgs {
     int ksplit;             // >= 1; slab z covers a K range, C/colsum slab stride below
     long long c_slab;       // elements between consecutive K-split slabs of C
     long long colsum_slab;
+    // forward-only cross entropy: when ce_part != nullptr C is NOT stored; instead every wave writes, per row of its
+    // 64-column slice, (max, sum exp(x - max)) over the columns < ce_nvocab into ce_part[row][2*tile_n + half] and
+    // the logit of the row's target column into ce_tgt_logit[row]
+    float2* ce_part; const int* ce_tgt; float* ce_tgt_logit; int ce_nvocab;
     int nt_store;           // 1: C is written with non-temporal stores (streaming, read back much later)
 };
 // amode/bmode in {OP_KC, OP_XC}. Supported combinations: (KC,XC) (XC,XC) (KC,KC)
@@ -75,6 +79,8 @@ hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, c
 // (softmax - onehot) * inv_n (pad columns zero) for the backward projection GEMMs
 hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt,
                           float* lse, float* ce, float* dlogits, float inv_n);
+// rows x nparts softmax partials (see GemmArgs::ce_part) -> ce[row] = logsumexp - target logit
+hipError_t launch_ce_combine(hipStream_t s, const float2* part, int nparts, const float* tgt_logit, int rows, float* ce);
 // out[g] = sum over t and b in group g of ce[t*B+b] / (T*rows_per_group + 1e-12); fixed order
 hipError_t launch_loss_reduce(hipStream_t s, const float* ce, int T, int B, int rows_per_group, int ngroups,
                               float* out);

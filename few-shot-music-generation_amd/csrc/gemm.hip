@@ -234,6 +234,30 @@ __global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void 
             const int rl = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
             const int row = m0 + wm * 64 + i * 32 + rl, col = ncol0 + c4;
             float4 v = *reinterpret_cast<const float4*>(ep + rl * EP_LD + c4);
+            if (g.ce_part != nullptr) {
+                // forward-only cross entropy: softmax statistics of this row over the wave's 64 columns; the 16
+                // lanes of a row (lane>>4 picks the row of this pass) reduce with width-16 shuffles
+                if (g.bias != nullptr && col < g.N) {
+                    const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                const float NEG = -INFINITY;
+                const float x0 = (col + 0 < g.ce_nvocab) ? v.x : NEG, x1 = (col + 1 < g.ce_nvocab) ? v.y : NEG;
+                const float x2 = (col + 2 < g.ce_nvocab) ? v.z : NEG, x3 = (col + 3 < g.ce_nvocab) ? v.w : NEG;
+                float m = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+                float sm = 0.0f;
+                if (m > NEG) sm = (expf(x0 - m) + expf(x1 - m)) + (expf(x2 - m) + expf(x3 - m));
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+                if (row < g.M) {
+                    const int t = g.ce_tgt[row];
+                    if (t >= col && t < col + 4) g.ce_tgt_logit[row] = (t == col) ? v.x : (t == col + 1) ? v.y : (t == col + 2) ? v.z : v.w;
+                    if ((lane & 15) == 0) g.ce_part[(long long)row * (2 * tilesN) + 2 * tn + wn] = make_float2(m, sm);
+                }
+                continue;
+            }
             if (row < g.M && col < g.N) {                      // N, ldc are multiples of 4: whole float4 in or out
                 if (g.bias != nullptr && z == 0) {
                     const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
