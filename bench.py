@@ -225,6 +225,15 @@ def main():
         torch.cuda.synchronize()
         out['eval'] = {'episodes_per_s': n_ev * reps / (time.perf_counter() - t0), 'batch_episodes': n_ev,
                        'mean_val_nll': float(np.mean(nll)), 'unit': 'eval episodes/s (query-only forward, 20 sequences/episode)'}
+    if rank == 0 and world == 1:
+        # the reference's calling convention: host numpy episodes in, the loss read back every step (one 23 KB H2D
+        # token copy + one synchronising 4-byte D2H per step) -- PCIe-inclusive, never the headline value
+        n_h = min(args.steps, 30)
+        t0 = time.perf_counter()
+        for i in range(n_h):
+            eng.train_step(*pool_host[i % POOL], want_loss=True)
+        out['host_synchronous'] = {'episodes_per_s': n_h / (time.perf_counter() - t0),
+                                   'note': 'host token buffers + per-step loss readback (reference train() semantics)'}
     if rank == 0 and world == 1 and not args.no_breakdown:
         # second, fully instrumented pass: every kernel class bracketed by HIP events (extra information)
         eng.timing_select(None)
