@@ -205,7 +205,7 @@ def main():
             'config': {'workload': (args.config + ' (diagnostic run, not the headline workload) -- ' if args.config != 'cfg-B' else '') + 'cfg-B: synthetic V=10000 (V1=10001) T=128 5-way 5-shot 4-query (B=45 sequences/episode), '
                                    'LSTM E=250 H=512 L=1, full train step (fwd+BPTT+clip+Adam), one episode per GPU per step',
                        'episodes_per_step': world, 'parallelism': 'episode-parallel x%d, 1 RCCL all-reduce/step' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_gemm<XC,XC,NONE,NONE> (dW = out^T * dlogits, M=512 N=10004 K=5760)',
+            'roofline': {'bound': 'mfma', 'kernel': 'k_gemm<XC,XC> = k_gemm<1, 1> (dW = out^T * dlogits, M=512 N=10004 K=5760)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': hbm_traffic(),
                          'avg_launch_ms': dom_avg_ms, 'launches': dom_n, 'algorithmic_gflop_per_launch': gf[DOMINANT]},
