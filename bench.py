@@ -14,7 +14,7 @@ With N > 1 every rank trains on its own episode per step and one RCCL all-reduce
 buffer (weak scaling: per-GPU work fixed); value = N * K / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (the dW = out^T * dlogits GEMM,
-k_gemm<XC,XC,NONE,NONE>, one launch per step) timed with HIP events on the library's stream over a
+k_gemm<XC,XC>, one launch per step) timed with HIP events on the library's stream over a
 repeat of the timed steps; `kernels` (extra) is a per-class breakdown from a second, fully instrumented pass;
 `cpu_baseline` is the oracle's torch-CPU restatement of the same step ("port": TensorFlow cannot run here)
 on a bounded sample of the same workload.
