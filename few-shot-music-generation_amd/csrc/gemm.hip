@@ -186,10 +186,12 @@ __global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
+#ifndef FSMG_DBG_NOFETCH
         if (more) {
             la.fetch(ra, kb + (kt + 1) * BK, ke, tid);
             lb.fetch(rb, kb + (kt + 1) * BK, ke, tid);
         }
+#endif
         const float* a_base = As + cur * ASZ + khalf * LDA + wm * 64 + l31;
         const float* b_base = Bs + cur * BSZ + khalf * LDB + wn * 64 + l31;
 #pragma unroll
@@ -206,11 +208,17 @@ __global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void 
 #pragma unroll
             for (int k = 0; k < BK; ++k) csum += bc[k * LDB];
         }
+#ifndef FSMG_DBG_NOSTORE
         if (more) {
             la.store(As + (cur ^ 1) * ASZ, ra, tid);
             lb.store(Bs + (cur ^ 1) * BSZ, rb, tid);
         }
+#endif
+#ifndef FSMG_DBG_NOBARRIER
         __syncthreads();
+#else
+        asm volatile("" ::: "memory");
+#endif
     }
 
     // ---- epilogue.  MFMA 32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): a lane holds

@@ -1,0 +1,74 @@
+// Standalone timing harness for csrc/gemm.hip at the cfg-B shapes of the step (links build/gemm.o directly):
+//   make -C few-shot-music-generation_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 \
+//       -Ifew-shot-music-generation_amd/csrc -Iinclude tools/gemm_bench.cpp few-shot-music-generation_amd/build/gemm.o -o tools/gemm_bench.bin
+// Usage: gemm_bench.bin [reps] [blocks_per_cu]      (blocks_per_cu < 4 applies the aux-stream LDS cap)
+// Prints per shape: ksplit, kernel-only ms (GEMM without the slab reduce), total ms, TF on the total.
+#include "fsmg_kernels.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace fsmg;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+struct Shape { const char* name; int amode, bmode; int M, N, K; int ksplit; bool colsum; };
+
+static float* dev_random(size_t n, unsigned seed) {
+    std::vector<float> h(n);
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+    float* d; CK(hipMalloc(&d, n * 4)); CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 20;
+    const int bpc = argc > 2 ? atoi(argv[2]) : 4;
+    const int pad = gemm_lds_pad_for(bpc);
+    const int TB = 5760, H = 512, V = 10004, E = 256;
+    Shape shapes[] = {
+        {"logits  Hout*W      <KC,XC>", OP_KC, OP_XC, TB, V, H, 1, false},
+        {"dhout   dlogits*W^T <KC,KC>", OP_KC, OP_KC, TB, H, V, 0, false},
+        {"dW      Hout^T*dlog <XC,XC>", OP_XC, OP_XC, H, V, TB, 0, true},
+        {"dW      (no colsum) <XC,XC>", OP_XC, OP_XC, H, V, TB, 0, false},
+        {"dKh     Hprev^T*dZ  <XC,XC>", OP_XC, OP_XC, H, 4 * H, TB, 0, true},
+        {"zx      X*Kx        <KC,XC>", OP_KC, OP_XC, TB, 4 * H, E, 1, false},
+    };
+    hipStream_t s; CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+    float* slabs; CK(hipMalloc(&slabs, (size_t)16 * 5760 * 512 * 4 + (size_t)16 * 512 * 10004 * 4));
+    float* csl; CK(hipMalloc(&csl, 16 * 10004 * 4));
+    for (const Shape& sh : shapes) {
+        const size_t an = (size_t)sh.M * sh.K, bn = (size_t)sh.K * sh.N, cn = (size_t)sh.M * sh.N;
+        float* A = dev_random(an, 1); float* B = dev_random(bn, 2);
+        float* C; CK(hipMalloc(&C, cn * 4)); float* cs; CK(hipMalloc(&cs, sh.N * 4));
+        // ksplit 0 = sweep
+        for (int S = (sh.ksplit ? sh.ksplit : 1); S <= (sh.ksplit ? sh.ksplit : 8); ++S) {
+            GemmArgs g{};
+            g.A = A; g.lda = (sh.amode == OP_KC) ? sh.K : sh.M;
+            g.B = B; g.ldb = (sh.bmode == OP_KC) ? sh.K : sh.N;
+            g.C = (S > 1) ? slabs : C; g.ldc = sh.N; g.M = sh.M; g.N = sh.N; g.K = sh.K;
+            g.ksplit = S; g.c_slab = (long long)cn;
+            if (sh.colsum) { g.colsum = (S > 1) ? csl : cs; g.colsum_slab = sh.N; }
+            float ms_k = 0, ms_t = 0;
+            for (int r = -2; r < reps; ++r) {
+                CK(hipEventRecord(e0, s));
+                CK(launch_gemm(s, sh.amode, sh.bmode, g, pad));
+                CK(hipEventRecord(e1, s));
+                if (S > 1) {
+                    CK(launch_reduce_slabs(s, slabs, (long long)cn, S, C, (long long)cn));
+                    if (sh.colsum) CK(launch_reduce_slabs(s, csl, sh.N, S, cs, sh.N));
+                }
+                CK(hipEventRecord(e2, s));
+                CK(hipEventSynchronize(e2));
+                float a, b; CK(hipEventElapsedTime(&a, e0, e1)); CK(hipEventElapsedTime(&b, e0, e2));
+                if (r >= 0) { ms_k += a; ms_t += b; }
+            }
+            ms_k /= reps; ms_t /= reps;
+            const int tiles = ((sh.M + gemm_tile_m() - 1) / gemm_tile_m()) * ((sh.N + 127) / 128);
+            printf("%s  M %5d N %5d K %5d  S %d  blocks %5d (%.2f rounds of %d)  gemm %.3f ms  total %.3f ms  %.1f TF\n", sh.name, sh.M, sh.N, sh.K, S,
+                   tiles * S, tiles * S / (256.0 * bpc), 256 * bpc, ms_k, ms_t, 2.0 * sh.M * sh.N * sh.K / (ms_t * 1e-3) / 1e12);
+        }
+        CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(cs));
+    }
+    return 0;
+}
