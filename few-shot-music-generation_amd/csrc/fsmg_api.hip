@@ -87,7 +87,7 @@ struct fsmg_model {
     hipStream_t aux = nullptr;          // low-priority stream for the projection GEMMs that overlap the recurrence
     static constexpr int NCHUNK = 16;   // max time chunks of the overlap schedule
     int nchunk = 8;                     // chunks in use (FSMG_NCHUNK)
-    int aux_blocks_per_cu = 3;          // occupancy cap of the overlapped GEMMs (FSMG_AUX_BLOCKS); swept: 8 x 3 is best at cfg-B
+    int aux_blocks_per_cu = 2;          // occupancy cap of the overlapped GEMMs (FSMG_AUX_BLOCKS); swept: 8 x 2 is best at cfg-B
     hipEvent_t ev_chunk[NCHUNK] = {};   // main -> aux (forward) / aux -> main (backward): chunk ready
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_bucket[2] = {};       // [0] softmax gradients final, [1] backward complete
@@ -483,6 +483,27 @@ int token_prep(fsmg_model* h, int n_sup, int n_qry) {
 // and FSMG_OVERLAP=0 use the single-stream order.
 inline bool use_overlap(const fsmg_model* h) { return h->overlap && !h->timing && h->aux != nullptr && h->T >= h->nchunk; }
 
+#ifdef FSMG_PHASE_DEBUG
+// compile-time debugging aid (make EXTRA=-DFSMG_PHASE_DEBUG): GPU time of the phases of the eager overlap
+// schedule, from events on the main stream; printed every 20th step
+static hipEvent_t g_ph[8]; static bool g_ph_init = false; static int g_ph_step = 0;
+static void phase_mark(fsmg_model* h, int i) {
+    if (!g_ph_init) { for (auto& e : g_ph) hipEventCreate(&e); g_ph_init = true; }
+    hipEventRecord(g_ph[i], h->stream);
+}
+static void phase_report(fsmg_model* h) {
+    if (++g_ph_step % 20) return;
+    hipStreamSynchronize(h->stream);
+    const char* nm[] = {"zx+memsets", "fwd chain", "fwd join+loss", "to bwd chain", "bwd chain", "dk/dx/embed + dW join", "update"};
+    float tot = 0;
+    for (int i = 0; i < 7; ++i) { float ms = 0; hipEventElapsedTime(&ms, g_ph[i], g_ph[i + 1]); tot += ms; fprintf(stderr, "[phase] %-24s %7.1f us\n", nm[i], ms * 1000); }
+    fprintf(stderr, "[phase] total %.1f us\n", tot * 1000);
+}
+#define PHASE(i) phase_mark(h, i)
+#else
+#define PHASE(i) ((void)0)
+#endif
+
 int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t rows_total, bool want_dlogits) {
     const int Hp = h->Hp;
     const int64_t r0 = (int64_t)t0 * B, m = (int64_t)(t1 - t0) * B;
@@ -522,6 +543,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
     const int nch = ov ? h->nchunk : 1;
+    PHASE(0);
     for (int l = 0; l < h->L; ++l) {
         const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
         const bool top = l == h->L - 1;
@@ -538,6 +560,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             g.bias = h->P + h->off_b[l]; g.ksplit = 1;
             GEMMCK(gemm(h, mainl, OP_KC, OP_XC, g));
         }
+        PHASE(1);
         for (int c = 0; c < nch; ++c) {
             const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
             {
@@ -562,6 +585,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             }
         }
     }
+    PHASE(2);
     if (ov) {
         HIPCK(h, hipEventRecord(h->ev_join, h->aux));
         HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));
@@ -601,6 +625,7 @@ int backward(fsmg_model* h, int B) {
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
     const int nch = ov ? h->nchunk : 1;
+    PHASE(3);
     HIPCK(h, hipMemsetAsync(h->G + h->off_emb, 0, sizeof(float) * (size_t)h->V1 * h->Ep, s));
     if (ov) {
         // aux: dH chunks in the order BPTT consumes them (last chunk first), then dW
@@ -621,6 +646,8 @@ int backward(fsmg_model* h, int B) {
     for (int l = h->L - 1; l >= 0; --l) {
         const bool top = l == h->L - 1;
         HIPCK(h, hipMemsetAsync(h->dC, 0, sizeof(float) * (size_t)B * Hp, s));
+        if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[nch - 1], 0));
+        PHASE(4);
         for (int c = nch - 1; c >= 0; --c) {
             const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
             if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[c], 0));
@@ -641,6 +668,7 @@ int backward(fsmg_model* h, int B) {
             }
         }
         const int in_p = h->in_dim[l];
+        PHASE(5);
         {
             ScopedTimer tm(h, "gemm_dk");
             GemmArgs g{};                     // dKh = Hprev^T * dZ, db = colsum(dZ)
@@ -672,6 +700,7 @@ int backward(fsmg_model* h, int B) {
         HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0));
     }
     if (ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));     // dW / dd landed
+    PHASE(6);
     h->have_grads = true;
     return FSMG_OK;
 }
@@ -694,6 +723,10 @@ int apply_update(fsmg_model* h, float grad_scale) {
         HIPCK(h, launch_repack_kh(s, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
                                   h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
     HIPCK(h, launch_step_increment(s, h->d_step, h->G + h->n_flat + 1, grad_scale, h->d_ring, RING_CAP));
+    PHASE(7);
+#ifdef FSMG_PHASE_DEBUG
+    phase_report(h);
+#endif
     h->have_grads = false;
     return FSMG_OK;
 }

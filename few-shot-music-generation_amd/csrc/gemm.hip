@@ -123,111 +123,17 @@ template <int XW> struct Loader<OP_XC, XW> : XcLoader<XW> {
     __device__ __forceinline__ void fetch(float4 (&r)[Nld<XW>::v], int k0, int kend, int tid) const { this->load(r, k0, kend, tid); }
 };
 
-template <int AMODE, int BMODE>
-__global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void k_gemm(const GemmArgs g) {
-    constexpr int LDA = TileLd<AMODE, BM>::v, LDB = TileLd<BMODE, BN>::v;
-    constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
-    constexpr int PIPE = 2 * ASZ + 2 * BSZ, EPI = NWAVES * 32 * 68;
-    __shared__ __attribute__((aligned(16))) float smem[PIPE > EPI ? PIPE : EPI];
-    float* As = smem;
-    float* Bs = smem + 2 * ASZ;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+// ---- epilogue shared by both kernels.  MFMA 32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): a
+// lane holds single floats of 16 rows.  Each wave transposes its 64x64 sub-tile through its own slice of the (now
+// idle) pipeline LDS, 32 rows at a time, and stores 16-byte row segments: 16 store instructions per lane
+// instead of 64 (the store tail of a short-K GEMM is issue bound).
+__device__ __forceinline__ void store_tile(const GemmArgs& g, f32x16 (&acc)[2][2], float* smem, int z, int m0, int n0,
+                                           int tn, int tilesN, int wave, int lane) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, khalf = lane >> 5;
-
-    // ---- XCD-aware tile numbering (bijective for any tile count)
-    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
-    const int nb = tilesM * tilesN;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, q = nb >> 3, r = nb & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm = bid % tilesM, tn = bid / tilesM;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- K range of this split
-    const int z = blockIdx.y;
-    int kb = 0, ke = g.K;
-    if (g.ksplit > 1) {
-        int per = ((g.K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK;
-        kb = z * per;
-        ke = min(g.K, kb + per);
-    }
-    const int nk = (ke > kb) ? (ke - kb + BK - 1) / BK : 0;
-
-    Loader<AMODE, BM> la;
-    Loader<BMODE, BN> lb;
-    la.init(g.A, g.lda, g.M, m0, g.gather, tid);
-    lb.init(g.B, g.ldb, g.N, n0, nullptr, tid);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0 && tid < BN;
-    float csum = 0.0f;
-
-    float4 ra[Nld<BM>::v], rb[Nld<BN>::v];
-    if (nk > 0) {
-        la.fetch(ra, kb, ke, tid);
-        lb.fetch(rb, kb, ke, tid);
-        la.store(As, ra, tid);
-        lb.store(Bs, rb, tid);
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-#ifndef FSMG_DBG_NOFETCH
-        if (more) {
-            la.fetch(ra, kb + (kt + 1) * BK, ke, tid);
-            lb.fetch(rb, kb + (kt + 1) * BK, ke, tid);
-        }
-#endif
-        const float* a_base = As + cur * ASZ + khalf * LDA + wm * 64 + l31;
-        const float* b_base = Bs + cur * BSZ + khalf * LDB + wn * 64 + l31;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = a_base[kk * LDA], a1 = a_base[kk * LDA + 32];
-            const float b0 = b_base[kk * LDB], b1 = b_base[kk * LDB + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (do_colsum) {
-            const float* bc = Bs + cur * BSZ + tid;
-#pragma unroll
-            for (int k = 0; k < BK; ++k) csum += bc[k * LDB];
-        }
-#ifndef FSMG_DBG_NOSTORE
-        if (more) {
-            la.store(As + (cur ^ 1) * ASZ, ra, tid);
-            lb.store(Bs + (cur ^ 1) * BSZ, rb, tid);
-        }
-#endif
-#ifndef FSMG_DBG_NOBARRIER
-        __syncthreads();
-#else
-        asm volatile("" ::: "memory");
-#endif
-    }
-
-    // ---- epilogue.  MFMA 32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): a lane holds
-    // single floats of 16 rows.  Each wave transposes its 64x64 sub-tile through its own slice of the (now
-    // idle) pipeline LDS, 32 rows at a time, and stores 16-byte row segments: 16 store instructions per lane
-    // instead of 64 (the store tail of a short-K GEMM is issue bound).
     float* C = g.C + (long long)z * g.c_slab;
     constexpr int EP_LD = 68;                                  // 64 + 4: rows stay 16-byte aligned
-    float* ep = smem + wave * (32 * EP_LD);                    // 4 waves x 8.5 KiB <= the 66 KiB pipeline buffers
+    float* ep = smem + wave * (32 * EP_LD);                    // one 8.5 KiB slice per wave
     const int ncol0 = n0 + wn * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -282,6 +188,282 @@ __global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void 
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                    // reads done before the slice is overwritten
     }
+}
+
+// XCD-aware tile numbering (bijective for any tile count): block b runs on XCD b % 8; each XCD walks a contiguous
+// range of tiles, M fastest, so the blocks sharing a B panel sit in one L2
+__device__ __forceinline__ int xcd_tile(int bid, int nb) {
+    const int xcd = bid & 7, q = nb >> 3, r = nb & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void k_gemm_staged(const GemmArgs g) {
+    constexpr int LDA = TileLd<AMODE, BM>::v, LDB = TileLd<BMODE, BN>::v;
+    constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
+    constexpr int PIPE = 2 * ASZ + 2 * BSZ, EPI = NWAVES * 32 * 68;
+    __shared__ __attribute__((aligned(16))) float smem[PIPE > EPI ? PIPE : EPI];
+    float* As = smem;
+    float* Bs = smem + 2 * ASZ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+
+    // ---- XCD-aware tile numbering (bijective for any tile count)
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    const int nb = tilesM * tilesN;
+    const int bid = xcd_tile(blockIdx.x, nb);
+    const int tm = bid % tilesM, tn = bid / tilesM;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- K range of this split
+    const int z = blockIdx.y;
+    int kb = 0, ke = g.K;
+    if (g.ksplit > 1) {
+        int per = ((g.K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK;
+        kb = z * per;
+        ke = min(g.K, kb + per);
+    }
+    const int nk = (ke > kb) ? (ke - kb + BK - 1) / BK : 0;
+
+    Loader<AMODE, BM> la;
+    Loader<BMODE, BN> lb;
+    la.init(g.A, g.lda, g.M, m0, g.gather, tid);
+    lb.init(g.B, g.ldb, g.N, n0, nullptr, tid);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0 && tid < BN;
+    float csum = 0.0f;
+
+    float4 ra[Nld<BM>::v], rb[Nld<BN>::v];
+    if (nk > 0) {
+        la.fetch(ra, kb, ke, tid);
+        lb.fetch(rb, kb, ke, tid);
+        la.store(As, ra, tid);
+        lb.store(Bs, rb, tid);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            la.fetch(ra, kb + (kt + 1) * BK, ke, tid);
+            lb.fetch(rb, kb + (kt + 1) * BK, ke, tid);
+        }
+        const float* a_base = As + cur * ASZ + khalf * LDA + wm * 64 + l31;
+        const float* b_base = Bs + cur * BSZ + khalf * LDB + wn * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = a_base[kk * LDA], a1 = a_base[kk * LDA + 32];
+            const float b0 = b_base[kk * LDB], b1 = b_base[kk * LDB + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (do_colsum) {
+            const float* bc = Bs + cur * BSZ + tid;
+#pragma unroll
+            for (int k = 0; k < BK; ++k) csum += bc[k * LDB];
+        }
+        if (more) {
+            la.store(As + (cur ^ 1) * ASZ, ra, tid);
+            lb.store(Bs + (cur ^ 1) * BSZ, rb, tid);
+        }
+        __syncthreads();
+    }
+
+    store_tile(g, acc, smem, z, m0, n0, tn, tilesN, wave, lane);
+    if (do_colsum && n0 + tid < g.N) g.colsum[(long long)z * g.colsum_slab + n0 + tid] = csum;
+}
+
+// ================================================================ main kernel
+// LDS images (dense, 8 KiB per 128 x 16 operand tile, "lane-linear": wave w owns pieces 2w and 2w+1 of each tile,
+// a piece is 1 KiB, and lane l's 16 bytes sit at piece + 16*l, so every ds_write_b128 is conflict free):
+//   XC tile: [16 k][128 x] (rows of 512 B).  Piece p = rows 2p, 2p+1; lane -> row 2p + lane/32, x = 4*(lane%32).
+//            MFMA operand read = ds_read_b32 at [k][x]: the two 32-lane halves read different rows and never
+//            conflict (ds_read_b32 is serviced per half).
+//   KC tile: 16-byte slots S = 4x + r; slot (x, r) holds k = 4*kq .. 4*kq+3 of row x with r = (kq + x/4) % 4.
+//            Piece p = rows 16p .. 16p+15; lane -> x = 16p + lane/4, r = lane%4: the 4 lanes of a row fetch its 64
+//            contiguous bytes (in rotated order) and store them untransposed.  MFMA operand read = one ds_read_b128
+//            per 4 MFMAs; the rotation spreads each of that instruction's 16-lane groups over all 64 banks.
+// K order inside a tile: a ds_read_b128 hands a lane four consecutive k of one row, so MFMA (jj, j), j = 0..3,
+// contracts k = 4*(2*jj + half) + j (half = lane/32) instead of k = 2*step + half; both operands follow the same
+// convention in either storage mode, and a sum over k does not care about the order it is taken in.
+// Edges: rows/columns past M or N are clamped to the last valid one (their products land in output rows/columns
+// that are never stored), so the steady-state loop has no predicated loads; a K range that is not a multiple of 16
+// zero-fills its last tile.
+// Global loads for tile t+1 are issued before the MFMAs of tile t (register prefetch) and written to the other LDS
+// buffer afterwards: one barrier per K tile.  (LDS-DMA, global_load_lds_dwordx4 into the same images, was measured
+// 5-10 % slower than this at 4 pieces per wave and tile: DESIGN.md "rejected".)
+constexpr int TILE_F = 128 * BK;        // floats per operand tile (both layouts are dense)
+constexpr int PIECE_F = 256;            // floats per wave instruction (1 KiB)
+
+template <int MODE>
+struct Stager {
+    const float* p[2];
+    float4 r[2];
+    long long step;
+    int kofs[2];
+    __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather, int kb, int wave, int lane) {
+        if (MODE == OP_XC) {
+            int x = x0 + 4 * (lane & 31);
+            x = min(x, X - 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                kofs[i] = 4 * wave + 2 * i + (lane >> 5);
+                p[i] = src + (long long)(kb + kofs[i]) * ld + x;
+            }
+            step = (long long)BK * ld;
+        } else {
+            const int xi = lane >> 2, r = lane & 3;
+            const int kq = (r - (xi >> 2)) & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int x = x0 + 16 * (2 * wave + i) + xi;
+                x = min(x, X - 1);
+                const long long row = gather ? (long long)gather[x] : (long long)x;
+                kofs[i] = 4 * kq;
+                p[i] = src + row * ld + kb + 4 * kq;
+            }
+            step = BK;
+        }
+    }
+    // full tile: unconditional 16-byte loads now ...
+    __device__ __forceinline__ void fetch() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { r[i] = *reinterpret_cast<const float4*>(p[i]); p[i] += step; }
+    }
+    // ... LDS writes after the MFMAs of the current tile
+    __device__ __forceinline__ void commit(float* tile, int wave, int lane) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(tile + (2 * wave + i) * PIECE_F + 4 * lane) = r[i];
+    }
+    // partial tile (k0 + 16 > kend): zeros past kend
+    __device__ __forceinline__ void fetch_partial(int k0, int kend) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + kofs[i] < kend) r[i] = *reinterpret_cast<const float4*>(p[i]);
+            p[i] += step;
+        }
+    }
+};
+
+// the four operand values of lane (x, half) for MFMAs (jj, 0..3)
+template <int MODE>
+__device__ __forceinline__ void read_frag(const float* tile, int x, int half, int jj, float (&f)[4]) {
+    if (MODE == OP_KC) {
+        const int kq = 2 * jj + half;
+        const float4 v = *reinterpret_cast<const float4*>(tile + 4 * (4 * x + ((kq + (x >> 2)) & 3)));
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+        const float* r = tile + (4 * (2 * jj + half)) * 128 + x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = r[j * 128];
+    }
+}
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 4) void k_gemm(const GemmArgs g) {
+    static_assert(BK == 16 && BM == 128, "the direct-to-LDS kernel is written for 128x128x16 tiles");
+    constexpr int PIPE = 4 * TILE_F, EPI = 4 * 32 * 68;
+    __shared__ __attribute__((aligned(1024))) float smem[PIPE > EPI ? PIPE : EPI];
+    float* As = smem;                   // [2][TILE_F]
+    float* Bs = smem + 2 * TILE_F;      // [2][TILE_F]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+
+    const int tilesM = (g.M + 127) / 128, tilesN = (g.N + 127) / 128;
+    const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
+    const int tm = bid % tilesM, tn = bid / tilesM;
+    const int m0 = tm * 128, n0 = tn * 128;
+
+    const int z = blockIdx.y;
+    int kb = 0, ke = g.K;
+    if (g.ksplit > 1) {
+        const int per = ((g.K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK;
+        kb = z * per;
+        ke = min(g.K, kb + per);
+    }
+    const int nk = (ke > kb) ? (ke - kb + BK - 1) / BK : 0;
+    const int nfull = (ke > kb) ? (ke - kb) / BK : 0;
+
+    Stager<AMODE> sa;
+    Stager<BMODE> sb;
+    sa.init(g.A, g.lda, g.M, m0, g.gather, kb, wave, lane);
+    sb.init(g.B, g.ldb, g.N, n0, nullptr, kb, wave, lane);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0 && tid < 128;
+    float csum = 0.0f;
+
+    if (nk > 0) {
+        if (nfull > 0) { sa.fetch(); sb.fetch(); }
+        else { sa.fetch_partial(kb, ke); sb.fetch_partial(kb, ke); }
+        sa.commit(As, wave, lane);
+        sb.commit(Bs, wave, lane);
+    }
+    __syncthreads();
+
+    const int xa = wm * 64 + l31, xb = wn * 64 + l31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            if (kt + 1 < nfull) { sa.fetch(); sb.fetch(); }
+            else { sa.fetch_partial(kb + (kt + 1) * BK, ke); sb.fetch_partial(kb + (kt + 1) * BK, ke); }
+        }
+        const float* at = As + cur * TILE_F;
+        const float* bt = Bs + cur * TILE_F;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            float a0[4], a1[4], b0[4], b1[4];
+            read_frag<AMODE>(at, xa, khalf, jj, a0);
+            read_frag<AMODE>(at, xa + 32, khalf, jj, a1);
+            read_frag<BMODE>(bt, xb, khalf, jj, b0);
+            read_frag<BMODE>(bt, xb + 32, khalf, jj, b1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (do_colsum) {
+            const float* bc = bt + tid;
+#pragma unroll
+            for (int k = 0; k < BK; ++k) csum += bc[k * 128];
+        }
+        if (more) {
+            sa.commit(As + (cur ^ 1) * TILE_F, wave, lane);
+            sb.commit(Bs + (cur ^ 1) * TILE_F, wave, lane);
+        }
+        __syncthreads();
+    }
+
+    store_tile(g, acc, smem, z, m0, n0, tn, tilesN, wave, lane);
     if (do_colsum && n0 + tid < g.N) g.colsum[(long long)z * g.colsum_slab + n0 + tid] = csum;
 }
 
@@ -290,7 +472,9 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     dim3 grid(tilesM * tilesN, g.ksplit > 1 ? g.ksplit : 1);
     // lds_pad: unused dynamic LDS that only lowers the number of co-resident blocks per CU
-    hipLaunchKernelGGL((k_gemm<AMODE, BMODE>), grid, dim3(NTHREADS), lds_pad, s, g);
+    // rows of a gathered XC operand change with k: that one (dKx) keeps the register-staged kernel
+    if (AMODE == OP_XC && g.gather != nullptr) hipLaunchKernelGGL((k_gemm_staged<OP_XC, OP_XC>), grid, dim3(NTHREADS), lds_pad, s, g);
+    else hipLaunchKernelGGL((k_gemm<AMODE, BMODE>), grid, dim3(NTHREADS), lds_pad, s, g);
     return hipGetLastError();
 }
 
@@ -309,14 +493,17 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, long long stride
 
 int gemm_block_slots() { return 256 * ((BK == 16 ? 4 : 2) * 256 / NTHREADS); }
 int gemm_tile_m() { return BM; }
-// dynamic-LDS padding that caps the resident blocks per CU (160 KiB LDS): leaves room for the recurrent-step
-// kernels' waves and registers when a GEMM runs beside them on the auxiliary stream
+// dynamic-LDS padding that caps the resident blocks per CU (160 KiB LDS) when a GEMM runs beside the recurrent-step
+// kernels on the auxiliary stream.  The padded block is just too big for blocks_per_cu + 1 of them to fit, NOT
+// 1/blocks_per_cu of the LDS: the first version of this cap handed the GEMM blocks all 160 KiB, so a step-kernel
+// block (4-9 KiB of LDS) could only be placed on a CU when a GEMM block retired, and a step co-running with the dW
+// GEMM took 15.8 us instead of 6.4.  With this sizing the capped blocks leave >= 36 KiB per CU.
 int gemm_lds_pad_for(int blocks_per_cu) {
-    constexpr int own = (BK == 16) ? NWAVES * 32 * 68 * 4 : 67584;  // static LDS of one block
+    constexpr int own = 4 * 32 * 68 * 4;                            // static LDS of one block (epilogue > pipeline)
     const int max_blocks = (BK == 16 ? 4 : 2) * 256 / NTHREADS;
     if (blocks_per_cu >= max_blocks) return 0;
-    const int budget = (160 * 1024) / blocks_per_cu;                // LDS share that admits exactly this many
-    return budget - own - 1024 > 0 ? budget - own - 1024 : 0;
+    const int block = (160 * 1024) / (blocks_per_cu + 1) + 1024;    // blocks_per_cu + 1 of these exceed 160 KiB
+    return block > own ? block - own : 0;
 }
 
 hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, int lds_pad) {

@@ -33,6 +33,12 @@ namespace {
 #ifndef FSMG_BWD_NW
 #define FSMG_BWD_NW 8
 #endif
+// wave priority of the step kernels.  Measured beside the cfg-B dW GEMM at 2 blocks/CU (tools/step_contention.cpp):
+// forward 18.7 us/step at priority 0, 10.9 at 3 (4.5 alone); backward 24.4 / 13.3 (6.2 alone)
+#ifndef FSMG_STEP_PRIO_LEVEL
+#define FSMG_STEP_PRIO_LEVEL 3
+#endif
+#define FSMG_STEP_PRIO __builtin_amdgcn_s_setprio(FSMG_STEP_PRIO_LEVEL)
 constexpr int FWD_NW = FSMG_FWD_NW;   // waves per forward-step block (split K = Hp)
 constexpr int BWD_NW = FSMG_BWD_NW;   // waves per backward-step block (split K = 4Hp)
 
@@ -81,7 +87,7 @@ __device__ __forceinline__ void fwd_chunk(const float4* __restrict__ af, const f
 template <bool PROF, int NW>
 __global__ __launch_bounds__(64 * NW, NW) void k_lstm_fwd_step(const LstmFwdArgs a, unsigned long long* prof) {
     __shared__ float red[NW][16][17];
-    __builtin_amdgcn_s_setprio(3);       // latency-critical chain: win issue arbitration against co-resident GEMM waves
+    FSMG_STEP_PRIO;       // latency-critical chain: win issue arbitration against co-resident GEMM waves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     const int nb = blockIdx.x;           // unit block: units 4nb..4nb+3, packed cols 16nb..16nb+15
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(64 * NW, NW) void k_lstm_fwd_patch(const LstmFwdArg
     constexpr int PAIRS = RT * 16 * CT * 4;                 // (row, unit) pairs of the patch, one epilogue thread each
     static_assert(PAIRS <= 64 * NW, "one epilogue thread per (row, unit)");
     __shared__ float red[NW][RT * 16][CT * 16 + 1];
-    __builtin_amdgcn_s_setprio(3);
+    FSMG_STEP_PRIO;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     const int Hp = a.Hp, G4 = 4 * a.Hp, ngroups = Hp >> 4;
@@ -281,7 +287,7 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ af, const f
 template <bool PROF, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void k_lstm_bwd_step(const LstmBwdArgs a, unsigned long long* prof) {
     __shared__ float red[NW][16][17];
-    __builtin_amdgcn_s_setprio(3);
+    FSMG_STEP_PRIO;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     const int u0 = blockIdx.x * 16, m0 = blockIdx.y * 16;

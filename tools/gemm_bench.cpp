@@ -1,16 +1,46 @@
 // Standalone timing harness for csrc/gemm.hip at the cfg-B shapes of the step (links build/gemm.o directly):
 //   make -C few-shot-music-generation_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 \
 //       -Ifew-shot-music-generation_amd/csrc -Iinclude tools/gemm_bench.cpp few-shot-music-generation_amd/build/gemm.o -o tools/gemm_bench.bin
-// Usage: gemm_bench.bin [reps] [blocks_per_cu]      (blocks_per_cu < 4 applies the aux-stream LDS cap)
+// Usage: gemm_bench.bin [reps] [blocks_per_cu] [verify 0/1: compare every result with a naive fp32 kernel]      (blocks_per_cu < 4 applies the aux-stream LDS cap)
 // Prints per shape: ksplit, kernel-only ms (GEMM without the slab reduce), total ms, TF on the total.
 #include "fsmg_kernels.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
+#include <algorithm>
 #include <vector>
 using namespace fsmg;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 struct Shape { const char* name; int amode, bmode; int M, N, K; int ksplit; bool colsum; };
+
+// reference: one thread per element, plain fp32 fma chain in k order
+__global__ void k_ref(const float* A, int lda, int amode, const float* B, int ldb, int bmode, float* C, int M, int N, int K) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * N) return;
+    const int m = (int)(i / N), n = (int)(i % N);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float a = (amode == OP_KC) ? A[(long long)m * lda + k] : A[(long long)k * lda + m];
+        const float b = (bmode == OP_KC) ? B[(long long)n * ldb + k] : B[(long long)k * ldb + n];
+        s = fmaf(a, b, s);
+    }
+    C[i] = s;
+}
+__global__ void k_ref_colsum(const float* B, int ldb, float* cs, int N, int K) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += B[(long long)k * ldb + n];
+    cs[n] = s;
+}
+static double max_rel(const float* d_a, const float* d_b, size_t n) {
+    std::vector<float> a(n), b(n);
+    CK(hipMemcpy(a.data(), d_a, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), d_b, n * 4, hipMemcpyDeviceToHost));
+    double e = 0, r = 0;
+    for (size_t i = 0; i < n; ++i) { double d = std::fabs((double)a[i] - b[i]); if (!(d <= e)) e = d; r = std::max(r, (double)std::fabs(b[i])); }
+    return e / (r > 0 ? r : 1);
+}
 
 static float* dev_random(size_t n, unsigned seed) {
     std::vector<float> h(n);
@@ -24,6 +54,7 @@ int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
     const int bpc = argc > 2 ? atoi(argv[2]) : 4;
     const int pad = gemm_lds_pad_for(bpc);
+    const bool verify = argc > 3 && atoi(argv[3]) != 0;
     const int TB = 5760, H = 512, V = 10004, E = 256;
     Shape shapes[] = {
         {"logits  Hout*W      <KC,XC>", OP_KC, OP_XC, TB, V, H, 1, false},
@@ -32,17 +63,34 @@ int main(int argc, char** argv) {
         {"dW      (no colsum) <XC,XC>", OP_XC, OP_XC, H, V, TB, 0, false},
         {"dKh     Hprev^T*dZ  <XC,XC>", OP_XC, OP_XC, H, 4 * H, TB, 0, true},
         {"zx      X*Kx        <KC,XC>", OP_KC, OP_XC, TB, 4 * H, E, 1, false},
+        // one of the 8 time chunks of the two-stream schedule (16 steps x 45 sequences)
+        {"logits/8 chunk      <KC,XC>", OP_KC, OP_XC, TB / 8, V, H, 1, false},
+        {"dhout/8  chunk      <KC,KC>", OP_KC, OP_KC, TB / 8, H, V, 0, false},
+        // edge shapes (partial M/N tiles, K not a multiple of 16, K < 16)
+        {"edge    <KC,XC> 70x52x20   ", OP_KC, OP_XC, 70, 52, 20, 1, false},
+        {"edge    <KC,KC> 130x48x44  ", OP_KC, OP_KC, 130, 48, 44, 0, false},
+        {"edge    <XC,XC> 48x260x49  ", OP_XC, OP_XC, 48, 260, 49, 0, true},
+        {"edge    <XC,XC> 16x64x7    ", OP_XC, OP_XC, 16, 64, 7, 1, true},
+        {"edge    <KC,XC> 6x200x12   ", OP_KC, OP_XC, 6, 200, 12, 1, false},
     };
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
     float* slabs; CK(hipMalloc(&slabs, (size_t)16 * 5760 * 512 * 4 + (size_t)16 * 512 * 10004 * 4));
-    float* csl; CK(hipMalloc(&csl, 16 * 10004 * 4));
+    float* csl; CK(hipMalloc(&csl, 32 * 10004 * 4));
     for (const Shape& sh : shapes) {
         const size_t an = (size_t)sh.M * sh.K, bn = (size_t)sh.K * sh.N, cn = (size_t)sh.M * sh.N;
         float* A = dev_random(an, 1); float* B = dev_random(bn, 2);
         float* C; CK(hipMalloc(&C, cn * 4)); float* cs; CK(hipMalloc(&cs, sh.N * 4));
+        float* Cref = nullptr; float* csref = nullptr;
+        if (verify) {
+            CK(hipMalloc(&Cref, cn * 4)); CK(hipMalloc(&csref, sh.N * 4));
+            hipLaunchKernelGGL(k_ref, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, s, A, (sh.amode == OP_KC) ? sh.K : sh.M, sh.amode,
+                               B, (sh.bmode == OP_KC) ? sh.K : sh.N, sh.bmode, Cref, sh.M, sh.N, sh.K);
+            if (sh.colsum) hipLaunchKernelGGL(k_ref_colsum, dim3((sh.N + 255) / 256), dim3(256), 0, s, B, sh.N, csref, sh.N, sh.K);
+            CK(hipStreamSynchronize(s));
+        }
         // ksplit 0 = sweep
-        for (int S = (sh.ksplit ? sh.ksplit : 1); S <= (sh.ksplit ? sh.ksplit : 8); ++S) {
+        for (int S = (sh.ksplit ? sh.ksplit : 1); S <= (sh.ksplit ? sh.ksplit : (sh.K < 256 ? 3 : (sh.M < 1000 && sh.N < 1000 ? 16 : 8))); ++S) {
             GemmArgs g{};
             g.A = A; g.lda = (sh.amode == OP_KC) ? sh.K : sh.M;
             g.B = B; g.ldb = (sh.bmode == OP_KC) ? sh.K : sh.N;
@@ -65,10 +113,17 @@ int main(int argc, char** argv) {
             }
             ms_k /= reps; ms_t /= reps;
             const int tiles = ((sh.M + gemm_tile_m() - 1) / gemm_tile_m()) * ((sh.N + 127) / 128);
+            if (verify) {
+                CK(hipStreamSynchronize(s));
+                const double e = max_rel(C, Cref, cn), ec = sh.colsum ? max_rel(cs, csref, sh.N) : 0.0;
+                printf("  verify S %d: C err %.2e  colsum err %.2e  %s\n", S, e, ec, (e < 2e-5 && ec < 2e-5) ? "ok" : "MISMATCH");
+                CK(hipMemset(C, 0xff, cn * 4));
+            }
             printf("%s  M %5d N %5d K %5d  S %d  blocks %5d (%.2f rounds of %d)  gemm %.3f ms  total %.3f ms  %.1f TF\n", sh.name, sh.M, sh.N, sh.K, S,
                    tiles * S, tiles * S / (256.0 * bpc), 256 * bpc, ms_k, ms_t, 2.0 * sh.M * sh.N * sh.K / (ms_t * 1e-3) / 1e12);
         }
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(cs));
+        if (Cref) { CK(hipFree(Cref)); CK(hipFree(csref)); }
     }
     return 0;
 }

@@ -19,7 +19,12 @@ __global__ __launch_bounds__(256) void k_mfma(float* out, int iters, float seed,
     __shared__ float lds[2 * 16 * 132];
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long t_begin = wall_clock64();
-    for (int i = tid; i < 2 * 16 * 132; i += 256) lds[i] = seed * (float)(i & 7);
+    for (int i = tid; i < 2 * 16 * 132; i += 256) {
+        // seed > 1: full-entropy operands in [-0.5, 0.5) (what a real GEMM feeds the multipliers: data toggling sets the
+        // power draw and with it the sustained clock); otherwise 8 small integers
+        unsigned hsh = (unsigned)(i + 1) * 2654435761u + blockIdx.x * 40503u; hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+        lds[i] = (seed > 1.0f) ? ((hsh >> 8) & 0xffff) / 65536.0f - 0.5f : seed * (float)(i & 7);
+    }
     __syncthreads();
     f32x16 acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -72,16 +77,16 @@ __global__ __launch_bounds__(256) void k_mfma(float* out, int iters, float seed,
 
 static int g_cap = 0, g_trace = 1;
 template <int FROM_LDS>
-static int run(const char* name, float* out, int blocks_per_cu, int iters, int reps) {
+static int run(const char* name, float* out, int blocks_per_cu, int iters, int reps, float seed = 1.0f) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int grid = 256 * blocks_per_cu;
     // dynamic LDS pad: exactly blocks_per_cu blocks fit in a CU's 160 KiB, so the dispatcher cannot stack a CU deeper
     const int dyn = g_cap ? (160 * 1024 / blocks_per_cu) - 2 * 16 * 132 * 4 - 512 : 0;
     CK(hipFuncSetAttribute((const void*)k_mfma<FROM_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-    hipLaunchKernelGGL(k_mfma<FROM_LDS>, dim3(grid), dim3(256), dyn, 0, out, iters, 1.0f, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_mfma<FROM_LDS>, dim3(grid), dim3(256), dyn, 0, out, iters, seed, (unsigned long long*)nullptr);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_mfma<FROM_LDS>, dim3(grid), dim3(256), dyn, 0, out, iters, 1.0f, (unsigned long long*)nullptr);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_mfma<FROM_LDS>, dim3(grid), dim3(256), dyn, 0, out, iters, seed, (unsigned long long*)nullptr);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -89,7 +94,7 @@ static int run(const char* name, float* out, int blocks_per_cu, int iters, int r
     const double tf = flops / (ms * 1e-3) / 1e12;
     if (g_trace) {
         unsigned long long* tr; CK(hipMalloc(&tr, grid * 32)); 
-        hipLaunchKernelGGL(k_mfma<FROM_LDS>, dim3(grid), dim3(256), dyn, 0, out, iters, 1.0f, tr);
+        hipLaunchKernelGGL(k_mfma<FROM_LDS>, dim3(grid), dim3(256), dyn, 0, out, iters, seed, tr);
         CK(hipDeviceSynchronize());
         std::vector<unsigned long long> h(grid * 4);
         CK(hipMemcpy(h.data(), tr, grid * 32, hipMemcpyDeviceToHost));
@@ -114,7 +119,12 @@ static int run(const char* name, float* out, int blocks_per_cu, int iters, int r
 
 int main() {
     float* out; CK(hipMalloc(&out, 256 * 8 * 256 * 4));
-    for (int w = 3; w <= 5; ++w) {
+    g_trace = 0;
+    for (int w = 1; w <= 3; ++w) {
+        if (run<1>("LDS      random data", out, w, 600 / w, 200, 2.0f)) return 1;
+        if (run<2>("LDS-pipe random data", out, w, 600 / w, 200, 2.0f)) return 1;
+    }
+    for (int w = 3; w <= 3; ++w) {
         if (g_cap) printf("capped: ");
         if (run<0>("REG      long ", out, w, 600 / w, 200)) return 1;     // ~0.1 s sustained
         if (run<1>("LDS      long ", out, w, 600 / w, 200)) return 1;
