@@ -102,6 +102,72 @@ __global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ logit
     }
 }
 
+// Register-resident variant for rows of up to NV * 1024 floats (cfg-B: 10 float4 per thread): the row is read ONCE,
+// exp() is evaluated once per element, and the gradient is written from registers -- the three-pass kernel above
+// re-reads 40 KB rows that have long left the L2 when thousands of rows are in flight (0.141 -> see DESIGN.md).
+// softmax = exp(x - max) / sum instead of exp(x - lse): the same value to ~1 ulp.
+template <int NV>
+__global__ __launch_bounds__(256) void k_ce_rows_reg(const float* __restrict__ logits, int ld, int n_vocab,
+                                                     const int* __restrict__ tgt, float* __restrict__ lse,
+                                                     float* __restrict__ ce, float* __restrict__ dlogits, float inv_n) {
+    __shared__ float sh[8];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = logits + (long long)r * ld;
+    float4 x[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = 4 * tid + 1024 * i;
+        x[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (v < ld) {                                   // ld is a multiple of 4 and >= n_vocab: whole float4 in bounds
+            const float4 q = *reinterpret_cast<const float4*>(row + v);
+            x[i].x = (v + 0 < n_vocab) ? q.x : -INFINITY; x[i].y = (v + 1 < n_vocab) ? q.y : -INFINITY;
+            x[i].z = (v + 2 < n_vocab) ? q.z : -INFINITY; x[i].w = (v + 3 < n_vocab) ? q.w : -INFINITY;
+        }
+        m = fmaxf(fmaxf(m, fmaxf(x[i].x, x[i].y)), fmaxf(x[i].z, x[i].w));
+    }
+    m = wave_max(m);
+    if (lane == 0) sh[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    const int t = tgt[r];
+    float s = 0.0f, xt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = 4 * tid + 1024 * i;
+        if (t >= v && t < v + 4) xt = (t == v) ? x[i].x : (t == v + 1) ? x[i].y : (t == v + 2) ? x[i].z : x[i].w;
+        x[i].x = expf(x[i].x - m); x[i].y = expf(x[i].y - m); x[i].z = expf(x[i].z - m); x[i].w = expf(x[i].w - m);
+        s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+    }
+    s = wave_sum(s);
+    xt = wave_sum(xt);                                   // exactly one lane of the block holds the target logit
+    if (lane == 0) { sh[4 + wave] = s; }
+    __syncthreads();
+    s = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+    const int tw = ((t >> 2) & 255) >> 6;                // the wave whose lanes cover column t
+    if (wave == tw && lane == 0) {
+        const float l = m + logf(s);
+        lse[r] = l;
+        ce[r] = l - xt;
+    }
+    if (dlogits == nullptr) return;
+    const float scale = inv_n / s;
+    float* drow = dlogits + (long long)r * ld;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = 4 * tid + 1024 * i;
+        if (v < ld) {
+            float4 d;
+            d.x = x[i].x * scale - (v + 0 == t ? inv_n : 0.0f);
+            d.y = x[i].y * scale - (v + 1 == t ? inv_n : 0.0f);
+            d.z = x[i].z * scale - (v + 2 == t ? inv_n : 0.0f);
+            d.w = x[i].w * scale - (v + 3 == t ? inv_n : 0.0f);
+            __builtin_nontemporal_store(d.x, drow + v); __builtin_nontemporal_store(d.y, drow + v + 1);
+            __builtin_nontemporal_store(d.z, drow + v + 2); __builtin_nontemporal_store(d.w, drow + v + 3);
+        }
+    }
+}
+
 // One wave per row: combine the per-slice (max, sum exp) partials written by the projection GEMM's epilogue.
 __global__ __launch_bounds__(256) void k_ce_combine(const float2* __restrict__ part, int nparts,
                                                     const float* __restrict__ tgt_logit, int rows, float* __restrict__ ce) {
@@ -355,7 +421,9 @@ hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, c
 hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt,
                           float* lse, float* ce, float* dlogits, float inv_n) {
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_ce_rows, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+    if (ld <= 6 * 1024) hipLaunchKernelGGL(k_ce_rows_reg<6>, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+    else if (ld <= 12 * 1024) hipLaunchKernelGGL(k_ce_rows_reg<12>, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+    else hipLaunchKernelGGL(k_ce_rows, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
     return hipGetLastError();
 }
 

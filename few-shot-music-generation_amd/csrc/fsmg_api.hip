@@ -87,6 +87,7 @@ struct fsmg_model {
     hipStream_t aux = nullptr;          // low-priority stream for the projection GEMMs that overlap the recurrence
     static constexpr int NCHUNK = 16;   // max time chunks of the overlap schedule
     int nchunk = 8;                     // chunks in use (FSMG_NCHUNK)
+    bool aux_blocks_from_env = false;
     int aux_blocks_per_cu = 2;          // occupancy cap of the overlapped GEMMs (FSMG_AUX_BLOCKS); swept: 8 x 2 is best at cfg-B
     hipEvent_t ev_chunk[NCHUNK] = {};   // main -> aux (forward) / aux -> main (backward): chunk ready
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -337,7 +338,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     int64_t slab_need = 0;
     {
         auto need = [&](int64_t M, int64_t N, int64_t K) {
-            for (int64_t slots : {(int64_t)256 * h->aux_blocks_per_cu, (int64_t)gemm_block_slots()}) {
+            for (int64_t slots : {(int64_t)256 * h->aux_blocks_per_cu, (int64_t)256 * std::min(4, h->aux_blocks_per_cu + 1), (int64_t)gemm_block_slots()}) {
                 const int S = pick_split(M, N, K, slots);
                 if (S > 1) slab_need = std::max(slab_need, (int64_t)S * M * N);
             }
@@ -348,7 +349,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     // chunked dH GEMMs of the overlap schedule have their own (smaller) shapes
     for (int c = 0; c < h->nchunk; ++c) {
         const int64_t m = ((int64_t)(c + 1) * T / h->nchunk - (int64_t)c * T / h->nchunk) * B;
-        for (int64_t slots : {(int64_t)256 * h->aux_blocks_per_cu, (int64_t)gemm_block_slots()}) {
+        for (int64_t slots : {(int64_t)256 * h->aux_blocks_per_cu, (int64_t)256 * std::min(4, h->aux_blocks_per_cu + 1), (int64_t)gemm_block_slots()}) {
             const int S = pick_split(m, Hp, h->V1p, slots);
             if (S > 1) slab_need = std::max(slab_need, (int64_t)S * m * Hp);
             const int S2 = pick_split(m, h->V1p, Hp, slots);
@@ -396,7 +397,12 @@ void drop_graphs(fsmg_model* h) {
 // A stream plus the split-K slab buffers its GEMMs may use.
 struct Lane { hipStream_t s; float* slabs; float* colsum_slabs; int lds_pad; int slots; };
 inline Lane main_lane(fsmg_model* h) { return Lane{h->stream, h->slabs, h->colsum_slabs, 0, gemm_block_slots()}; }
-inline Lane aux_lane(fsmg_model* h) { return Lane{h->aux, h->slabs2, h->colsum_slabs2, gemm_lds_pad_for(h->aux_blocks_per_cu), 256 * h->aux_blocks_per_cu}; }
+// forward-only passes (validation: many rows per step, patch step kernel) tolerate one more overlapped GEMM block
+// per CU than training steps do (measured at cfg-B: eval 2862 vs 2690 episodes/s, train 290 vs 303)
+inline Lane aux_lane(fsmg_model* h, bool forward_only = false) {
+    const int cap = std::min(4, h->aux_blocks_per_cu + (forward_only && !h->aux_blocks_from_env ? 1 : 0));
+    return Lane{h->aux, h->slabs2, h->colsum_slabs2, gemm_lds_pad_for(cap), 256 * cap};
+}
 
 // C (contiguous, ldc == N) = op(A) * op(B) with the K range split over pick_split() slabs that are
 // summed in a fixed order (deterministic); colsum likewise.
@@ -581,7 +587,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             if (top && ov) {      // projection + CE of this chunk on the auxiliary stream
                 HIPCK(h, hipEventRecord(h->ev_chunk[c], s));
                 HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_chunk[c], 0));
-                GEMMCK(logits_and_ce(h, aux_lane(h), B, t0, t1, rows, want_dlogits));
+                GEMMCK(logits_and_ce(h, aux_lane(h, !want_dlogits), B, t0, t1, rows, want_dlogits));
             }
         }
     }
@@ -814,7 +820,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         const char* env = std::getenv("FSMG_OVERLAP");
         h->overlap = env ? (env[0] != '0') : ((int64_t)h->V1 >= 8LL * h->H * h->L);
         if (const char* e = std::getenv("FSMG_NCHUNK")) h->nchunk = std::max(1, std::min((int)fsmg_model::NCHUNK, std::atoi(e)));
-        if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) h->aux_blocks_per_cu = std::max(1, std::min(4, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) { h->aux_blocks_per_cu = std::max(1, std::min(4, std::atoi(e))); h->aux_blocks_from_env = true; }
         int least = 0, greatest = 0;
         hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, least) != hipSuccess) return bail(FSMG_ERR_HIP, "aux stream create failed");

@@ -23,6 +23,8 @@ SHAPES = [
     (dict(hidden_size=48, embedding_size=24, input_size=301, max_len=9), 5, 5, 4),  # B=45 like cfg-B
     (dict(hidden_size=32, embedding_size=16, input_size=130, max_len=5), 10, 4, 3),  # B=70 > 48 rows: 2 row chunks
     (dict(hidden_size=32, embedding_size=12, input_size=77, max_len=6, n_layers=2), 3, 2, 2),   # stacked
+    (dict(hidden_size=16, embedding_size=8, input_size=12500, max_len=4), 2, 1, 1),   # vocab rows > 12288 floats: 3-pass CE kernel
+    (dict(hidden_size=16, embedding_size=8, input_size=7000, max_len=4), 2, 1, 1),    # 6144 < row <= 12288: 12-register CE kernel
 ]
 
 
