@@ -7,19 +7,16 @@
 // exp(logit - lse) - onehot inside the operand loads of two GEMMs, 4x per element, and was
 // slower).
 //
-// Tiling: 128x128 block tile, BK = 32, 256 threads = 4 wave64 as 2x2, each wave owns a
-// 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs).  Both operands are staged
-// through LDS K-major ([k][x]) so that the MFMA operand read is one conflict-free
-// ds_read_b32 per 32-lane half (lanes 0-31 take k, lanes 32-63 take k+1):
-//   * XC sources (x contiguous in HBM) are copied with 16-B loads + ds_write_b128, row
-//     stride 132 floats;
-//   * KC sources (k contiguous in HBM) are loaded 16 B along k and transposed on the way
-//     in with 4 ds_write_b32, row stride 129 floats (129 = 1 mod 32 makes the 32 lanes of
-//     a group hit 32 distinct banks).
-// Global loads for tile t+1 are issued before the MFMAs of tile t (register prefetch) and
-// written to the other LDS buffer afterwards: one barrier per K tile.
-// Blocks are numbered so that the 8 XCDs (block b -> XCD b % 8 as observed on MI355X) each
-// walk a contiguous range of tiles and share operand panels in their private L2.
+// Tiling: 128x128 block tile, BK = 16, 256 threads = 4 wave64 as 2x2, each wave owns a
+// 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs).  Two kernels:
+//   * k_gemm (the default, "main kernel" below): dense lane-linear LDS tiles, k-contiguous sources stored
+//     untransposed and read with ds_read_b128 under a permuted contraction order, branch-free steady loop;
+//   * k_gemm_staged (first version; kept for the x-contiguous operand whose K rows are GATHERED, dKx): both
+//     operands K-major in LDS ([k][x], row stride 132 floats for 16-byte copies / 129 for k-contiguous sources
+//     that are transposed on the way in with 4 ds_write_b32), predicated loads.
+// Both: global loads for tile t+1 are issued before the MFMAs of tile t (register prefetch) and written to the
+// other LDS buffer afterwards, one barrier per K tile; blocks are numbered so that the 8 XCDs (block b -> XCD
+// b % 8 as observed on MI355X) each walk a contiguous range of tiles and share operand panels in their private L2.
 #include "fsmg_kernels.h"
 
 namespace fsmg {
@@ -31,7 +28,7 @@ namespace {
 #ifndef FSMG_GEMM_BK
 #define FSMG_GEMM_BK 16
 #endif
-// BK = 16: 34 KiB LDS and <=116 VGPRs per block -> 4 resident blocks (16 waves) per CU, which covers the
+// BK = 16: 34 KiB LDS and <=104 VGPRs per block -> 4 resident blocks (16 waves) per CU, which covers the
 // per-tile barrier and the prologue/epilogue bubbles better than 2 blocks of BK = 32 (measured +5..15 % per GEMM)
 #ifndef FSMG_GEMM_BM
 #define FSMG_GEMM_BM 128
