@@ -78,6 +78,7 @@ struct fsmg_model {
     int partials_cap = 0;
     std::vector<float*> HF;             // fragment-ordered h per layer: [T+1][ceil(B/16)*16][Hp]
     float* dzF = nullptr;               // fragment-ordered dz ping-pong: [2][ceil(B/16)*16][4Hp]
+    bool persist = false;               // FSMG_PERSISTENT=1: one persistent launch per chain chunk instead of one per step
     float* khf = nullptr;               // fragment-ordered recurrent weights: per layer fwd copy, bwd copy
     bool khf_dirty = true;              // host wrote parameters since the last repack
     float* slabs = nullptr;             // split-K partial outputs of the GEMMs on the main stream
@@ -567,9 +568,18 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             GEMMCK(gemm(h, mainl, OP_KC, OP_XC, g));
         }
         PHASE(1);
+        const bool chain = h->persist && lstm_fwd_chain_supported(B, Hp);
+        if (chain)       // "not written yet" fill pattern of the h fragments of time indices 1..T (index 0 is the zero state)
+            HIPCK(h, hipMemsetAsync(h->HF[l] + Bp16 * Hp, 0xFF, sizeof(float) * (size_t)T * Bp16 * Hp, s));
         for (int c = 0; c < nch; ++c) {
             const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
-            {
+            if (chain) {
+                ScopedTimer tm(h, "lstm_fwd");
+                LstmFwdChainArgs a{};
+                a.KhF = h->khf + (size_t)(2 * l) * Hp * G4; a.HF = h->HF[l]; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
+                a.err_flag = h->d_err; a.B = B; a.Hp = Hp; a.T = T; a.t0 = t0; a.t1 = t1;
+                HIPCK(h, launch_lstm_fwd_chain(s, a));
+            } else {
                 ScopedTimer tm(h, "lstm_fwd");
                 for (int t = t0; t < t1; ++t) {
                     LstmFwdArgs a{};
@@ -746,6 +756,12 @@ int check_tokens_and_read(fsmg_model* h, const float* d_src, float scale, float*
     HIPCK(h, hipStreamSynchronize(h->stream));
     if (err) {
         HIPCK(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
+        if (err == 2) {      // a persistent step kernel gave up waiting for its peers: fall back to one launch per step
+            h->persist = false;
+            drop_graphs(h);
+            return fail(h, FSMG_ERR_HIP, "persistent recurrent kernel timed out waiting for a peer block (blocks not co-resident); "
+                                         "this handle now uses one launch per time step");
+        }
         return fail(h, FSMG_ERR_TOKEN_RANGE, "token id outside [0, input_size)");
     }
     for (int i = 0; i < n; ++i) host_out[i] = tmp[i] * scale;
@@ -819,6 +835,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         // shapes; FSMG_OVERLAP=0/1 forces the single-stream (hipGraph-replayed) / two-stream (eager) order
         const char* env = std::getenv("FSMG_OVERLAP");
         h->overlap = env ? (env[0] != '0') : ((int64_t)h->V1 >= 8LL * h->H * h->L);
+        if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_NCHUNK")) h->nchunk = std::max(1, std::min((int)fsmg_model::NCHUNK, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) { h->aux_blocks_per_cu = std::max(1, std::min(4, std::atoi(e))); h->aux_blocks_from_env = true; }
         int least = 0, greatest = 0;

@@ -55,6 +55,23 @@ struct LstmFwdArgs {
 // partials in LDS, past the barrier, done)
 hipError_t launch_lstm_fwd_step(hipStream_t s, const LstmFwdArgs& a, unsigned long long* prof = nullptr);
 
+// Persistent variant of the forward steps: ONE launch runs the time steps [t0, t1) of a layer.  Block (column tile,
+// row tile) keeps its slice of the recurrent weights in registers for the whole launch; the blocks of a row tile
+// hand h_t to each other through the fragment-ordered copy HF, whose time indices t0+1 .. t1 must be pre-filled
+// with 0xFF bytes ("not written yet", see lstm_step.hip).  All blocks must be co-resident: check
+// lstm_fwd_chain_supported() first.  A spin that does not complete sets *err_flag = 2 and every block leaves.
+struct LstmFwdChainArgs {
+    const float* KhF;     // forward fragment-ordered recurrent weights of the layer
+    float* HF;            // [T+1][ceil(B/16)*16][Hp] fragment-ordered h, time index 0 = initial state
+    float* Z;             // [T][B][4Hp] in: x-part pre-activations (+bias); out: activated gates
+    float* Cs;            // [T+1][B][Hp]
+    float* Hs;            // [T+1][B][Hp]
+    int* err_flag;
+    int B, Hp, T, t0, t1;
+};
+bool lstm_fwd_chain_supported(int B, int Hp);
+hipError_t launch_lstm_fwd_chain(hipStream_t s, const LstmFwdChainArgs& a);
+
 struct LstmBwdArgs {
     const float* KhF;      // fragment-ordered recurrent weights (backward copy)
     const float* dzF_next; // fragment-ordered dz of step t+1: [ceil(B/16)][4Hp/16][64][4] (nullptr at the last step)

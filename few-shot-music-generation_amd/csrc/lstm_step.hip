@@ -155,6 +155,158 @@ __global__ __launch_bounds__(64 * NW, NW) void k_lstm_fwd_step(const LstmFwdArgs
 }
 
 
+// ---------------------------------------------------------------- forward, persistent over a range of time steps
+// Same decomposition as k_lstm_fwd_step (block = 16 packed gate columns = 4 hidden units x one 16-row tile, 4 waves
+// split K = Hp), but the launch loops over t: the wave's slice of Kh is loaded ONCE into GPW float4 registers, c
+// stays in a register, and the only per-step traffic is the h_t fragment (GPW KiB per wave) plus the cell's own
+// inputs and outputs.  Hand-off of h_t between the 4Hp/16 blocks of a row tile (MI355X_MICROARCH.md "inter-workgroup
+// visibility"): the data is its own flag.  The fragment buffer of every time index is pre-filled with 0xFFFFFFFF
+// words (no h value has that bit pattern, not even a NaN produced by arithmetic); the producer writes its 256
+// contiguous bytes with 16-byte sc1 (write-through) stores and nothing else; each consumer wave polls ONE of its
+// fragments with sc1 loads until no component shows the fill pattern, then fetches the others and re-fetches until
+// none does (4-byte words are never torn).  A first version with a per-(row tile, step) arrival counter (drain +
+// atomic + one-lane poll + barrier + sc1 loads) took 5.3 us per step against 4.75 for one launch per step.
+// Every spin is bounded: on a timeout (some block not resident) err_flag becomes 2 and all blocks leave.
+__device__ __forceinline__ f32x4 load_sc1(const f32x4* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void store_sc1(f32x4* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// all 4 components of a fragment written (the buffer is pre-filled with 0xFFFFFFFF words; no h value has that pattern)
+__device__ __forceinline__ bool frag_ready(const f32x4& v) {
+    return __float_as_uint(v[0]) != 0xFFFFFFFFu && __float_as_uint(v[1]) != 0xFFFFFFFFu &&
+           __float_as_uint(v[2]) != 0xFFFFFFFFu && __float_as_uint(v[3]) != 0xFFFFFFFFu;
+}
+
+template <int GPW>
+__global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArgs a) {
+    __shared__ float red[4][16][17];
+    __shared__ int s_fail;
+    FSMG_STEP_PRIO;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int nb = blockIdx.x, rt = blockIdx.y;
+    const int m0 = rt * 16;
+    const int Hp = a.Hp, G4 = 4 * a.Hp, B = a.B;
+    const int ngroups = Hp >> 4;
+    const size_t hf_step = (size_t)gridDim.y * 16 * Hp;          // floats per time index of HF
+    if (tid == 0) s_fail = 0;
+
+    // this wave's slice of the recurrent weights: resident for the whole launch
+    f32x4 bw[GPW];
+    {
+        const f32x4* bf = reinterpret_cast<const f32x4*>(a.KhF) + ((size_t)nb * ngroups + wave * GPW) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < GPW; ++j) bw[j] = bf[j * 64];
+    }
+    // epilogue mapping (wave 0): thread -> (row, unit)
+    const int erow = tid >> 2, euu = tid & 3;
+    const int eb = m0 + erow, eu = 4 * nb + euu;
+    const bool eact = (tid < 64) && (eb < B);
+    float cp = eact ? a.Cs[((size_t)a.t0 * B + eb) * Hp + eu] : 0.0f;
+    __syncthreads();
+
+    for (int t = a.t0; t < a.t1; ++t) {
+        // x-part pre-activations of this step do not depend on the recurrence: requested before the wait
+        float zin[4] = {0.f, 0.f, 0.f, 0.f};
+        float* zp = a.Z + ((size_t)t * B + eb) * G4 + 16 * nb + euu;
+        if (eact) {
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) zin[gi] = zp[4 * gi];
+        }
+        // h_t fragments of this row tile, this wave's K range.  The data is its own flag: poll ONE fragment until
+        // its producer has written it, then fetch the rest and re-fetch until none shows the fill pattern.
+        f32x4 av[GPW];
+        {
+            const f32x4* af = reinterpret_cast<const f32x4*>(a.HF + (size_t)t * hf_step) + ((size_t)rt * ngroups + wave * GPW) * 64 + lane;
+            bool fail = false;
+            for (int spins = 0;; ++spins) {
+                av[0] = load_sc1(af);
+                drain_vmem();
+                asm volatile("" : "+v"(av[0]));
+                if (__all(frag_ready(av[0]))) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 255) == 255 &&
+                    (spins > (1 << 18) || __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+            }
+            if (GPW > 1 && !fail) {
+                for (int spins = 0;; ++spins) {
+#pragma unroll
+                    for (int j = 1; j < GPW; ++j) av[j] = load_sc1(af + j * 64);
+                    drain_vmem();
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 1; j < GPW; ++j) { asm volatile("" : "+v"(av[j])); ok &= frag_ready(av[j]); }
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((spins & 255) == 255 &&
+                        (spins > (1 << 18) || __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+                }
+            }
+            if (fail && lane == 0) {
+                __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_fail = 1;
+            }
+        }
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < GPW; ++j) {
+            f32x4& acc = (j & 1) ? acc1 : acc0;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][0], bw[j][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][1], bw[j][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][2], bw[j][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][3], bw[j][3], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][4 * q + r][l15] = acc0[r] + acc1[r];
+        __syncthreads();
+        if (s_fail) return;                                          // block-uniform: a wave of this block timed out
+
+        if (tid < 64) {
+            float hn = 0.0f;
+            if (eact) {
+                float zg[4];
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    const int c = 4 * gi + euu;
+                    float zs = 0.0f;                                  // same summation order as k_lstm_fwd_step
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) zs += red[w][erow][c];
+                    zg[gi] = zin[gi] + zs;
+                }
+                const float si = sigmoidf_(zg[0]);
+                const float tj = tanhf_(zg[1]);
+                const float sf = sigmoidf_(zg[2] + 1.0f);          // forget_bias = 1 added at run time
+                const float so = sigmoidf_(zg[3]);
+                const float cn = cp * sf + si * tj;
+                hn = tanhf_(cn) * so;
+                cp = cn;
+                a.Cs[((size_t)(t + 1) * B + eb) * Hp + eu] = cn;
+                a.Hs[((size_t)(t + 1) * B + eb) * Hp + eu] = hn;
+                zp[0] = si; zp[4] = tj; zp[8] = sf; zp[12] = so;  // activated gates kept for BPTT
+            }
+            // fragment-ordered h_{t+1}: the 4 units of a row are one float4 (group eu/16, lane slot 4*(eu&12) + row);
+            // pad rows publish zeros, so every word of the buffer is written and the readers' test terminates
+            f32x4 hv;
+            hv[0] = __shfl(hn, (lane & ~3) + 0); hv[1] = __shfl(hn, (lane & ~3) + 1);
+            hv[2] = __shfl(hn, (lane & ~3) + 2); hv[3] = __shfl(hn, (lane & ~3) + 3);
+            if (euu == 0) {
+                const int u0 = 4 * nb;
+                f32x4* dst = reinterpret_cast<f32x4*>(a.HF + (size_t)(t + 1) * hf_step) +
+                             ((size_t)rt * ngroups + (u0 >> 4)) * 64 + 4 * (u0 & 12) + erow;
+                store_sc1(dst, hv);
+            }
+        }
+        // the other waves may run ahead into step t+1: they cannot pass its poll before wave 0 has published, which
+        // it does after its last read of `red`
+    }
+}
+
 // ---------------------------------------------------------------- forward, many rows (validation batches, wide episodes)
 // With R row tiles every (column group, row tile) block of the kernel above re-fetches fragments that its
 // neighbours fetch too: R x the weights, 4Hp/16 x the activations (164 MB of L2->CU traffic per step at 320
@@ -389,6 +541,33 @@ hipError_t launch_lstm_fwd_step(hipStream_t s, const LstmFwdArgs& a, unsigned lo
     dim3 grid(ncg, ntiles);
     if (prof) hipLaunchKernelGGL((k_lstm_fwd_step<true, FWD_NW>), grid, dim3(64 * FWD_NW), 0, s, a, prof);
     else hipLaunchKernelGGL((k_lstm_fwd_step<false, FWD_NW>), grid, dim3(64 * FWD_NW), 0, s, a, nullptr);
+    return hipGetLastError();
+}
+
+// shapes the persistent forward kernel takes: K groups split evenly over the 4 waves into 1..16 per wave, and every
+// block of the grid resident at once (with a margin: co-resident GEMM blocks only delay residency, but another
+// persistent launch could hold slots for good)
+bool lstm_fwd_chain_supported(int B, int Hp) {
+    const int ngroups = Hp >> 4;
+    if ((Hp & 15) || (ngroups & 3)) return false;
+    const int gpw = ngroups >> 2;
+    if (gpw != 1 && gpw != 2 && gpw != 4 && gpw != 8 && gpw != 16) return false;
+    const long long blocks = (long long)(4 * Hp / 16) * ((B + 15) / 16);
+    const int per_cu = gpw >= 16 ? 2 : 4;                      // register-limited residency of 256-thread blocks
+    return blocks <= (long long)256 * per_cu * 3 / 4;
+}
+
+hipError_t launch_lstm_fwd_chain(hipStream_t s, const LstmFwdChainArgs& a) {
+    if (a.t1 <= a.t0) return hipSuccess;
+    dim3 grid((4 * a.Hp) / 16, (a.B + 15) / 16);
+    switch ((a.Hp >> 4) >> 2) {
+        case 1: hipLaunchKernelGGL((k_lstm_fwd_chain<1>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_lstm_fwd_chain<2>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_lstm_fwd_chain<4>), grid, dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_lstm_fwd_chain<8>), grid, dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_lstm_fwd_chain<16>), grid, dim3(256), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

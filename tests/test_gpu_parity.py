@@ -23,6 +23,8 @@ SHAPES = [
     (dict(hidden_size=48, embedding_size=24, input_size=301, max_len=9), 5, 5, 4),  # B=45 like cfg-B
     (dict(hidden_size=32, embedding_size=16, input_size=130, max_len=5), 10, 4, 3),  # B=70 > 48 rows: 2 row chunks
     (dict(hidden_size=32, embedding_size=12, input_size=77, max_len=6, n_layers=2), 3, 2, 2),   # stacked
+    (dict(hidden_size=64, embedding_size=16, input_size=120, max_len=6), 3, 2, 2),                # Hp = 64: persistent chain kernels, 1 k-group per wave
+    (dict(hidden_size=128, embedding_size=24, input_size=90, max_len=7), 5, 5, 4),               # Hp = 128, 3 row tiles: 2 k-groups per wave
     (dict(hidden_size=16, embedding_size=8, input_size=12500, max_len=4), 2, 1, 1),   # vocab rows > 12288 floats: 3-pass CE kernel
     (dict(hidden_size=16, embedding_size=8, input_size=7000, max_len=4), 2, 1, 1),    # 6144 < row <= 12288: 12-register CE kernel
 ]
@@ -207,6 +209,24 @@ def test_all_schedules_are_bit_identical(monkeypatch):
         assert out[0][0] == other[0] and out[0][1] == other[1]
         for k in out[0][2]:
             np.testing.assert_array_equal(out[0][2][k], other[2][k])
+
+
+def test_persistent_forward_chain_is_bit_identical(monkeypatch):
+    """FSMG_PERSISTENT=1 (one launch per chain chunk, h handed between blocks inside the launch; measured slower
+    than one launch per step and off by default) computes exactly the same step, in both schedules."""
+    cfg = small_config(hidden_size=128, embedding_size=32, input_size=150, max_len=24, n_layers=2)
+    eps = O.synthetic_episodes(3, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=12)      # 45 rows: 3 row tiles
+    out = []
+    for persistent, overlap in (('0', '0'), ('1', '0'), ('1', '1')):
+        monkeypatch.setenv('FSMG_PERSISTENT', persistent)
+        monkeypatch.setenv('FSMG_OVERLAP', overlap)
+        model = new_model(cfg)
+        losses = [model.train_step(s, q) for s, q in eps]
+        out.append((losses, model.get_params()))
+    for other in out[1:]:
+        assert out[0][0] == other[0]
+        for k in out[0][1]:
+            np.testing.assert_array_equal(out[0][1][k], other[1][k])
 
 
 def test_split_k_paths_match_oracle_at_wide_shapes():
