@@ -273,6 +273,8 @@ __global__ __launch_bounds__(256) void k_sqnorm_partials(const float* __restrict
 __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
     __shared__ double sh[4];
     __shared__ float s_scale, s_alpha;
+    // the gradients of a step whose persistent recurrent kernel timed out are garbage: keep the parameters
+    if (a.err_flag != nullptr && *a.err_flag == 2) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;
     for (int i = tid; i < a.n_partials; i += 256) s += a.partials[i];
@@ -316,7 +318,8 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
 }
 
 __global__ void k_step_increment(long long* step, const float* loss_src, float loss_scale, float* ring,
-                                 int ring_cap) {
+                                 int ring_cap, const int* err_flag) {
+    if (err_flag != nullptr && *err_flag == 2) return;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const long long s = *step;
         if (ring != nullptr && loss_src != nullptr) ring[s % ring_cap] = *loss_src * loss_scale;
@@ -465,8 +468,8 @@ hipError_t launch_adam_update(hipStream_t s, const UpdateArgs& a) {
 }
 
 hipError_t launch_step_increment(hipStream_t s, long long* step, const float* loss_src, float loss_scale,
-                                 float* loss_ring, int ring_cap) {
-    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(64), 0, s, step, loss_src, loss_scale, loss_ring, ring_cap);
+                                 float* loss_ring, int ring_cap, const int* err_flag) {
+    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(64), 0, s, step, loss_src, loss_scale, loss_ring, ring_cap, err_flag);
     return hipGetLastError();
 }
 

@@ -78,7 +78,10 @@ struct fsmg_model {
     int partials_cap = 0;
     std::vector<float*> HF;             // fragment-ordered h per layer: [T+1][ceil(B/16)*16][Hp]
     float* dzF = nullptr;               // fragment-ordered dz ping-pong: [2][ceil(B/16)*16][4Hp]
-    bool persist = false;               // FSMG_PERSISTENT=1: one persistent launch per chain chunk instead of one per step
+    float* dzF_all = nullptr;           // persistent backward chain: fragment-ordered dz of every time step [T][ceil(B/16)*16][4Hp]
+    int chain_spin_limit = 1 << 18;     // FSMG_CHAIN_SPIN_LIMIT (0 forces the timeout + fallback path: tests)
+    bool persist_timed_out = false;     // set when a persistent kernel gave up (the handle has switched to per-step launches)
+    bool persist = true;                // FSMG_PERSISTENT=0: one launch per time step instead of one persistent launch per chain chunk
     float* khf = nullptr;               // fragment-ordered recurrent weights: per layer fwd copy, bwd copy
     bool khf_dirty = true;              // host wrote parameters since the last repack
     float* slabs = nullptr;             // split-K partial outputs of the GEMMs on the main stream
@@ -87,7 +90,9 @@ struct fsmg_model {
     float* colsum_slabs2 = nullptr;
     hipStream_t aux = nullptr;          // low-priority stream for the projection GEMMs that overlap the recurrence
     static constexpr int NCHUNK = 16;   // max time chunks of the overlap schedule
-    int nchunk = 8;                     // chunks in use (FSMG_NCHUNK)
+    int nchunk = 8;                     // chunks in use with one launch per step (FSMG_NCHUNK)
+    int nchunk_persist = 2;             // ... and with the persistent step kernels (swept at cfg-B: 2 chunks x 3 blocks/CU)
+    int aux_blocks_persist = 3;
     bool aux_blocks_from_env = false;
     int aux_blocks_per_cu = 2;          // occupancy cap of the overlapped GEMMs (FSMG_AUX_BLOCKS); swept: 8 x 2 is best at cfg-B
     hipEvent_t ev_chunk[NCHUNK] = {};   // main -> aux (forward) / aux -> main (backward): chunk ready
@@ -328,6 +333,8 @@ int ensure_scratch(fsmg_model* h, int B) {
     std::vector<int64_t> o_hf(h->L);
     for (int l = 0; l < h->L; ++l) o_hf[l] = place(4 * (T + 1) * Bp16 * Hp);
     const int64_t o_dzf = place(4 * 2 * Bp16 * G4);
+    const bool want_dzfa = h->persist && lstm_bwd_chain_supported(B, (int)Hp);
+    const int64_t o_dzfa = place(want_dzfa ? 4 * T * Bp16 * G4 : 256);
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
     const int64_t o_lg = place(4 * rows * h->V1p), o_dlg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
     const int64_t o_dx = place(4 * rows * h->Ep);
@@ -339,7 +346,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     int64_t slab_need = 0;
     {
         auto need = [&](int64_t M, int64_t N, int64_t K) {
-            for (int64_t slots : {(int64_t)256 * h->aux_blocks_per_cu, (int64_t)256 * std::min(4, h->aux_blocks_per_cu + 1), (int64_t)gemm_block_slots()}) {
+            for (int64_t slots : {(int64_t)256, (int64_t)512, (int64_t)768, (int64_t)gemm_block_slots()}) {
                 const int S = pick_split(M, N, K, slots);
                 if (S > 1) slab_need = std::max(slab_need, (int64_t)S * M * N);
             }
@@ -348,9 +355,10 @@ int ensure_scratch(fsmg_model* h, int B) {
         need(h->Ep, G4, rows); need(rows, h->Ep, G4); need(rows, Hp, G4); need(rows, G4, h->Ep); need(rows, G4, Hp);
     }
     // chunked dH GEMMs of the overlap schedule have their own (smaller) shapes
-    for (int c = 0; c < h->nchunk; ++c) {
-        const int64_t m = ((int64_t)(c + 1) * T / h->nchunk - (int64_t)c * T / h->nchunk) * B;
-        for (int64_t slots : {(int64_t)256 * h->aux_blocks_per_cu, (int64_t)256 * std::min(4, h->aux_blocks_per_cu + 1), (int64_t)gemm_block_slots()}) {
+    for (int nc : {h->nchunk, h->nchunk_persist})
+    for (int c = 0; c < nc; ++c) {
+        const int64_t m = ((int64_t)(c + 1) * T / nc - (int64_t)c * T / nc) * B;
+        for (int64_t slots : {(int64_t)256, (int64_t)512, (int64_t)768, (int64_t)gemm_block_slots()}) {
             const int S = pick_split(m, Hp, h->V1p, slots);
             if (S > 1) slab_need = std::max(slab_need, (int64_t)S * m * Hp);
             const int S2 = pick_split(m, h->V1p, Hp, slots);
@@ -376,6 +384,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     h->HF.assign(h->L, nullptr);
     for (int l = 0; l < h->L; ++l) h->HF[l] = (float*)(s + o_hf[l]);
     h->dzF = (float*)(s + o_dzf);
+    h->dzF_all = want_dzfa ? (float*)(s + o_dzfa) : nullptr;
     // pad rows of the fragment buffers are never written: clear once so they hold finite values
     HIPCK(h, hipMemsetAsync(s + o_hf[0], 0, (size_t)(o_dc - o_hf[0]), h->stream));
     h->dC = (float*)(s + o_dc); h->dH = (float*)(s + o_dh); h->logits = (float*)(s + o_lg);
@@ -400,8 +409,8 @@ struct Lane { hipStream_t s; float* slabs; float* colsum_slabs; int lds_pad; int
 inline Lane main_lane(fsmg_model* h) { return Lane{h->stream, h->slabs, h->colsum_slabs, 0, gemm_block_slots()}; }
 // forward-only passes (validation: many rows per step, patch step kernel) tolerate one more overlapped GEMM block
 // per CU than training steps do (measured at cfg-B: eval 2862 vs 2690 episodes/s, train 290 vs 303)
-inline Lane aux_lane(fsmg_model* h, bool forward_only = false) {
-    const int cap = std::min(4, h->aux_blocks_per_cu + (forward_only && !h->aux_blocks_from_env ? 1 : 0));
+inline Lane aux_lane(fsmg_model* h, bool forward_only = false, bool persistent_chain = false) {
+    const int cap = std::min(4, (persistent_chain ? h->aux_blocks_persist : h->aux_blocks_per_cu) + (forward_only && !h->aux_blocks_from_env ? 1 : 0));
     return Lane{h->aux, h->slabs2, h->colsum_slabs2, gemm_lds_pad_for(cap), 256 * cap};
 }
 
@@ -488,7 +497,7 @@ int token_prep(fsmg_model* h, int n_sup, int n_qry) {
 // so the projection work runs on a low-priority auxiliary stream, forked / joined with events (inside
 // the captured graph these become parallel branches).  Event timing (eager, one class at a time)
 // and FSMG_OVERLAP=0 use the single-stream order.
-inline bool use_overlap(const fsmg_model* h) { return h->overlap && !h->timing && h->aux != nullptr && h->T >= h->nchunk; }
+inline bool use_overlap(const fsmg_model* h) { return h->overlap && !h->timing && h->aux != nullptr && h->T >= std::max(h->nchunk, h->nchunk_persist); }
 
 #ifdef FSMG_PHASE_DEBUG
 // compile-time debugging aid (make EXTRA=-DFSMG_PHASE_DEBUG): GPU time of the phases of the eager overlap
@@ -549,7 +558,8 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
-    const int nch = ov ? h->nchunk : 1;
+    const bool chain = h->persist && lstm_fwd_chain_supported(B, Hp);
+    const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
     PHASE(0);
     for (int l = 0; l < h->L; ++l) {
         const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
@@ -568,7 +578,6 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             GEMMCK(gemm(h, mainl, OP_KC, OP_XC, g));
         }
         PHASE(1);
-        const bool chain = h->persist && lstm_fwd_chain_supported(B, Hp);
         if (chain)       // "not written yet" fill pattern of the h fragments of time indices 1..T (index 0 is the zero state)
             HIPCK(h, hipMemsetAsync(h->HF[l] + Bp16 * Hp, 0xFF, sizeof(float) * (size_t)T * Bp16 * Hp, s));
         for (int c = 0; c < nch; ++c) {
@@ -577,7 +586,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
                 ScopedTimer tm(h, "lstm_fwd");
                 LstmFwdChainArgs a{};
                 a.KhF = h->khf + (size_t)(2 * l) * Hp * G4; a.HF = h->HF[l]; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
-                a.err_flag = h->d_err; a.B = B; a.Hp = Hp; a.T = T; a.t0 = t0; a.t1 = t1;
+                a.err_flag = h->d_err; a.B = B; a.Hp = Hp; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_fwd_chain(s, a));
             } else {
                 ScopedTimer tm(h, "lstm_fwd");
@@ -597,7 +606,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             if (top && ov) {      // projection + CE of this chunk on the auxiliary stream
                 HIPCK(h, hipEventRecord(h->ev_chunk[c], s));
                 HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_chunk[c], 0));
-                GEMMCK(logits_and_ce(h, aux_lane(h, !want_dlogits), B, t0, t1, rows, want_dlogits));
+                GEMMCK(logits_and_ce(h, aux_lane(h, !want_dlogits, chain), B, t0, t1, rows, want_dlogits));
             }
         }
     }
@@ -640,7 +649,9 @@ int backward(fsmg_model* h, int B) {
     const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
-    const int nch = ov ? h->nchunk : 1;
+    const bool chain = h->persist && h->dzF_all != nullptr && lstm_bwd_chain_supported(B, Hp);
+    const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
+    const Lane auxl = aux_lane(h, false, chain);
     PHASE(3);
     HIPCK(h, hipMemsetAsync(h->G + h->off_emb, 0, sizeof(float) * (size_t)h->V1 * h->Ep, s));
     if (ov) {
@@ -649,10 +660,10 @@ int backward(fsmg_model* h, int B) {
         HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
         for (int c = nch - 1; c >= 0; --c) {
             const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
-            GEMMCK(dhout_chunk(h, aux_lane(h), B, t0, t1));
+            GEMMCK(dhout_chunk(h, auxl, B, t0, t1));
             HIPCK(h, hipEventRecord(h->ev_chunk[c], h->aux));
         }
-        GEMMCK(dw_gemm(h, aux_lane(h), B));
+        GEMMCK(dw_gemm(h, auxl, B));
         HIPCK(h, hipEventRecord(h->ev_join, h->aux));
         HIPCK(h, hipEventRecord(h->ev_bucket[0], h->aux));
     } else {
@@ -664,10 +675,21 @@ int backward(fsmg_model* h, int B) {
         HIPCK(h, hipMemsetAsync(h->dC, 0, sizeof(float) * (size_t)B * Hp, s));
         if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[nch - 1], 0));
         PHASE(4);
+        if (chain) {     // "not written yet" fill pattern of the dz fragments of every time step
+            const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
+            HIPCK(h, hipMemsetAsync(h->dzF_all, 0xFF, sizeof(float) * (size_t)T * Bp16 * G4, s));
+        }
         for (int c = nch - 1; c >= 0; --c) {
             const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
             if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[c], 0));
             ScopedTimer tm(h, "lstm_bwd");
+            if (chain) {
+                LstmBwdChainArgs a{};
+                a.KhF = h->khf + (size_t)(2 * l + 1) * Hp * G4; a.dzF_all = h->dzF_all; a.Z = h->Z[l]; a.Cs = h->Cs[l];
+                a.dc = h->dC; a.dH = h->dH; a.err_flag = h->d_err; a.B = B; a.Hp = Hp; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
+                HIPCK(h, launch_lstm_bwd_chain(s, a));
+                continue;
+            }
             for (int t = t1 - 1; t >= t0; --t) {
                 LstmBwdArgs a{};
                 const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
@@ -733,12 +755,12 @@ int apply_update(fsmg_model* h, float grad_scale) {
     a.p = h->P; a.m = h->M; a.v = h->Vv; a.g = h->G; a.n = h->n_flat;
     a.partials = h->partials; a.n_partials = nb; a.tail = h->G + h->n_flat; a.use_slices = slices ? 1 : 0;
     a.grad_scale = grad_scale; a.lr = h->cfg.lr; a.n_decay = h->cfg.n_decay; a.clip = h->cfg.max_grad_norm;
-    a.step = h->d_step; a.gnorm_out = h->d_gnorm;
+    a.step = h->d_step; a.gnorm_out = h->d_gnorm; a.err_flag = h->d_err;
     HIPCK(h, launch_adam_update(s, a));
     for (int l = 0; l < h->L; ++l)           // refresh the fragment-ordered recurrent weights
         HIPCK(h, launch_repack_kh(s, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
                                   h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
-    HIPCK(h, launch_step_increment(s, h->d_step, h->G + h->n_flat + 1, grad_scale, h->d_ring, RING_CAP));
+    HIPCK(h, launch_step_increment(s, h->d_step, h->G + h->n_flat + 1, grad_scale, h->d_ring, RING_CAP, h->d_err));
     PHASE(7);
 #ifdef FSMG_PHASE_DEBUG
     phase_report(h);
@@ -758,6 +780,7 @@ int check_tokens_and_read(fsmg_model* h, const float* d_src, float scale, float*
         HIPCK(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
         if (err == 2) {      // a persistent step kernel gave up waiting for its peers: fall back to one launch per step
             h->persist = false;
+            h->persist_timed_out = true;
             drop_graphs(h);
             return fail(h, FSMG_ERR_HIP, "persistent recurrent kernel timed out waiting for a peer block (blocks not co-resident); "
                                          "this handle now uses one launch per time step");
@@ -836,8 +859,9 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         const char* env = std::getenv("FSMG_OVERLAP");
         h->overlap = env ? (env[0] != '0') : ((int64_t)h->V1 >= 8LL * h->H * h->L);
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
-        if (const char* e = std::getenv("FSMG_NCHUNK")) h->nchunk = std::max(1, std::min((int)fsmg_model::NCHUNK, std::atoi(e)));
-        if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) { h->aux_blocks_per_cu = std::max(1, std::min(4, std::atoi(e))); h->aux_blocks_from_env = true; }
+        if (const char* e = std::getenv("FSMG_CHAIN_SPIN_LIMIT")) h->chain_spin_limit = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("FSMG_NCHUNK")) h->nchunk = h->nchunk_persist = std::max(1, std::min((int)fsmg_model::NCHUNK, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) { h->aux_blocks_per_cu = h->aux_blocks_persist = std::max(1, std::min(4, std::atoi(e))); h->aux_blocks_from_env = true; }
         int least = 0, greatest = 0;
         hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, least) != hipSuccess) return bail(FSMG_ERR_HIP, "aux stream create failed");
@@ -1064,7 +1088,16 @@ int fsmg_train_step(fsmg_handle h, const int32_t* support, const int32_t* query,
                     int32_t tokens_on_device, float* loss) {
     int rc = fsmg_forward_backward(h, support, query, N, K, Q, tokens_on_device);
     if (rc != FSMG_OK) return rc;
-    return fsmg_apply_update(h, 1.0f, loss);
+    rc = fsmg_apply_update(h, 1.0f, loss);
+    if (rc == FSMG_ERR_HIP && h->persist_timed_out) {
+        // a persistent step kernel could not get all of its blocks resident (another workload holds the CUs): the
+        // update kernels saw the flag and left parameters, Adam state and step counter alone, and the handle has
+        // fallen back to one launch per time step -- repeat the step that way
+        h->persist_timed_out = false;
+        rc = fsmg_forward_backward(h, support, query, N, K, Q, tokens_on_device);
+        if (rc == FSMG_OK) rc = fsmg_apply_update(h, 1.0f, loss);
+    }
+    return rc;
 }
 
 int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, int32_t N, int32_t Q,

@@ -68,6 +68,7 @@ struct LstmFwdChainArgs {
     float* Hs;            // [T+1][B][Hp]
     int* err_flag;
     int B, Hp, T, t0, t1;
+    int spin_limit;       // polls before a wave gives up (each ~0.5 us); 0 forces the timeout path (tests)
 };
 bool lstm_fwd_chain_supported(int B, int Hp);
 hipError_t launch_lstm_fwd_chain(hipStream_t s, const LstmFwdChainArgs& a);
@@ -84,6 +85,23 @@ struct LstmBwdArgs {
     int B, Hp;
 };
 hipError_t launch_lstm_bwd_step(hipStream_t s, const LstmBwdArgs& a, unsigned long long* prof = nullptr);
+
+// Persistent variant of the backward steps: ONE launch runs BPTT for the time steps t1-1 down to t0 of a layer.  Same
+// hand-off protocol as LstmFwdChainArgs; dz_t is handed over through dzF_all[t], whose indices t0 .. t1-1 must be
+// pre-filled with 0xFF bytes.  Step t reads dzF_all[t+1] (skipped when t+1 == T: no recurrent gradient arrives).
+struct LstmBwdChainArgs {
+    const float* KhF;      // backward fragment-ordered recurrent weights of the layer
+    float* dzF_all;        // [T][ceil(B/16)*16][4Hp] fragment-ordered dz per time step
+    float* Z;              // [T][B][4Hp] in: activated gates; out: dz (row-major, for the weight-gradient GEMMs)
+    const float* Cs;       // [T+1][B][Hp]
+    float* dc;             // [B][Hp] carried cell gradient: read at t1-1, written back after t0
+    const float* dH;       // [T][B][Hp] gradient arriving from above
+    int* err_flag;
+    int B, Hp, T, t0, t1;
+    int spin_limit;
+};
+bool lstm_bwd_chain_supported(int B, int Hp);
+hipError_t launch_lstm_bwd_chain(hipStream_t s, const LstmBwdChainArgs& a);
 // recurrent weights [Hp][4Hp] -> the forward and backward fragment-ordered copies (Hp*4Hp floats each)
 hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp);
 
@@ -116,10 +134,11 @@ struct UpdateArgs {
     float lr, n_decay, clip;
     const long long* step;                        // global_step BEFORE this update (device)
     float* gnorm_out;                             // optional: pre-clip global norm
+    const int* err_flag;                          // optional: *err_flag == 2 (a persistent step kernel gave up) -> no update
 };
 hipError_t launch_adam_update(hipStream_t s, const UpdateArgs& a);
 hipError_t launch_step_increment(hipStream_t s, long long* step, const float* loss_src, float loss_scale,
-                                 float* loss_ring, int ring_cap);
+                                 float* loss_ring, int ring_cap, const int* err_flag = nullptr);
 // dst[0] = (float) sum of partials[0..n) (fixed order)
 hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst);
 // greedy decode step pieces (sample)

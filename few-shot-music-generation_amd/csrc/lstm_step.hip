@@ -231,8 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
                 asm volatile("" : "+v"(av[0]));
                 if (__all(frag_ready(av[0]))) break;
                 __builtin_amdgcn_s_sleep(1);
-                if ((spins & 255) == 255 &&
-                    (spins > (1 << 18) || __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+                if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
             }
             if (GPW > 1 && !fail) {
                 for (int spins = 0;; ++spins) {
@@ -244,8 +243,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
                     for (int j = 1; j < GPW; ++j) { asm volatile("" : "+v"(av[j])); ok &= frag_ready(av[j]); }
                     if (__all(ok)) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if ((spins & 255) == 255 &&
-                        (spins > (1 << 18) || __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+                    if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
                 }
             }
             if (fail && lane == 0) {
@@ -412,6 +410,23 @@ __global__ __launch_bounds__(64 * NW, NW) void k_lstm_fwd_patch(const LstmFwdArg
     }
 }
 
+// Gate gradients of one (row, unit) of one time step.  One definition with floating-point contraction OFF, shared by
+// the per-step and the persistent kernels, so both produce the same bits whatever fusions the surrounding code invites.
+struct CellGrad { float di, dj, df, dg, dc_out; };
+__device__ __forceinline__ CellGrad cell_backward(float si, float tj, float sf, float so, float ct, float cp,
+                                                  float dc_in, float dh) {
+#pragma clang fp contract(off)
+    CellGrad g;
+    const float tc = tanhf_(ct);
+    const float dc = dc_in + dh * so * (1.0f - tc * tc);
+    g.di = dc * tj * si * (1.0f - si);
+    g.dj = dc * si * (1.0f - tj * tj);
+    g.df = dc * cp * sf * (1.0f - sf);
+    g.dg = dh * tc * so * (1.0f - so);
+    g.dc_out = dc * sf;
+    return g;
+}
+
 // ---------------------------------------------------------------- backward
 // grid (Hp/16, ceil(B/16)); 512 threads = 8 waves splitting K = 4Hp (packed gate columns).
 // dh_rec[b][u] = sum_pc dz_{t+1}[b][pc] * Kh[u][pc]; then the gate gradients of step t for the
@@ -481,20 +496,130 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_lstm_bwd_step(const LstmBwd
         float dh_rec = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) dh_rec += red[w][erow][eun];
-        const float tc = tanhf_(ct);
-        const float dh = dht + dh_rec;
-        const float dc = dcv + dh * so * (1.0f - tc * tc);
-        const float di = dc * tj * si * (1.0f - si);
-        const float dj = dc * si * (1.0f - tj * tj);
-        const float df = dc * cp * sf * (1.0f - sf);
-        const float dg = dh * tc * so * (1.0f - so);
+        const CellGrad cg = cell_backward(si, tj, sf, so, ct, cp, dcv, dht + dh_rec);
+        const float di = cg.di, dj = cg.dj, df = cg.df, dg = cg.dg;
         gp[0] = di; gp[4] = dj; gp[8] = df; gp[12] = dg;   // row-major dz for the weight-gradient GEMMs
         // fragment-ordered copy for step t-1: packed column 16*(u/4) + 4*gate + u%4 -> group u/4, slot q = gate
         float* fp = a.dzF_cur + (((size_t)blockIdx.y * (G4 >> 4) + (eu >> 2)) * 64 + erow) * 4 + (eu & 3);
         fp[0] = di; fp[64] = dj; fp[128] = df; fp[192] = dg;
-        a.dc[hi] = dc * sf;
+        a.dc[hi] = cg.dc_out;
     }
     FSMG_STAMP(4);
+}
+
+// ---------------------------------------------------------------- backward, persistent over a range of time steps
+// Block = 16 hidden units x one 16-row tile, 8 waves split K = 4Hp; the wave's slice of Kh (GPW float4 per lane)
+// stays in registers, dc stays in a register, and dz_t travels between the Hp/16 blocks of a row tile exactly like
+// h_t does in k_lstm_fwd_chain (one buffer per time step, pre-filled with the "not written" pattern).  The four
+// gates of four units form one 16-byte fragment word, so the four lanes holding those units exchange their gate
+// gradients with shuffles and each stores one float4.
+template <int GPW>
+__global__ __launch_bounds__(512, 2) void k_lstm_bwd_chain(const LstmBwdChainArgs a) {
+    __shared__ float red[8][16][17];
+    __shared__ int s_fail;
+    FSMG_STEP_PRIO;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int ug = blockIdx.x, rt = blockIdx.y;
+    const int u0 = ug * 16, m0 = rt * 16;
+    const int Hp = a.Hp, G4 = 4 * a.Hp, B = a.B;
+    const int ngroups = G4 >> 4;
+    const size_t dz_step = (size_t)gridDim.y * 16 * G4;          // floats per time index of dzF_all
+    if (tid == 0) s_fail = 0;
+
+    f32x4 bw[GPW];
+    {
+        const f32x4* bf = reinterpret_cast<const f32x4*>(a.KhF) + ((size_t)ug * ngroups + wave * GPW) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < GPW; ++j) bw[j] = bf[j * 64];
+    }
+    // epilogue mapping (waves 0-3): thread -> (row, unit)
+    const int erow = tid >> 4, eun = tid & 15;
+    const int eb = m0 + erow, eu = u0 + eun;
+    const bool epi = tid < 256;
+    const bool eact = epi && (eb < B);
+    const long long hi = (long long)eb * Hp + eu;
+    float dcv = eact ? a.dc[hi] : 0.0f;
+    __syncthreads();
+
+    for (int t = a.t1 - 1; t >= a.t0; --t) {
+        // everything the cell gradient needs besides dh_rec was produced by earlier launches: requested before the wait
+        float si = 0.f, tj = 0.f, sf = 0.f, so = 0.f, ct = 0.f, cp = 0.f, dht = 0.f;
+        float* gp = a.Z + ((size_t)t * B + eb) * G4 + 16 * (eu >> 2) + (eu & 3);
+        if (eact) {
+            si = gp[0]; tj = gp[4]; sf = gp[8]; so = gp[12];
+            ct = a.Cs[(size_t)(t + 1) * B * Hp + hi]; cp = a.Cs[(size_t)t * B * Hp + hi];
+            dht = a.dH[(size_t)t * B * Hp + hi];
+        }
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < a.T) {
+            f32x4 av[GPW];
+            const f32x4* af = reinterpret_cast<const f32x4*>(a.dzF_all + (size_t)(t + 1) * dz_step) + ((size_t)rt * ngroups + wave * GPW) * 64 + lane;
+            bool fail = false;
+            for (int spins = 0;; ++spins) {
+                av[0] = load_sc1(af);
+                drain_vmem();
+                asm volatile("" : "+v"(av[0]));
+                if (__all(frag_ready(av[0]))) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+            }
+            if (GPW > 1 && !fail) {
+                for (int spins = 0;; ++spins) {
+#pragma unroll
+                    for (int j = 1; j < GPW; ++j) av[j] = load_sc1(af + j * 64);
+                    drain_vmem();
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 1; j < GPW; ++j) { asm volatile("" : "+v"(av[j])); ok &= frag_ready(av[j]); }
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+                }
+            }
+            if (fail && lane == 0) {
+                __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_fail = 1;
+            }
+#pragma unroll
+            for (int j = 0; j < GPW; ++j) {
+                f32x4& acc = (j & 1) ? acc1 : acc0;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][0], bw[j][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][1], bw[j][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][2], bw[j][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][3], bw[j][3], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][4 * q + r][l15] = acc0[r] + acc1[r];
+        __syncthreads();
+        if (s_fail) return;
+
+        if (epi) {
+            float di = 0.f, dj = 0.f, df = 0.f, dg = 0.f;
+            if (eact) {
+                float dh_rec = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) dh_rec += red[w][erow][eun];
+                const CellGrad cg = cell_backward(si, tj, sf, so, ct, cp, dcv, dht + dh_rec);
+                di = cg.di; dj = cg.dj; df = cg.df; dg = cg.dg;
+                gp[0] = di; gp[4] = dj; gp[8] = df; gp[12] = dg;   // row-major dz for the weight-gradient GEMMs
+                dcv = cg.dc_out;
+            }
+            // fragment word (group eu/4, lane 16*gate + row) = that gate of units 4*(eu/4) .. +3: lane k of the four
+            // lanes that hold those units collects gate k of all four and stores it
+            const int base = lane & ~3, k = lane & 3;
+            f32x4 w4;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float xi = __shfl(di, base + m), xj = __shfl(dj, base + m), xf = __shfl(df, base + m), xg = __shfl(dg, base + m);
+                w4[m] = (k == 0) ? xi : (k == 1) ? xj : (k == 2) ? xf : xg;
+            }
+            f32x4* dst = reinterpret_cast<f32x4*>(a.dzF_all + (size_t)t * dz_step) + ((size_t)rt * ngroups + (eu >> 2)) * 64 + 16 * k + erow;
+            store_sc1(dst, w4);
+        }
+    }
+    if (eact) a.dc[hi] = dcv;
 }
 
 // Kh [Hp][4Hp] (packed gate columns) -> the two fragment-ordered copies the step kernels stream:
@@ -566,6 +691,28 @@ hipError_t launch_lstm_fwd_chain(hipStream_t s, const LstmFwdChainArgs& a) {
         case 4: hipLaunchKernelGGL((k_lstm_fwd_chain<4>), grid, dim3(256), 0, s, a); break;
         case 8: hipLaunchKernelGGL((k_lstm_fwd_chain<8>), grid, dim3(256), 0, s, a); break;
         case 16: hipLaunchKernelGGL((k_lstm_fwd_chain<16>), grid, dim3(256), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+bool lstm_bwd_chain_supported(int B, int Hp) {
+    const int ngroups = (4 * Hp) >> 4;
+    if ((Hp & 15) || (ngroups & 7)) return false;
+    const int gpw = ngroups >> 3;
+    if (gpw != 2 && gpw != 4 && gpw != 8 && gpw != 16) return false;
+    const long long blocks = (long long)(Hp / 16) * ((B + 15) / 16);
+    return blocks <= (long long)256 * 3 / 4;                   // one 512-thread block per CU, with a margin
+}
+
+hipError_t launch_lstm_bwd_chain(hipStream_t s, const LstmBwdChainArgs& a) {
+    if (a.t1 <= a.t0) return hipSuccess;
+    dim3 grid(a.Hp / 16, (a.B + 15) / 16);
+    switch (((4 * a.Hp) >> 4) >> 3) {
+        case 2: hipLaunchKernelGGL((k_lstm_bwd_chain<2>), grid, dim3(512), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_lstm_bwd_chain<4>), grid, dim3(512), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_lstm_bwd_chain<8>), grid, dim3(512), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_lstm_bwd_chain<16>), grid, dim3(512), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -229,6 +229,32 @@ def test_persistent_forward_chain_is_bit_identical(monkeypatch):
             np.testing.assert_array_equal(out[0][1][k], other[1][k])
 
 
+def test_persistent_kernel_timeout_falls_back_and_repeats_the_step(monkeypatch):
+    """FSMG_CHAIN_SPIN_LIMIT=0 makes every persistent kernel give up at its first wait (what happens when another
+    workload keeps its blocks from becoming co-resident): the update is skipped on the device, the handle falls back to
+    one launch per time step and fsmg_train_step repeats the step -- same numbers as a handle that never tried."""
+    cfg = small_config(hidden_size=64, embedding_size=16, input_size=80, max_len=10)
+    eps = O.synthetic_episodes(3, 3, 2, 2, cfg['max_len'], cfg['input_size'], seed=13)
+    monkeypatch.setenv('FSMG_PERSISTENT', '0')
+    ref = new_model(cfg)
+    want = [ref.train_step(s, q) for s, q in eps]
+    monkeypatch.setenv('FSMG_PERSISTENT', '1')
+    monkeypatch.setenv('FSMG_CHAIN_SPIN_LIMIT', '0')
+    model = new_model(cfg)
+    got = [model.train_step(s, q) for s, q in eps]
+    assert got == want and model.step == 3
+    for k, v in ref.get_params().items():
+        np.testing.assert_array_equal(model.get_param(k), v)
+    # the split entry points report the failure instead of repeating (the caller owns the gradient exchange)
+    model2 = new_model(cfg)
+    model2.forward_backward(*eps[0])
+    with pytest.raises(Exception, match='persistent recurrent kernel timed out'):
+        model2.apply_update(1.0)
+    assert model2.step == 0
+    model2.forward_backward(*eps[0])
+    assert model2.apply_update(1.0) == want[0]
+
+
 def test_split_k_paths_match_oracle_at_wide_shapes():
     """rows = 45*40 = 1800 with H=128: the dK / dH / dW GEMMs take the split-K + slab-reduce path."""
     cfg = small_config(hidden_size=128, embedding_size=64, input_size=1500, max_len=40)
