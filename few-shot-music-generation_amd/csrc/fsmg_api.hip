@@ -78,7 +78,10 @@ struct fsmg_model {
     int partials_cap = 0;
     std::vector<float*> HF;             // fragment-ordered h per layer: [T+1][ceil(B/16)*16][Hp]
     float* dzF = nullptr;               // fragment-ordered dz ping-pong: [2][ceil(B/16)*16][4Hp]
-    float* dzF_all = nullptr;           // persistent backward chain: fragment-ordered dz of every time step [T][ceil(B/16)*16][4Hp]
+    float* dzF_all = nullptr;           // persistent backward chain, all-gather form (FSMG_BWD_RS=0): fragment-ordered dz of every time step
+    float* inbox = nullptr;             // persistent backward chain, reduce-scatter form: dh partial tiles [2][row tiles][P][P][64][4]
+    int64_t inbox_floats = 0;
+    bool bwd_rs = true;                 // FSMG_BWD_RS=0 selects the all-gather form
     int chain_spin_limit = 1 << 18;     // FSMG_CHAIN_SPIN_LIMIT (0 forces the timeout + fallback path: tests)
     bool persist_timed_out = false;     // set when a persistent kernel gave up (the handle has switched to per-step launches)
     bool persist = true;                // FSMG_PERSISTENT=0: one launch per time step instead of one persistent launch per chain chunk
@@ -333,8 +336,11 @@ int ensure_scratch(fsmg_model* h, int B) {
     std::vector<int64_t> o_hf(h->L);
     for (int l = 0; l < h->L; ++l) o_hf[l] = place(4 * (T + 1) * Bp16 * Hp);
     const int64_t o_dzf = place(4 * 2 * Bp16 * G4);
-    const bool want_dzfa = h->persist && lstm_bwd_chain_supported(B, (int)Hp);
+    const bool want_inbox = h->persist && h->bwd_rs && lstm_bwd_rs_supported(B, (int)Hp);
+    const bool want_dzfa = h->persist && !want_inbox && lstm_bwd_chain_supported(B, (int)Hp);
     const int64_t o_dzfa = place(want_dzfa ? 4 * T * Bp16 * G4 : 256);
+    const int64_t n_inbox = want_inbox ? lstm_bwd_rs_inbox_floats(B, (int)Hp) : 0;
+    const int64_t o_inbox = place(want_inbox ? 4 * n_inbox : 256);
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
     const int64_t o_lg = place(4 * rows * h->V1p), o_dlg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
     const int64_t o_dx = place(4 * rows * h->Ep);
@@ -385,6 +391,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     for (int l = 0; l < h->L; ++l) h->HF[l] = (float*)(s + o_hf[l]);
     h->dzF = (float*)(s + o_dzf);
     h->dzF_all = want_dzfa ? (float*)(s + o_dzfa) : nullptr;
+    h->inbox = want_inbox ? (float*)(s + o_inbox) : nullptr; h->inbox_floats = n_inbox;
     // pad rows of the fragment buffers are never written: clear once so they hold finite values
     HIPCK(h, hipMemsetAsync(s + o_hf[0], 0, (size_t)(o_dc - o_hf[0]), h->stream));
     h->dC = (float*)(s + o_dc); h->dH = (float*)(s + o_dh); h->logits = (float*)(s + o_lg);
@@ -649,7 +656,8 @@ int backward(fsmg_model* h, int B) {
     const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
-    const bool chain = h->persist && h->dzF_all != nullptr && lstm_bwd_chain_supported(B, Hp);
+    const bool rs = h->persist && h->inbox != nullptr && lstm_bwd_rs_supported(B, Hp) && lstm_bwd_rs_inbox_floats(B, Hp) <= h->inbox_floats;
+    const bool chain = rs || (h->persist && h->dzF_all != nullptr && lstm_bwd_chain_supported(B, Hp));
     const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
     const Lane auxl = aux_lane(h, false, chain);
     PHASE(3);
@@ -675,7 +683,9 @@ int backward(fsmg_model* h, int B) {
         HIPCK(h, hipMemsetAsync(h->dC, 0, sizeof(float) * (size_t)B * Hp, s));
         if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[nch - 1], 0));
         PHASE(4);
-        if (chain) {     // "not written yet" fill pattern of the dz fragments of every time step
+        if (rs) {        // "not written yet" fill pattern of the dh partial inboxes
+            HIPCK(h, hipMemsetAsync(h->inbox, 0xFF, sizeof(float) * (size_t)lstm_bwd_rs_inbox_floats(B, Hp), s));
+        } else if (chain) {     // ... or of the dz fragments of every time step
             const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
             HIPCK(h, hipMemsetAsync(h->dzF_all, 0xFF, sizeof(float) * (size_t)T * Bp16 * G4, s));
         }
@@ -683,6 +693,13 @@ int backward(fsmg_model* h, int B) {
             const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
             if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[c], 0));
             ScopedTimer tm(h, "lstm_bwd");
+            if (rs) {
+                LstmBwdRsArgs a{};
+                a.KhF = h->khf + (size_t)(2 * l + 1) * Hp * G4; a.inbox = h->inbox; a.Z = h->Z[l]; a.Cs = h->Cs[l];
+                a.dc = h->dC; a.dH = h->dH; a.err_flag = h->d_err; a.B = B; a.Hp = Hp; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
+                HIPCK(h, launch_lstm_bwd_rs(s, a));
+                continue;
+            }
             if (chain) {
                 LstmBwdChainArgs a{};
                 a.KhF = h->khf + (size_t)(2 * l + 1) * Hp * G4; a.dzF_all = h->dzF_all; a.Z = h->Z[l]; a.Cs = h->Cs[l];
@@ -859,6 +876,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         const char* env = std::getenv("FSMG_OVERLAP");
         h->overlap = env ? (env[0] != '0') : ((int64_t)h->V1 >= 8LL * h->H * h->L);
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_BWD_RS")) h->bwd_rs = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_CHAIN_SPIN_LIMIT")) h->chain_spin_limit = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("FSMG_NCHUNK")) h->nchunk = h->nchunk_persist = std::max(1, std::min((int)fsmg_model::NCHUNK, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) { h->aux_blocks_per_cu = h->aux_blocks_persist = std::max(1, std::min(4, std::atoi(e))); h->aux_blocks_from_env = true; }

@@ -102,6 +102,27 @@ struct LstmBwdChainArgs {
 };
 bool lstm_bwd_chain_supported(int B, int Hp);
 hipError_t launch_lstm_bwd_chain(hipStream_t s, const LstmBwdChainArgs& a);
+
+// Reduce-scatter form of the persistent backward steps.  Block j of a row tile owns 16 hidden units = 64 packed gate
+// columns and keeps dz_t for those columns to itself; what travels is dh: after step t+1 it multiplies its dz slice
+// with its COLUMN slice of Kh (all Hp units x 64 columns, resident in registers) and sends every block i the 16x16
+// partial of dh_t that belongs to i's units (1 KiB), so a block receives Hp/16 KiB per step instead of the
+// 16 x 4Hp x 4 B of dz the all-gather form reads.  inbox: [2 slots][row tiles][consumer][producer][64 lanes][4],
+// every word 0xFFFFFFFF before the first launch of a pass (readers put the pattern back after reading).
+struct LstmBwdRsArgs {
+    const float* KhF;      // backward fragment-ordered recurrent weights of the layer
+    float* inbox;
+    float* Z;              // [T][B][4Hp] in: activated gates; out: dz (row-major, for the weight-gradient GEMMs)
+    const float* Cs;       // [T+1][B][Hp]
+    float* dc;             // [B][Hp] carried cell gradient: read at t1-1, written back after t0
+    const float* dH;       // [T][B][Hp] gradient arriving from above
+    int* err_flag;
+    int B, Hp, T, t0, t1;
+    int spin_limit;
+};
+bool lstm_bwd_rs_supported(int B, int Hp);
+long long lstm_bwd_rs_inbox_floats(int B, int Hp);
+hipError_t launch_lstm_bwd_rs(hipStream_t s, const LstmBwdRsArgs& a);
 // recurrent weights [Hp][4Hp] -> the forward and backward fragment-ordered copies (Hp*4Hp floats each)
 hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp);
 

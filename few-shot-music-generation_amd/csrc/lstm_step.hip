@@ -172,8 +172,11 @@ __device__ __forceinline__ f32x4 load_sc1(const f32x4* p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
+// The trailing s_nop covers the VMEM-store-data hazard (a VALU write to the data VGPRs of a store wider than 8 bytes
+// needs a wait state after it): hipcc inserts that for its own stores, not behind inline asm -- and it did reuse the
+// first two data registers as the next store's address (k_lstm_bwd_rs<8>: garbage in one tile per wave).
 __device__ __forceinline__ void store_sc1(f32x4* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -451,6 +454,40 @@ __device__ __forceinline__ void bwd_chunk(const float4* __restrict__ af, const f
     }
 }
 
+// Producer-major accumulation: every quadruple of k-groups (= the 64 packed gate columns of 16 hidden units, what one
+// block of the reduce-scatter kernel k_lstm_bwd_rs contributes) gets its own accumulator chain, and the chains are
+// added in order -- the summation order of that kernel, so the two agree to the bit.  N groups, N % 4 == 0.
+template <int N>
+__device__ __forceinline__ void bwd_chunk_quads(const float4* __restrict__ af, const float4* __restrict__ bf, int g0,
+                                                f32x4& wsum, bool& first) {
+    float4 av[N], bv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        av[j] = af[(g0 + j) * 64];
+        bv[j] = bf[(g0 + j) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[N / 4];
+#pragma unroll
+    for (int p = 0; p < N / 4; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)                 // interleave the N/4 independent chains
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int p = 0; p < N / 4; ++p) {
+                const float4 x = av[4 * p + jj], y = bv[4 * p + jj];
+                const float xa = e == 0 ? x.x : e == 1 ? x.y : e == 2 ? x.z : x.w;
+                const float ya = e == 0 ? y.x : e == 1 ? y.y : e == 2 ? y.z : y.w;
+                acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, ya, acc[p], 0, 0, 0);
+            }
+#pragma unroll
+    for (int p = 0; p < N / 4; ++p) {
+        wsum = first ? acc[p] : wsum + acc[p];
+        first = false;
+    }
+}
+
 template <bool PROF, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void k_lstm_bwd_step(const LstmBwdArgs a, unsigned long long* prof) {
     __shared__ float red[NW][16][17];
@@ -480,10 +517,16 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_lstm_bwd_step(const LstmBwd
         const float4* af = reinterpret_cast<const float4*>(a.dzF_next) + ((size_t)blockIdx.y * ngroups) * 64 + lane;
         const float4* bf = reinterpret_cast<const float4*>(a.KhF) + ((size_t)blockIdx.x * ngroups) * 64 + lane;
         int g = g_beg;
-        while (g + 8 <= g_end) { bwd_chunk<8>(af, bf, g, acc0, acc1); g += 8; }
-        if (g + 4 <= g_end) { bwd_chunk<4>(af, bf, g, acc0, acc1); g += 4; }
-        if (g + 2 <= g_end) { bwd_chunk<2>(af, bf, g, acc0, acc1); g += 2; }
-        if (g < g_end) bwd_chunk<1>(af, bf, g, acc0, acc1);
+        if (ngroups % (4 * NW) == 0) {       // whole quadruples per wave (Hp % 128 == 0): producer-major order
+            bool first = true;
+            while (g + 8 <= g_end) { bwd_chunk_quads<8>(af, bf, g, acc0, first); g += 8; }
+            if (g + 4 <= g_end) { bwd_chunk_quads<4>(af, bf, g, acc0, first); g += 4; }
+        } else {
+            while (g + 8 <= g_end) { bwd_chunk<8>(af, bf, g, acc0, acc1); g += 8; }
+            if (g + 4 <= g_end) { bwd_chunk<4>(af, bf, g, acc0, acc1); g += 4; }
+            if (g + 2 <= g_end) { bwd_chunk<2>(af, bf, g, acc0, acc1); g += 2; }
+            if (g < g_end) bwd_chunk<1>(af, bf, g, acc0, acc1);
+        }
     }
     if (PROF) { __builtin_amdgcn_s_waitcnt(0); FSMG_STAMP(1); }
 #pragma unroll
@@ -622,6 +665,139 @@ __global__ __launch_bounds__(512, 2) void k_lstm_bwd_chain(const LstmBwdChainArg
     if (eact) a.dc[hi] = dcv;
 }
 
+// ---------------------------------------------------------------- backward, persistent, reduce-scatter form
+// See LstmBwdRsArgs.  Iteration t (descending) of block j = blockIdx.x, P = Hp/16 blocks per row tile, 8 waves:
+//   A  consume: thread (wave w, lane) polls the partials of producers w*TPW .. w*TPW+TPW-1 for its own units (one
+//      float4 = 4 rows of one unit column in MFMA C/D layout), puts the fill pattern back (the slot is reused two
+//      steps later), adds them in producer order and leaves the wave's sum in LDS;
+//   B  waves 0-3: dh_rec = sum over waves (in order) -> gate gradients of (row, unit) -> row-major dz for the GEMMs
+//      and the block's own 16 x 64 dz slice in MFMA A-fragment order in LDS;
+//   C  produce: wave w multiplies that slice with its TPW resident 64 x 16 weight tiles (one accumulator chain of
+//      16 MFMAs per destination block) and stores the C/D registers straight into the destinations' inboxes with
+//      16-byte write-through stores.  The resets of phase A are drained before the first of these stores, which is
+//      what makes two slots enough: nobody can overwrite a slot before every reader of its previous content has put
+//      the fill pattern back, because progress of any block depends on these stores.
+// Summation order (producer-major, then wave-major) is the one k_lstm_bwd_step uses when Hp is a multiple of 128, so
+// the two paths agree to the bit.
+template <int TPW>
+__global__ __launch_bounds__(512, 2) void k_lstm_bwd_rs(const LstmBwdRsArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[8][64][4];
+    __shared__ __attribute__((aligned(16))) float frag[4][64][4];
+    __shared__ int s_fail;
+    FSMG_STEP_PRIO;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = blockIdx.x, rt = blockIdx.y, P = gridDim.x;
+    const int u0 = j * 16, m0 = rt * 16;
+    const int Hp = a.Hp, G4 = 4 * a.Hp, B = a.B;
+    const int ngroups = G4 >> 4;
+    if (tid == 0) s_fail = 0;
+
+    // resident weights: for each of this wave's destination blocks i, the 4 k-groups of this block's 64 columns
+    f32x4 bw[TPW][4];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bw[ti][g] = reinterpret_cast<const f32x4*>(a.KhF)[((size_t)(wave * TPW + ti) * ngroups + 4 * j + g) * 64 + lane];
+
+    const size_t slot_f = (size_t)gridDim.y * P * P * 256;                       // floats per slot
+    float* const inbox_rt = a.inbox + (size_t)rt * P * P * 256;
+    // epilogue mapping (waves 0-3): thread -> (row, unit)
+    const int erow = tid >> 4, eun = tid & 15;
+    const int eb = m0 + erow, eu = u0 + eun;
+    const bool epi = tid < 256;
+    const bool eact = epi && (eb < B);
+    const long long hi = (long long)eb * Hp + eu;
+    float dcv = eact ? a.dc[hi] : 0.0f;
+    __syncthreads();
+
+    for (int t = a.t1 - 1; t >= a.t0; --t) {
+        float si = 0.f, tj = 0.f, sf = 0.f, so = 0.f, ct = 0.f, cp = 0.f, dht = 0.f;
+        float* gp = a.Z + ((size_t)t * B + eb) * G4 + 16 * (eu >> 2) + (eu & 3);
+        if (eact) {
+            si = gp[0]; tj = gp[4]; sf = gp[8]; so = gp[12];
+            ct = a.Cs[(size_t)(t + 1) * B * Hp + hi]; cp = a.Cs[(size_t)t * B * Hp + hi];
+            dht = a.dH[(size_t)t * B * Hp + hi];
+        }
+        // ---- A: consume the partials of dh_t
+        f32x4 wsum = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < a.T) {
+            f32x4* in = reinterpret_cast<f32x4*>(inbox_rt + (size_t)((t + 1) & 1) * slot_f) + ((size_t)j * P + wave * TPW) * 64 + lane;
+            f32x4 v[TPW];
+            bool fail = false;
+            for (int spins = 0;; ++spins) {
+#pragma unroll
+                for (int k = 0; k < TPW; ++k) v[k] = load_sc1(in + k * 64);
+                drain_vmem();
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < TPW; ++k) { asm volatile("" : "+v"(v[k])); ok &= frag_ready(v[k]); }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+            }
+            if (fail && lane == 0) {
+                __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_fail = 1;
+            }
+            const f32x4 fill = f32x4{__uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu)};
+#pragma unroll
+            for (int k = 0; k < TPW; ++k) {
+                store_sc1(in + k * 64, fill);
+                wsum = (k == 0) ? v[0] : wsum + v[k];
+            }
+        }
+        *reinterpret_cast<f32x4*>(&red[wave][lane][0]) = wsum;
+        __syncthreads();
+        if (s_fail) return;
+
+        // ---- B: gate gradients; the block's dz slice goes to LDS in A-fragment order
+        if (epi) {
+            float di = 0.f, dj = 0.f, df = 0.f, dg = 0.f;
+            if (eact) {
+                float dh_rec = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) dh_rec += red[w][eun + 16 * (erow >> 2)][erow & 3];
+                const CellGrad cg = cell_backward(si, tj, sf, so, ct, cp, dcv, dht + dh_rec);
+                di = cg.di; dj = cg.dj; df = cg.df; dg = cg.dg;
+                gp[0] = di; gp[4] = dj; gp[8] = df; gp[12] = dg;   // row-major dz for the weight-gradient GEMMs
+                dcv = cg.dc_out;
+            }
+            // fragment [group eun/4][lane = 16*gate + row][eun%4]
+            float* f = &frag[eun >> 2][erow][eun & 3];
+            f[0] = di; f[16 * 4] = dj; f[32 * 4] = df; f[48 * 4] = dg;
+        }
+        __syncthreads();
+
+        // ---- C: partials of dh_{t-1} for every block of the row tile
+        if (t > 0) {
+            f32x4 af[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) af[g] = *reinterpret_cast<const f32x4*>(&frag[g][lane][0]);
+            f32x4 acc[TPW];
+#pragma unroll
+            for (int ti = 0; ti < TPW; ++ti) acc[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ti = 0; ti < TPW; ++ti)
+                        acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][e], bw[ti][g][e], acc[ti], 0, 0, 0);
+            // the stores below are inline asm: hipcc does not know that they read the MFMA results, so the wait states
+            // between an XDL write and a VMEM read of the same VGPRs (up to 19 for these MFMAs) are inserted by hand --
+            // without them the stores picked up stale accumulator registers now and then (gradients off by ~1e-3)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+            drain_vmem();                                             // the resets of phase A have landed
+            f32x4* out = reinterpret_cast<f32x4*>(inbox_rt + (size_t)(t & 1) * slot_f) + (size_t)j * 64 + lane;
+#pragma unroll
+            for (int ti = 0; ti < TPW; ++ti) store_sc1(out + (size_t)(wave * TPW + ti) * P * 64, acc[ti]);
+        }
+    }
+    if (eact) a.dc[hi] = dcv;
+}
+
 // Kh [Hp][4Hp] (packed gate columns) -> the two fragment-ordered copies the step kernels stream:
 //   fwd: B[k][n = packed col], block nb = 16 cols:  KhF_fwd[nb][g][lane=16q+n][s] = Kh[16g+4q+s][16nb+n]
 //   bwd: B[k = packed col][n = unit], block ug:      KhF_bwd[ug][g][lane=16q+n][s] = Kh[16ug+n][16g+4q+s]
@@ -713,6 +889,29 @@ hipError_t launch_lstm_bwd_chain(hipStream_t s, const LstmBwdChainArgs& a) {
         case 4: hipLaunchKernelGGL((k_lstm_bwd_chain<4>), grid, dim3(512), 0, s, a); break;
         case 8: hipLaunchKernelGGL((k_lstm_bwd_chain<8>), grid, dim3(512), 0, s, a); break;
         case 16: hipLaunchKernelGGL((k_lstm_bwd_chain<16>), grid, dim3(512), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+bool lstm_bwd_rs_supported(int B, int Hp) {
+    if (Hp % 128) return false;
+    const int tpw = Hp / 128;
+    if (tpw != 1 && tpw != 2 && tpw != 4 && tpw != 8) return false;
+    return (long long)(Hp / 16) * ((B + 15) / 16) <= (long long)256 * 3 / 4;   // one 512-thread block per CU, with a margin
+}
+long long lstm_bwd_rs_inbox_floats(int B, int Hp) {
+    const long long P = Hp / 16;
+    return 2LL * ((B + 15) / 16) * P * P * 256;
+}
+hipError_t launch_lstm_bwd_rs(hipStream_t s, const LstmBwdRsArgs& a) {
+    if (a.t1 <= a.t0) return hipSuccess;
+    dim3 grid(a.Hp / 16, (a.B + 15) / 16);
+    switch (a.Hp / 128) {
+        case 1: hipLaunchKernelGGL((k_lstm_bwd_rs<1>), grid, dim3(512), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_lstm_bwd_rs<2>), grid, dim3(512), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_lstm_bwd_rs<4>), grid, dim3(512), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_lstm_bwd_rs<8>), grid, dim3(512), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
