@@ -94,8 +94,8 @@ struct fsmg_model {
     hipStream_t aux = nullptr;          // low-priority stream for the projection GEMMs that overlap the recurrence
     static constexpr int NCHUNK = 16;   // max time chunks of the overlap schedule
     int nchunk = 8;                     // chunks in use with one launch per step (FSMG_NCHUNK)
-    int nchunk_persist = 2;             // ... and with the persistent step kernels (swept at cfg-B: 2 chunks x 3 blocks/CU)
-    int aux_blocks_persist = 3;
+    int nchunk_persist = 4;             // ... and with the persistent step kernels (swept at cfg-B: 3-4 chunks x 2 blocks/CU)
+    int aux_blocks_persist = 2;
     bool aux_blocks_from_env = false;
     int aux_blocks_per_cu = 2;          // occupancy cap of the overlapped GEMMs (FSMG_AUX_BLOCKS); swept: 8 x 2 is best at cfg-B
     hipEvent_t ev_chunk[NCHUNK] = {};   // main -> aux (forward) / aux -> main (backward): chunk ready

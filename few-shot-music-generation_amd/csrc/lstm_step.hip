@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
         if (s_fail) return;                                          // block-uniform: a wave of this block timed out
 
         if (tid < 64) {
-            float hn = 0.0f;
+            float hn = 0.0f, g_si = 0.f, g_tj = 0.f, g_sf = 0.f, g_so = 0.f;
             if (eact) {
                 float zg[4];
 #pragma unroll
@@ -287,9 +287,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
                 const float cn = cp * sf + si * tj;
                 hn = tanhf_(cn) * so;
                 cp = cn;
-                a.Cs[((size_t)(t + 1) * B + eb) * Hp + eu] = cn;
-                a.Hs[((size_t)(t + 1) * B + eb) * Hp + eu] = hn;
-                zp[0] = si; zp[4] = tj; zp[8] = sf; zp[12] = so;  // activated gates kept for BPTT
+                g_si = si; g_tj = tj; g_sf = sf; g_so = so;
             }
             // fragment-ordered h_{t+1}: the 4 units of a row are one float4 (group eu/16, lane slot 4*(eu&12) + row);
             // pad rows publish zeros, so every word of the buffer is written and the readers' test terminates
@@ -301,6 +299,11 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
                 f32x4* dst = reinterpret_cast<f32x4*>(a.HF + (size_t)(t + 1) * hf_step) +
                              ((size_t)rt * ngroups + (u0 >> 4)) * 64 + 4 * (u0 & 12) + erow;
                 store_sc1(dst, hv);
+            }
+            if (eact) {      // the outputs nobody waits for go out behind the hand-off
+                a.Cs[((size_t)(t + 1) * B + eb) * Hp + eu] = cp;
+                a.Hs[((size_t)(t + 1) * B + eb) * Hp + eu] = hn;
+                zp[0] = g_si; zp[4] = g_tj; zp[8] = g_sf; zp[12] = g_so;  // activated gates kept for BPTT
             }
         }
         // the other waves may run ahead into step t+1: they cannot pass its poll before wave 0 has published, which
