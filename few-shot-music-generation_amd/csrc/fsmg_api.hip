@@ -79,6 +79,7 @@ struct fsmg_model {
     std::vector<float*> HF;             // fragment-ordered h per layer: [T+1][ceil(B/16)*16][Hp]
     float* dzF = nullptr;               // fragment-ordered dz ping-pong: [2][ceil(B/16)*16][4Hp]
     float* dzF_all = nullptr;           // persistent backward chain, all-gather form (FSMG_BWD_RS=0): fragment-ordered dz of every time step
+    int64_t dzfa_floats = 0;
     float* inbox = nullptr;             // persistent backward chain, reduce-scatter form: dh partial tiles [2][row tiles][P][P][64][4]
     int64_t inbox_floats = 0;
     bool bwd_rs = true;                 // FSMG_BWD_RS=0 selects the all-gather form
@@ -336,10 +337,18 @@ int ensure_scratch(fsmg_model* h, int B) {
     std::vector<int64_t> o_hf(h->L);
     for (int l = 0; l < h->L; ++l) o_hf[l] = place(4 * (T + 1) * Bp16 * Hp);
     const int64_t o_dzf = place(4 * 2 * Bp16 * G4);
-    const bool want_inbox = h->persist && h->bwd_rs && lstm_bwd_rs_supported(B, (int)Hp);
-    const bool want_dzfa = h->persist && !want_inbox && lstm_bwd_chain_supported(B, (int)Hp);
-    const int64_t o_dzfa = place(want_dzfa ? 4 * T * Bp16 * G4 : 256);
-    const int64_t n_inbox = want_inbox ? lstm_bwd_rs_inbox_floats(B, (int)Hp) : 0;
+    // hand-off buffers of the persistent BPTT kernels, sized for the LARGEST row count they take at this Hp (not for
+    // B: a validation batch grows the scratch far beyond that, and training steps must keep their fast path)
+    int rows_rs = 0, rows_ag = 0;
+    for (int r = 16; r <= (int)Bp16; r += 16) {
+        if (lstm_bwd_rs_supported(r, (int)Hp)) rows_rs = r;
+        if (lstm_bwd_chain_supported(r, (int)Hp)) rows_ag = r;
+    }
+    const bool want_inbox = h->persist && h->bwd_rs && rows_rs > 0;
+    const bool want_dzfa = h->persist && !want_inbox && rows_ag > 0;
+    const int64_t n_dzfa = want_dzfa ? T * (int64_t)rows_ag * G4 : 0;
+    const int64_t o_dzfa = place(want_dzfa ? 4 * n_dzfa : 256);
+    const int64_t n_inbox = want_inbox ? lstm_bwd_rs_inbox_floats(rows_rs, (int)Hp) : 0;
     const int64_t o_inbox = place(want_inbox ? 4 * n_inbox : 256);
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
     const int64_t o_lg = place(4 * rows * h->V1p), o_dlg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
@@ -390,7 +399,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     h->HF.assign(h->L, nullptr);
     for (int l = 0; l < h->L; ++l) h->HF[l] = (float*)(s + o_hf[l]);
     h->dzF = (float*)(s + o_dzf);
-    h->dzF_all = want_dzfa ? (float*)(s + o_dzfa) : nullptr;
+    h->dzF_all = want_dzfa ? (float*)(s + o_dzfa) : nullptr; h->dzfa_floats = n_dzfa;
     h->inbox = want_inbox ? (float*)(s + o_inbox) : nullptr; h->inbox_floats = n_inbox;
     // pad rows of the fragment buffers are never written: clear once so they hold finite values
     HIPCK(h, hipMemsetAsync(s + o_hf[0], 0, (size_t)(o_dc - o_hf[0]), h->stream));
@@ -657,7 +666,8 @@ int backward(fsmg_model* h, int B) {
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
     const bool rs = h->persist && h->inbox != nullptr && lstm_bwd_rs_supported(B, Hp) && lstm_bwd_rs_inbox_floats(B, Hp) <= h->inbox_floats;
-    const bool chain = rs || (h->persist && h->dzF_all != nullptr && lstm_bwd_chain_supported(B, Hp));
+    const bool chain = rs || (h->persist && h->dzF_all != nullptr && lstm_bwd_chain_supported(B, Hp) &&
+                              (int64_t)T * ((B + 15) / 16 * 16) * G4 <= h->dzfa_floats);
     const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
     const Lane auxl = aux_lane(h, false, chain);
     PHASE(3);

@@ -258,6 +258,27 @@ def test_persistent_kernel_timeout_falls_back_and_repeats_the_step(monkeypatch):
     assert model2.apply_update(1.0) == want[0]
 
 
+def test_training_keeps_the_persistent_path_after_a_large_validation_batch():
+    """A validation batch grows the activation scratch to hundreds of rows; the hand-off buffers of the persistent BPTT
+    kernel must survive that (they are sized per hidden size, not per batch) -- observable through the forced-timeout
+    knob: only a persistent launch can time out."""
+    cfg = small_config(hidden_size=128, embedding_size=16, input_size=60, max_len=6)
+    eps = O.synthetic_episodes(2, 3, 2, 2, cfg['max_len'], cfg['input_size'], seed=14)
+    model = new_model(cfg)
+    big = np.stack([q for _, q in O.synthetic_episodes(16, 10, 1, 4, cfg['max_len'], cfg['input_size'], seed=15)])   # 640 rows
+    model.eval_batch(big)
+    os.environ['FSMG_CHAIN_SPIN_LIMIT'] = '0'          # read at create time: does not touch `model`
+    try:
+        probe = new_model(cfg)
+        probe.eval_batch(big)
+        probe.forward_backward(*eps[0])
+        with pytest.raises(Exception, match='persistent recurrent kernel timed out'):
+            probe.apply_update(1.0)
+    finally:
+        del os.environ['FSMG_CHAIN_SPIN_LIMIT']
+    assert np.isfinite(model.train_step(*eps[0]))
+
+
 def test_split_k_paths_match_oracle_at_wide_shapes():
     """rows = 45*40 = 1800 with H=128: the dK / dH / dW GEMMs take the split-K + slab-reduce path."""
     cfg = small_config(hidden_size=128, embedding_size=64, input_size=1500, max_len=40)
