@@ -94,6 +94,7 @@ struct fsmg_model {
     float* colsum_slabs2 = nullptr;
     hipStream_t aux = nullptr;          // low-priority stream for the projection GEMMs that overlap the recurrence
     static constexpr int NCHUNK = 16;   // max time chunks of the overlap schedule
+    std::vector<int> chunk_edges;       // explicit chunk boundaries (FSMG_CHUNK_STEPS), empty = uniform
     int nchunk = 8;                     // chunks in use with one launch per step (FSMG_NCHUNK)
     int nchunk_persist = 4;             // ... and with the persistent step kernels (swept at cfg-B: 3-4 chunks x 2 blocks/CU)
     int aux_blocks_persist = 2;
@@ -513,6 +514,11 @@ int token_prep(fsmg_model* h, int n_sup, int n_qry) {
 // so the projection work runs on a low-priority auxiliary stream, forked / joined with events (inside
 // the captured graph these become parallel branches).  Event timing (eager, one class at a time)
 // and FSMG_OVERLAP=0 use the single-stream order.
+// time-chunk boundaries of the overlap schedule: uniform, or the explicit step counts of FSMG_CHUNK_STEPS ("12,36,34,34,12")
+inline int chunk_begin(const fsmg_model* h, int c, int nch) {
+    if (!h->chunk_edges.empty() && (int)h->chunk_edges.size() == nch + 1) return h->chunk_edges[c];
+    return (int)((int64_t)c * h->T / nch);
+}
 inline bool use_overlap(const fsmg_model* h) { return h->overlap && !h->timing && h->aux != nullptr && h->T >= std::max(h->nchunk, h->nchunk_persist); }
 
 #ifdef FSMG_PHASE_DEBUG
@@ -597,7 +603,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
         if (chain)       // "not written yet" fill pattern of the h fragments of time indices 1..T (index 0 is the zero state)
             HIPCK(h, hipMemsetAsync(h->HF[l] + Bp16 * Hp, 0xFF, sizeof(float) * (size_t)T * Bp16 * Hp, s));
         for (int c = 0; c < nch; ++c) {
-            const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
+            const int t0 = chunk_begin(h, c, nch), t1 = chunk_begin(h, c + 1, nch);
             if (chain) {
                 ScopedTimer tm(h, "lstm_fwd");
                 LstmFwdChainArgs a{};
@@ -677,7 +683,7 @@ int backward(fsmg_model* h, int B) {
         HIPCK(h, hipEventRecord(h->ev_fork, s));
         HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
         for (int c = nch - 1; c >= 0; --c) {
-            const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
+            const int t0 = chunk_begin(h, c, nch), t1 = chunk_begin(h, c + 1, nch);
             GEMMCK(dhout_chunk(h, auxl, B, t0, t1));
             HIPCK(h, hipEventRecord(h->ev_chunk[c], h->aux));
         }
@@ -700,7 +706,7 @@ int backward(fsmg_model* h, int B) {
             HIPCK(h, hipMemsetAsync(h->dzF_all, 0xFF, sizeof(float) * (size_t)T * Bp16 * G4, s));
         }
         for (int c = nch - 1; c >= 0; --c) {
-            const int t0 = (int)((int64_t)c * T / nch), t1 = (int)((int64_t)(c + 1) * T / nch);
+            const int t0 = chunk_begin(h, c, nch), t1 = chunk_begin(h, c + 1, nch);
             if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[c], 0));
             ScopedTimer tm(h, "lstm_bwd");
             if (rs) {
@@ -889,6 +895,14 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_BWD_RS")) h->bwd_rs = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_CHAIN_SPIN_LIMIT")) h->chain_spin_limit = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("FSMG_NCHUNK")) h->nchunk = h->nchunk_persist = std::max(1, std::min((int)fsmg_model::NCHUNK, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_CHUNK_STEPS")) {      // e.g. "12,36,34,34,12": must add up to max_len
+            std::vector<int> edges{0};
+            for (const char* p = e; *p;) { edges.push_back(edges.back() + std::max(1, std::atoi(p))); while (*p && *p != ',') ++p; if (*p) ++p; }
+            if (edges.back() == h->T && (int)edges.size() - 1 <= (int)fsmg_model::NCHUNK) {
+                h->chunk_edges = edges;
+                h->nchunk = h->nchunk_persist = (int)edges.size() - 1;
+            }
+        }
         if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) { h->aux_blocks_per_cu = h->aux_blocks_persist = std::max(1, std::min(4, std::atoi(e))); h->aux_blocks_from_env = true; }
         int least = 0, greatest = 0;
         hipDeviceGetStreamPriorityRange(&least, &greatest);
