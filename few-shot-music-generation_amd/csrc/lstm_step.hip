@@ -39,6 +39,10 @@ namespace {
 #define FSMG_STEP_PRIO_LEVEL 3
 #endif
 #define FSMG_STEP_PRIO __builtin_amdgcn_s_setprio(FSMG_STEP_PRIO_LEVEL)
+// s_sleep argument between two polls of a hand-off word (units of 64 clocks)
+#ifndef FSMG_POLL_SLEEP
+#define FSMG_POLL_SLEEP 1
+#endif
 constexpr int FWD_NW = FSMG_FWD_NW;   // waves per forward-step block (split K = Hp)
 constexpr int BWD_NW = FSMG_BWD_NW;   // waves per backward-step block (split K = 4Hp)
 
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
                 drain_vmem();
                 asm volatile("" : "+v"(av[0]));
                 if (__all(frag_ready(av[0]))) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
                 if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
             }
             if (GPW > 1 && !fail) {
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
 #pragma unroll
                     for (int j = 1; j < GPW; ++j) { asm volatile("" : "+v"(av[j])); ok &= frag_ready(av[j]); }
                     if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
                     if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
                 }
             }
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_bwd_chain(const LstmBwdChainArg
                 drain_vmem();
                 asm volatile("" : "+v"(av[0]));
                 if (__all(frag_ready(av[0]))) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
                 if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
             }
             if (GPW > 1 && !fail) {
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_bwd_chain(const LstmBwdChainArg
 #pragma unroll
                     for (int j = 1; j < GPW; ++j) { asm volatile("" : "+v"(av[j])); ok &= frag_ready(av[j]); }
                     if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
                     if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
                 }
             }
@@ -736,7 +740,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_bwd_rs(const LstmBwdRsArgs a) {
 #pragma unroll
                 for (int k = 0; k < TPW; ++k) { asm volatile("" : "+v"(v[k])); ok &= frag_ready(v[k]); }
                 if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
                 if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
             }
             if (fail && lane == 0) {
