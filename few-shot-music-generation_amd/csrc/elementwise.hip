@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
     __shared__ double sh[4];
     __shared__ float s_scale, s_alpha;
     // the gradients of a step whose persistent recurrent kernel timed out are garbage: keep the parameters
-    if (a.err_flag != nullptr && *a.err_flag == 2) return;
+    if ((a.err_flag != nullptr && *a.err_flag == 2) || a.tail[2] != 0.0f) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;
     for (int i = tid; i < a.n_partials; i += 256) s += a.partials[i];
@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
 
 __global__ void k_step_increment(long long* step, const float* loss_src, float loss_scale, float* ring,
                                  int ring_cap, const int* err_flag) {
-    if (err_flag != nullptr && *err_flag == 2) return;
+    // loss_src is tail[1]; tail[2] is the (all-reduced) time-out indicator
+    if ((err_flag != nullptr && *err_flag == 2) || (loss_src != nullptr && loss_src[1] != 0.0f)) return;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const long long s = *step;
         if (ring != nullptr && loss_src != nullptr) ring[s % ring_cap] = *loss_src * loss_scale;
@@ -327,7 +328,11 @@ __global__ void k_step_increment(long long* step, const float* loss_src, float l
     }
 }
 
-__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partials, int n, float* dst) {
+// flag_src != nullptr: also dst[2] = (*flag_src == 2) -- the "a persistent recurrent kernel timed out" indicator travels
+// in the gradient tail, so after the all-reduce EVERY rank of an episode-parallel step knows that some rank's gradients
+// are garbage
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partials, int n, float* dst,
+                                                      const int* flag_src) {
     __shared__ double sh[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;
@@ -335,7 +340,10 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
     s = wave_sum_d(s);
     if (lane == 0) sh[wave] = s;
     __syncthreads();
-    if (tid == 0) dst[0] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+    if (tid == 0) {
+        dst[0] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+        if (flag_src != nullptr) dst[2] = (*flag_src == 2) ? 1.0f : 0.0f;
+    }
 }
 
 // ---------------------------------------------------------------- greedy decode (K10)
@@ -473,8 +481,8 @@ hipError_t launch_step_increment(hipStream_t s, long long* step, const float* lo
     return hipGetLastError();
 }
 
-hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst) {
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partials, n, dst);
+hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst, const int* flag_src) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partials, n, dst, flag_src);
     return hipGetLastError();
 }
 

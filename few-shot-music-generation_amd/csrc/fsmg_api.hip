@@ -85,6 +85,7 @@ struct fsmg_model {
     bool bwd_rs = true;                 // FSMG_BWD_RS=0 selects the all-gather form
     int chain_spin_limit = 1 << 18;     // FSMG_CHAIN_SPIN_LIMIT (0 forces the timeout + fallback path: tests)
     bool persist_timed_out = false;     // set when a persistent kernel gave up (the handle has switched to per-step launches)
+    bool persist_fwd = true, persist_bwd = true;   // FSMG_PERSIST_FWD / FSMG_PERSIST_BWD = 0: that direction launches per step
     bool persist = true;                // FSMG_PERSISTENT=0: one launch per time step instead of one persistent launch per chain chunk
     float* khf = nullptr;               // fragment-ordered recurrent weights: per layer fwd copy, bwd copy
     bool khf_dirty = true;              // host wrote parameters since the last repack
@@ -580,7 +581,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
-    const bool chain = h->persist && lstm_fwd_chain_supported(B, Hp);
+    const bool chain = h->persist && h->persist_fwd && lstm_fwd_chain_supported(B, Hp);
     const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
     PHASE(0);
     for (int l = 0; l < h->L; ++l) {
@@ -671,8 +672,8 @@ int backward(fsmg_model* h, int B) {
     const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
-    const bool rs = h->persist && h->inbox != nullptr && lstm_bwd_rs_supported(B, Hp) && lstm_bwd_rs_inbox_floats(B, Hp) <= h->inbox_floats;
-    const bool chain = rs || (h->persist && h->dzF_all != nullptr && lstm_bwd_chain_supported(B, Hp) &&
+    const bool rs = h->persist && h->persist_bwd && h->inbox != nullptr && lstm_bwd_rs_supported(B, Hp) && lstm_bwd_rs_inbox_floats(B, Hp) <= h->inbox_floats;
+    const bool chain = rs || (h->persist && h->persist_bwd && h->dzF_all != nullptr && lstm_bwd_chain_supported(B, Hp) &&
                               (int64_t)T * ((B + 15) / 16 * 16) * G4 <= h->dzfa_floats);
     const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
     const Lane auxl = aux_lane(h, false, chain);
@@ -768,7 +769,7 @@ int backward(fsmg_model* h, int B) {
         HIPCK(h, launch_embed_grad(s, h->X, (int)rows, h->dXemb, h->Ep, h->G + h->off_emb));
         const int nb = sqnorm_blocks(rows * h->Ep);
         HIPCK(h, launch_sqnorm_partials(s, h->dXemb, rows * h->Ep, h->partials));
-        HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0));
+        HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0, h->d_err));   // + tail[2] = time-out indicator
     }
     if (ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));     // dW / dd landed
     PHASE(6);
@@ -802,13 +803,17 @@ int apply_update(fsmg_model* h, float grad_scale) {
     return FSMG_OK;
 }
 
-int check_tokens_and_read(fsmg_model* h, const float* d_src, float scale, float* host_out, int n) {
-    // one synchronising readback: loss value(s) + the token-range flag
+int check_tokens_and_read(fsmg_model* h, const float* d_src, float scale, float* host_out, int n, bool train_tail = false) {
+    // one synchronising readback: loss value(s) + the token-range / time-out flag (+ for a train step the time-out
+    // indicator of the gradient tail, which after an all-reduce also reports OTHER ranks' time-outs)
     std::vector<float> tmp(n);
     int err = 0;
+    float peer_timeout = 0.0f;
     HIPCK(h, hipMemcpyAsync(tmp.data(), d_src, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (train_tail) HIPCK(h, hipMemcpyAsync(&peer_timeout, h->G + h->n_flat + 2, sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
+    if (err == 0 && peer_timeout != 0.0f) err = 2;
     if (err) {
         HIPCK(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
         if (err == 2) {      // a persistent step kernel gave up waiting for its peers: fall back to one launch per step
@@ -893,6 +898,8 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         h->overlap = env ? (env[0] != '0') : ((int64_t)h->V1 >= 8LL * h->H * h->L);
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_BWD_RS")) h->bwd_rs = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_PERSIST_FWD")) h->persist_fwd = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_PERSIST_BWD")) h->persist_bwd = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_CHAIN_SPIN_LIMIT")) h->chain_spin_limit = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("FSMG_NCHUNK")) h->nchunk = h->nchunk_persist = std::max(1, std::min((int)fsmg_model::NCHUNK, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_CHUNK_STEPS")) {      // e.g. "12,36,34,34,12": must add up to max_len
@@ -1122,7 +1129,7 @@ int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss) {
     int rc = run_graphed(h, "up:" + std::to_string(bits), [&]() -> int { return apply_update(h, grad_scale); });
     if (rc != FSMG_OK) return rc;
     h->have_grads = false;
-    if (loss) return check_tokens_and_read(h, h->G + h->n_flat + 1, grad_scale, loss, 1);
+    if (loss) return check_tokens_and_read(h, h->G + h->n_flat + 1, grad_scale, loss, 1, true);
     return FSMG_OK;
 }
 

@@ -149,7 +149,7 @@ hipError_t launch_sqnorm_partials(hipStream_t s, const float* x, long long n, do
 struct UpdateArgs {
     float* p; float* m; float* v; const float* g; long long n;   // flat buffers
     const double* partials; int n_partials;       // squared-norm partials of everything that counts
-    const float* tail;                            // grad tail scalars (tail[0] = slices_sq, used when slices)
+    const float* tail;                            // grad tail scalars (tail[0] = slices_sq, used when slices; tail[2] != 0: no update)
     int use_slices;                               // add tail[0]*grad_scale^2 to the norm
     float grad_scale;                             // 1/world (g is a SUM over ranks)
     float lr, n_decay, clip;
@@ -161,7 +161,7 @@ hipError_t launch_adam_update(hipStream_t s, const UpdateArgs& a);
 hipError_t launch_step_increment(hipStream_t s, long long* step, const float* loss_src, float loss_scale,
                                  float* loss_ring, int ring_cap, const int* err_flag = nullptr);
 // dst[0] = (float) sum of partials[0..n) (fixed order)
-hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst);
+hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst, const int* flag_src = nullptr);
 // greedy decode step pieces (sample)
 hipError_t launch_decode_cell(hipStream_t s, const float* Kx, int in_dim, const float* Kh, const float* bias,
                               const float* x, const float* h_in, float* h_out, float* c, int Hp);

@@ -192,7 +192,11 @@ __device__ __forceinline__ bool frag_ready(const f32x4& v) {
 
 template <int GPW>
 __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArgs a) {
-    __shared__ float red[4][16][17];
+    // two copies, alternating by time step: three of the four waves poll fragments that come from OTHER blocks only, so
+    // they can be a whole step ahead of wave 0 (never two: the barrier below) and would otherwise overwrite the partial
+    // sums wave 0 is still adding up -- seen as a 1e-3 relative glitch in one block's h about once in 300 passes, and
+    // only beside GEMMs that delay wave 0
+    __shared__ float red[2][4][16][17];
     __shared__ int s_fail;
     FSMG_STEP_PRIO;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][3], bw[j][3], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][4 * q + r][l15] = acc0[r] + acc1[r];
+        for (int r = 0; r < 4; ++r) red[t & 1][wave][4 * q + r][l15] = acc0[r] + acc1[r];
         __syncthreads();
         if (s_fail) return;                                          // block-uniform: a wave of this block timed out
 
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
                     const int c = 4 * gi + euu;
                     float zs = 0.0f;                                  // same summation order as k_lstm_fwd_step
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) zs += red[w][erow][c];
+                    for (int w = 0; w < 4; ++w) zs += red[t & 1][w][erow][c];
                     zg[gi] = zin[gi] + zs;
                 }
                 const float si = sigmoidf_(zg[0]);
@@ -310,8 +314,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
                 zp[0] = g_si; zp[4] = g_tj; zp[8] = g_sf; zp[12] = g_so;  // activated gates kept for BPTT
             }
         }
-        // the other waves may run ahead into step t+1: they cannot pass its poll before wave 0 has published, which
-        // it does after its last read of `red`
+        // the other waves run ahead into step t+1 (into the other copy of `red`)
     }
 }
 
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_lstm_bwd_step(const LstmBwd
 // gradients with shuffles and each stores one float4.
 template <int GPW>
 __global__ __launch_bounds__(512, 2) void k_lstm_bwd_chain(const LstmBwdChainArgs a) {
-    __shared__ float red[8][16][17];
+    __shared__ float red[2][8][16][17];     // alternating by time step: see k_lstm_fwd_chain
     __shared__ int s_fail;
     FSMG_STEP_PRIO;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_bwd_chain(const LstmBwdChainArg
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][4 * q + r][l15] = acc0[r] + acc1[r];
+        for (int r = 0; r < 4; ++r) red[t & 1][wave][4 * q + r][l15] = acc0[r] + acc1[r];
         __syncthreads();
         if (s_fail) return;
 
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_bwd_chain(const LstmBwdChainArg
             if (eact) {
                 float dh_rec = 0.0f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) dh_rec += red[w][erow][eun];
+                for (int w = 0; w < 8; ++w) dh_rec += red[t & 1][w][erow][eun];
                 const CellGrad cg = cell_backward(si, tj, sf, so, ct, cp, dcv, dht + dh_rec);
                 di = cg.di; dj = cg.dj; df = cg.df; dg = cg.dg;
                 gp[0] = di; gp[4] = dj; gp[8] = df; gp[12] = dg;   // row-major dz for the weight-gradient GEMMs

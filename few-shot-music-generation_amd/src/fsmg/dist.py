@@ -50,6 +50,16 @@ class EpisodeParallel(object):
                 dist.broadcast(tensor, src=0, group=self.group)
 
     def train_step(self, support, query, want_loss=True, **kw):
+        try:
+            return self._train_step_once(support, query, want_loss, **kw)
+        except Exception as e:
+            # a persistent recurrent kernel of SOME rank timed out: the indicator travelled in the reduced gradient
+            # tail, so every rank skipped the update, raised here and has fallen back to one launch per time step
+            if 'persistent recurrent kernel timed out' not in str(e):
+                raise
+            return self._train_step_once(support, query, want_loss, **kw)
+
+    def _train_step_once(self, support, query, want_loss=True, **kw):
         self.engine.forward_backward(support, query, **kw)
         buckets = getattr(self.engine, 'grad_buckets', None)
         if self.world > 1 and buckets is not None and self.bucketed:

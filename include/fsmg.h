@@ -122,7 +122,9 @@ int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* 
                           int32_t N, int32_t K, int32_t Q, int32_t tokens_on_device);
 /* device address + element count of the flat gradient buffer; the last FSMG_GRAD_TAIL floats
  * are scalars that must be reduced with it: [0] = sum of squared embedding-slice gradients,
- * [1] = loss */
+ * [1] = loss, [2] = non-zero when a persistent recurrent kernel of this rank timed out (its gradients are garbage):
+ * fsmg_apply_update then leaves parameters, Adam state and step counter alone on every rank and, when it reads the
+ * loss back, returns FSMG_ERR_HIP after switching the handle to one launch per time step -- repeat the step */
 #define FSMG_GRAD_TAIL 16
 int fsmg_grad_buffer(fsmg_handle h, void** device_ptr, int64_t* count);
 int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss);
