@@ -417,6 +417,31 @@ def test_full_size_properties(name):
     assert [again.train_step(sup, qry) for _ in range(4)] == losses
 
 
+def test_fresh_handles_reproduce_each_other_bit_for_bit_at_cfg_b():
+    """Race screen (tools/race_hunt2.py in small): 100 fresh handles, two train steps each on DIFFERENT episodes (so a
+    stale buffer of the previous handle or step would carry different data), every gradient and parameter identical
+    to the first handle's.  This is the test that exposed the LDS write-after-read race of the persistent forward
+    kernel (about one pass in 300, two-stream schedule only)."""
+    over, N, K, Q = FULL['cfg-B']
+    cfg = small_config(**over)
+    eps = O.synthetic_episodes(2, N, K, Q, cfg['max_len'], cfg['input_size'], seed=22)
+    ref = None
+    for rep in range(100):
+        model = new_model(cfg)
+        model.forward_backward(*eps[0])
+        g1 = {k: model.get_grad(k).tobytes() for k in model.param_shapes}
+        model.apply_update(1.0)
+        loss2 = model.train_step(*eps[1])
+        cur = (g1, loss2, {k: v.tobytes() for k, v in model.get_params().items()})
+        if ref is None:
+            ref = cur
+        else:
+            assert cur[1] == ref[1], rep
+            assert all(cur[0][k] == ref[0][k] for k in ref[0]), rep
+            assert all(cur[2][k] == ref[2][k] for k in ref[2]), rep
+        model.close()
+
+
 def test_nccl_allreduce_runs_on_the_gradient_tensor_and_model_stream():
     """Single-rank RCCL group: the real flat gradient tensor (a view into the torch-allocated state arena) goes
     through dist.all_reduce on the model's stream, and the split step (forward_backward -> all_reduce ->
