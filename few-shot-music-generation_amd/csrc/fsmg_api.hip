@@ -85,6 +85,7 @@ struct fsmg_model {
     bool bwd_rs = true;                 // FSMG_BWD_RS=0 selects the all-gather form
     int chain_spin_limit = 1 << 18;     // FSMG_CHAIN_SPIN_LIMIT (0 forces the timeout + fallback path: tests)
     bool persist_timed_out = false;     // set when a persistent kernel gave up (the handle has switched to per-step launches)
+    bool force_fwd_rt = false;          // FSMG_FWD_RT=1: take the all-row-tiles forward kernel wherever it applies (tests)
     bool persist_fwd = true, persist_bwd = true;   // FSMG_PERSIST_FWD / FSMG_PERSIST_BWD = 0: that direction launches per step
     bool persist = true;                // FSMG_PERSISTENT=0: one launch per time step instead of one persistent launch per chain chunk
     float* khf = nullptr;               // fragment-ordered recurrent weights: per layer fwd copy, bwd copy
@@ -581,7 +582,9 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
-    const bool chain = h->persist && h->persist_fwd && lstm_fwd_chain_supported(B, Hp);
+    const bool chain1 = h->persist && h->persist_fwd && !h->force_fwd_rt && lstm_fwd_chain_supported(B, Hp);
+    const bool chain_rt = h->persist && h->persist_fwd && !chain1 && lstm_fwd_chain_rt_supported(B, Hp);   // all row tiles per block
+    const bool chain = chain1 || chain_rt;
     const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
     PHASE(0);
     for (int l = 0; l < h->L; ++l) {
@@ -610,7 +613,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
                 LstmFwdChainArgs a{};
                 a.KhF = h->khf + (size_t)(2 * l) * Hp * G4; a.HF = h->HF[l]; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
                 a.err_flag = h->d_err; a.B = B; a.Hp = Hp; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
-                HIPCK(h, launch_lstm_fwd_chain(s, a));
+                HIPCK(h, chain_rt ? launch_lstm_fwd_chain_rt(s, a) : launch_lstm_fwd_chain(s, a));
             } else {
                 ScopedTimer tm(h, "lstm_fwd");
                 for (int t = t0; t < t1; ++t) {
@@ -899,6 +902,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_BWD_RS")) h->bwd_rs = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_PERSIST_FWD")) h->persist_fwd = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_FWD_RT")) h->force_fwd_rt = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_PERSIST_BWD")) h->persist_bwd = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_CHAIN_SPIN_LIMIT")) h->chain_spin_limit = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("FSMG_NCHUNK")) h->nchunk = h->nchunk_persist = std::max(1, std::min((int)fsmg_model::NCHUNK, std::atoi(e)));

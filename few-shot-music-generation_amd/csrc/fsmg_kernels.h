@@ -72,6 +72,10 @@ struct LstmFwdChainArgs {
 };
 bool lstm_fwd_chain_supported(int B, int Hp);
 hipError_t launch_lstm_fwd_chain(hipStream_t s, const LstmFwdChainArgs& a);
+// Variant for shapes whose (column tile x row tile) grid does not fit the chip (H = 1024; 100-row episodes): a block
+// owns a column tile for ALL row tiles (2..8) and walks them inside a step with the same resident weights.
+bool lstm_fwd_chain_rt_supported(int B, int Hp);
+hipError_t launch_lstm_fwd_chain_rt(hipStream_t s, const LstmFwdChainArgs& a);
 
 struct LstmBwdArgs {
     const float* KhF;      // fragment-ordered recurrent weights (backward copy)

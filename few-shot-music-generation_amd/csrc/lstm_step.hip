@@ -57,6 +57,21 @@ __device__ __forceinline__ float tanhf_(float x) {
     return fabsf(x) < 0.25f ? poly : big;
 }
 
+// The cell update of one (row, unit): one definition with floating-point contraction OFF, shared by every forward
+// kernel (per step, patch, persistent, all-row-tiles persistent) so that they produce the same bits.
+struct CellOut { float si, tj, sf, so, c, h; };
+__device__ __forceinline__ CellOut cell_forward(const float (&zg)[4], float c_prev) {
+#pragma clang fp contract(off)
+    CellOut o;
+    o.si = sigmoidf_(zg[0]);
+    o.tj = tanhf_(zg[1]);
+    o.sf = sigmoidf_(zg[2] + 1.0f);          // forget_bias = 1 added at run time
+    o.so = sigmoidf_(zg[3]);
+    o.c = c_prev * o.sf + o.si * o.tj;
+    o.h = tanhf_(o.c) * o.so;
+    return o;
+}
+
 // ---------------------------------------------------------------- forward
 // grid (4Hp/16, ceil(B/16)); 256 threads = 4 waves, wave w owns a quarter of the K = Hp range.
 // Every operand of a wave's K range is requested before the first MFMA (the loop over groups is
@@ -143,12 +158,8 @@ __global__ __launch_bounds__(64 * NW, NW) void k_lstm_fwd_step(const LstmFwdArgs
             for (int w = 0; w < NW; ++w) zs += red[w][erow][c];
             zg[gi] = zin[gi] + zs;
         }
-        const float si = sigmoidf_(zg[0]);
-        const float tj = tanhf_(zg[1]);
-        const float sf = sigmoidf_(zg[2] + 1.0f);          // forget_bias = 1 added at run time
-        const float so = sigmoidf_(zg[3]);
-        const float cn = cp * sf + si * tj;
-        const float hn = tanhf_(cn) * so;
+        const CellOut co = cell_forward(zg, cp);
+        const float si = co.si, tj = co.tj, sf = co.sf, so = co.so, cn = co.c, hn = co.h;
         a.c_next[(long long)eb * Hp + eu] = cn;
         a.h_next[(long long)eb * Hp + eu] = hn;
         // fragment-ordered copy for the next step's A operand: group eu/16, slot q = (eu%16)/4, sub-step eu%4
@@ -288,14 +299,10 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
                     for (int w = 0; w < 4; ++w) zs += red[t & 1][w][erow][c];
                     zg[gi] = zin[gi] + zs;
                 }
-                const float si = sigmoidf_(zg[0]);
-                const float tj = tanhf_(zg[1]);
-                const float sf = sigmoidf_(zg[2] + 1.0f);          // forget_bias = 1 added at run time
-                const float so = sigmoidf_(zg[3]);
-                const float cn = cp * sf + si * tj;
-                hn = tanhf_(cn) * so;
-                cp = cn;
-                g_si = si; g_tj = tj; g_sf = sf; g_so = so;
+                const CellOut co = cell_forward(zg, cp);
+                hn = co.h;
+                cp = co.c;
+                g_si = co.si; g_tj = co.tj; g_sf = co.sf; g_so = co.so;
             }
             // fragment-ordered h_{t+1}: the 4 units of a row are one float4 (group eu/16, lane slot 4*(eu&12) + row);
             // pad rows publish zeros, so every word of the buffer is written and the readers' test terminates
@@ -315,6 +322,136 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
             }
         }
         // the other waves run ahead into step t+1 (into the other copy of `red`)
+    }
+}
+
+// ---------------------------------------------------------------- forward, persistent, all row tiles in one block
+// grid (4Hp/16): block = one column tile (4 hidden units) x ALL RT = ceil(B/16) row tiles, for the shapes whose
+// (column tile, row tile) grid cannot be resident at once (Hp = 1024: 768 blocks at B = 45; 100-row episodes at
+// Hp = 512: 896).  Same weights-in-registers / data-as-flag protocol as k_lstm_fwd_chain; inside a step every wave
+// walks the row tiles with its GPW resident weight fragments, then wave w finishes the cell for row tiles w, w+4
+// (c stays in registers there).  The partial sums live in dynamic LDS, two copies alternating by time step.
+template <int GPW>
+__global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain_rt(const LstmFwdChainArgs a) {
+    extern __shared__ float red_rt[];                         // [2][RT][4 waves][16][17]
+    __shared__ int s_fail;
+    FSMG_STEP_PRIO;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int nb = blockIdx.x;
+    const int Hp = a.Hp, G4 = 4 * a.Hp, B = a.B;
+    const int RT = (B + 15) / 16;
+    const int ngroups = Hp >> 4;
+    const size_t hf_step = (size_t)RT * 16 * Hp;
+    if (tid == 0) s_fail = 0;
+    auto red = [&](int buf, int rt, int w, int row, int col) -> float& { return red_rt[((((size_t)buf * RT + rt) * 4 + w) * 16 + row) * 17 + col]; };
+
+    f32x4 bw[GPW];
+    {
+        const f32x4* bf = reinterpret_cast<const f32x4*>(a.KhF) + ((size_t)nb * ngroups + wave * GPW) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < GPW; ++j) bw[j] = bf[j * 64];
+    }
+    // epilogue: wave w owns row tiles w and w + 4; lane -> (row, unit)
+    const int erow = lane >> 2, euu = lane & 3, eu = 4 * nb + euu;
+    int eb[2]; bool eact[2]; float cp[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int rt = wave + 4 * e;
+        eb[e] = rt * 16 + erow;
+        eact[e] = rt < RT && eb[e] < B;
+        cp[e] = eact[e] ? a.Cs[((size_t)a.t0 * B + eb[e]) * Hp + eu] : 0.0f;
+    }
+    __syncthreads();
+
+    for (int t = a.t0; t < a.t1; ++t) {
+        float zin[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi)
+                zin[e][gi] = eact[e] ? a.Z[((size_t)t * B + eb[e]) * G4 + 16 * nb + euu + 4 * gi] : 0.0f;
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 av[GPW];
+            const f32x4* af = reinterpret_cast<const f32x4*>(a.HF + (size_t)t * hf_step) + ((size_t)rt * ngroups + wave * GPW) * 64 + lane;
+            bool fail = false;
+            for (int spins = 0;; ++spins) {
+                av[0] = load_sc1(af);
+                drain_vmem();
+                asm volatile("" : "+v"(av[0]));
+                if (__all(frag_ready(av[0]))) break;
+                __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
+                if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+            }
+            if (GPW > 1 && !fail) {
+                for (int spins = 0;; ++spins) {
+#pragma unroll
+                    for (int j = 1; j < GPW; ++j) av[j] = load_sc1(af + j * 64);
+                    drain_vmem();
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 1; j < GPW; ++j) { asm volatile("" : "+v"(av[j])); ok &= frag_ready(av[j]); }
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
+                    if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+                }
+            }
+            if (fail && lane == 0) {
+                __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_fail = 1;
+            }
+            f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < GPW; ++j) {
+                f32x4& acc = (j & 1) ? acc1 : acc0;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][0], bw[j][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][1], bw[j][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][2], bw[j][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][3], bw[j][3], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red(t & 1, rt, wave, 4 * q + r, l15) = acc0[r] + acc1[r];
+            if (fail) break;
+        }
+        __syncthreads();
+        if (s_fail) return;
+
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int rt = wave + 4 * e;
+            if (rt >= RT) break;                                      // wave-uniform
+            float hn = 0.0f, g_si = 0.f, g_tj = 0.f, g_sf = 0.f, g_so = 0.f;
+            if (eact[e]) {
+                float zg[4];
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    const int c = 4 * gi + euu;
+                    float zs = 0.0f;                                  // same summation order as k_lstm_fwd_step
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) zs += red(t & 1, rt, w, erow, c);
+                    zg[gi] = zin[e][gi] + zs;
+                }
+                const CellOut co = cell_forward(zg, cp[e]);
+                g_si = co.si; g_tj = co.tj; g_sf = co.sf; g_so = co.so;
+                hn = co.h;
+                cp[e] = co.c;
+            }
+            f32x4 hv;
+            hv[0] = __shfl(hn, (lane & ~3) + 0); hv[1] = __shfl(hn, (lane & ~3) + 1);
+            hv[2] = __shfl(hn, (lane & ~3) + 2); hv[3] = __shfl(hn, (lane & ~3) + 3);
+            if (euu == 0) {
+                const int u0 = 4 * nb;
+                f32x4* dst = reinterpret_cast<f32x4*>(a.HF + (size_t)(t + 1) * hf_step) +
+                             ((size_t)rt * ngroups + (u0 >> 4)) * 64 + 4 * (u0 & 12) + erow;
+                store_sc1(dst, hv);
+            }
+            if (eact[e]) {
+                a.Cs[((size_t)(t + 1) * B + eb[e]) * Hp + eu] = cp[e];
+                a.Hs[((size_t)(t + 1) * B + eb[e]) * Hp + eu] = hn;
+                float* zp = a.Z + ((size_t)t * B + eb[e]) * G4 + 16 * nb + euu;
+                zp[0] = g_si; zp[4] = g_tj; zp[8] = g_sf; zp[12] = g_so;
+            }
+        }
     }
 }
 
@@ -410,12 +547,8 @@ __global__ __launch_bounds__(64 * NW, NW) void k_lstm_fwd_patch(const LstmFwdArg
             for (int w = 0; w < NW; ++w) zs += red[w][prow][c];
             zg[gi] = zin[gi] + zs;
         }
-        const float si = sigmoidf_(zg[0]);
-        const float tj = tanhf_(zg[1]);
-        const float sf = sigmoidf_(zg[2] + 1.0f);
-        const float so = sigmoidf_(zg[3]);
-        const float cn = cp * sf + si * tj;
-        const float hn = tanhf_(cn) * so;
+        const CellOut co = cell_forward(zg, cp);
+        const float si = co.si, tj = co.tj, sf = co.sf, so = co.so, cn = co.c, hn = co.h;
         a.c_next[(long long)eb * Hp + eu] = cn;
         a.h_next[(long long)eb * Hp + eu] = hn;
         a.hF_next[(((size_t)(eb >> 4) * ngroups + (eu >> 4)) * 64 + 4 * (eu & 12) + (eb & 15)) * 4 + (eu & 3)] = hn;
@@ -880,6 +1013,42 @@ hipError_t launch_lstm_fwd_chain(hipStream_t s, const LstmFwdChainArgs& a) {
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+bool lstm_fwd_chain_rt_supported(int B, int Hp) {
+    const int ngroups = Hp >> 4;
+    if ((Hp & 15) || (ngroups & 3)) return false;
+    const int gpw = ngroups >> 2;
+    if (gpw != 1 && gpw != 2 && gpw != 4 && gpw != 8 && gpw != 16) return false;
+    const int rt = (B + 15) / 16;
+    if (rt < 2 || rt > 4) return false;        // 7 row tiles (cfg-D) measured 12 us per step against 6.1 with one launch per step
+    return (long long)(4 * Hp / 16) <= (long long)256 * (gpw >= 16 ? 2 : 3) * 3 / 4;
+}
+
+template <int GPW>
+static hipError_t launch_fwd_chain_rt_t(hipStream_t s, const LstmFwdChainArgs& a) {
+    const int rt = (a.B + 15) / 16;
+    const size_t lds = (size_t)2 * rt * 4 * 16 * 17 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_lstm_fwd_chain_rt<GPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 16 * 17 * 4);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_lstm_fwd_chain_rt<GPW>), dim3((4 * a.Hp) / 16), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_lstm_fwd_chain_rt(hipStream_t s, const LstmFwdChainArgs& a) {
+    if (a.t1 <= a.t0) return hipSuccess;
+    switch ((a.Hp >> 4) >> 2) {
+        case 1: return launch_fwd_chain_rt_t<1>(s, a);
+        case 2: return launch_fwd_chain_rt_t<2>(s, a);
+        case 4: return launch_fwd_chain_rt_t<4>(s, a);
+        case 8: return launch_fwd_chain_rt_t<8>(s, a);
+        case 16: return launch_fwd_chain_rt_t<16>(s, a);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 bool lstm_bwd_chain_supported(int B, int Hp) {

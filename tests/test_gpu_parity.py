@@ -232,6 +232,22 @@ def test_persistent_forward_chain_is_bit_identical(monkeypatch):
             np.testing.assert_array_equal(out[0][1][k], other[1][k])
 
 
+def test_all_row_tiles_forward_kernel_is_bit_identical(monkeypatch):
+    """FSMG_FWD_RT=1 forces the persistent forward kernel that keeps a column tile for ALL row tiles in one block (what
+    H = 1024 and 100-row episodes get by default): same bits as the one-row-tile kernel, 3 and 4 row tiles."""
+    for (N, K, Q), hidden in (((5, 5, 4), 128), ((12, 1, 4), 64)):
+        cfg = small_config(hidden_size=hidden, embedding_size=32, input_size=150, max_len=12, n_layers=2)
+        eps = O.synthetic_episodes(2, N, K, Q, cfg['max_len'], cfg['input_size'], seed=16)
+        out = []
+        for rt in ('0', '1'):
+            monkeypatch.setenv('FSMG_FWD_RT', rt)
+            model = new_model(cfg)
+            out.append(([model.train_step(s, q) for s, q in eps], model.get_params()))
+        assert out[0][0] == out[1][0]
+        for k in out[0][1]:
+            np.testing.assert_array_equal(out[0][1][k], out[1][1][k])
+
+
 def test_persistent_kernel_timeout_falls_back_and_repeats_the_step(monkeypatch):
     """FSMG_CHAIN_SPIN_LIMIT=0 makes every persistent kernel give up at its first wait (what happens when another
     workload keeps its blocks from becoming co-resident): the update is skipped on the device, the handle falls back to
