@@ -998,7 +998,7 @@ bool lstm_fwd_chain_supported(int B, int Hp) {
     if (gpw != 1 && gpw != 2 && gpw != 4 && gpw != 8 && gpw != 16) return false;
     const long long blocks = (long long)(4 * Hp / 16) * ((B + 15) / 16);
     const int per_cu = gpw >= 16 ? 2 : 4;                      // register-limited residency of 256-thread blocks
-    return blocks <= (long long)256 * per_cu * 3 / 4;
+    return blocks <= (long long)256 * per_cu * 9 / 10;
 }
 
 hipError_t launch_lstm_fwd_chain(hipStream_t s, const LstmFwdChainArgs& a) {
@@ -1077,7 +1077,7 @@ bool lstm_bwd_rs_supported(int B, int Hp) {
     if (Hp % 128) return false;
     const int tpw = Hp / 128;
     if (tpw != 1 && tpw != 2 && tpw != 4 && tpw != 8) return false;
-    return (long long)(Hp / 16) * ((B + 15) / 16) <= (long long)256 * 3 / 4;   // one 512-thread block per CU, with a margin
+    return (long long)(Hp / 16) * ((B + 15) / 16) <= (long long)256 * 9 / 10;  // one 512-thread block per CU, with a margin
 }
 long long lstm_bwd_rs_inbox_floats(int B, int Hp) {
     const long long P = Hp / 16;

@@ -25,6 +25,7 @@ SHAPES = [
     (dict(hidden_size=32, embedding_size=12, input_size=77, max_len=6, n_layers=2), 3, 2, 2),   # stacked
     (dict(hidden_size=64, embedding_size=16, input_size=120, max_len=6), 3, 2, 2),                # Hp = 64: persistent chain kernels, 1 k-group per wave
     (dict(hidden_size=128, embedding_size=24, input_size=90, max_len=7), 5, 5, 4),               # Hp = 128, 3 row tiles: 2 k-groups per wave
+    (dict(hidden_size=128, embedding_size=16, input_size=80, max_len=5), 20, 1, 4),               # 100 rows = 7 row tiles (cfg-D's episode shape) on the persistent kernels
     (dict(hidden_size=256, embedding_size=16, input_size=70, max_len=5), 4, 3, 2),                # Hp = 256: reduce-scatter BPTT kernel with 2 destination tiles per wave
     (dict(hidden_size=512, embedding_size=16, input_size=60, max_len=4), 2, 1, 1),                # Hp = 512 (cfg-B's recurrent shape): 4 per wave
     (dict(hidden_size=1024, embedding_size=16, input_size=60, max_len=4, n_layers=2), 2, 1, 1),   # Hp = 1024 (cfg-C's): 8 per wave, forward per step

@@ -9,7 +9,7 @@ import bench
 from fsmg.binding import FsmgModel
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 only = os.environ.get('STRESS_ONLY')
-for name, (cfg, N, K, Q) in (('cfg-B', (dict(bench.CFG_B), 5, 5, 4)), ('cfg-C', bench.OTHER['cfg-C'])):
+for name, (cfg, N, K, Q) in (('cfg-B', (dict(bench.CFG_B), 5, 5, 4)), ('cfg-C', bench.OTHER['cfg-C']), ('cfg-D', bench.OTHER['cfg-D'])):
     if only and name != only: continue
     eps = bench.synthetic_episodes(3, N, K, Q, cfg['max_len'], cfg['input_size'], 5)
     ref = None
