@@ -201,6 +201,35 @@ __device__ __forceinline__ bool frag_ready(const f32x4& v) {
            __float_as_uint(v[2]) != 0xFFFFFFFFu && __float_as_uint(v[3]) != 0xFFFFFFFFu;
 }
 
+// Waits until the N hand-off fragments at af, af + 64, ... (one 16-byte word per lane each) have been written: polls the
+// first one until none of its four components shows the fill pattern, then fetches the rest and re-fetches them until
+// none does.  Returns false when the spin limit is hit or another wave has already raised the time-out flag.
+template <int N>
+__device__ __forceinline__ bool wait_fragments(const f32x4* af, f32x4 (&av)[N], int spin_limit, int* err_flag) {
+    for (int spins = 0;; ++spins) {
+        av[0] = load_sc1(af);
+        drain_vmem();
+        asm volatile("" : "+v"(av[0]));
+        if (__all(frag_ready(av[0]))) break;
+        __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
+        if (spins >= spin_limit || ((spins & 255) == 255 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) return false;
+    }
+    if (N > 1) {
+        for (int spins = 0;; ++spins) {
+#pragma unroll
+            for (int j = 1; j < N; ++j) av[j] = load_sc1(af + j * 64);
+            drain_vmem();
+            bool ok = true;
+#pragma unroll
+            for (int j = 1; j < N; ++j) { asm volatile("" : "+v"(av[j])); ok &= frag_ready(av[j]); }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
+            if (spins >= spin_limit || ((spins & 255) == 255 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) return false;
+        }
+    }
+    return true;
+}
+
 template <int GPW>
 __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArgs a) {
     // two copies, alternating by time step: three of the four waves poll fragments that come from OTHER blocks only, so
@@ -246,28 +275,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
         f32x4 av[GPW];
         {
             const f32x4* af = reinterpret_cast<const f32x4*>(a.HF + (size_t)t * hf_step) + ((size_t)rt * ngroups + wave * GPW) * 64 + lane;
-            bool fail = false;
-            for (int spins = 0;; ++spins) {
-                av[0] = load_sc1(af);
-                drain_vmem();
-                asm volatile("" : "+v"(av[0]));
-                if (__all(frag_ready(av[0]))) break;
-                __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
-                if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
-            }
-            if (GPW > 1 && !fail) {
-                for (int spins = 0;; ++spins) {
-#pragma unroll
-                    for (int j = 1; j < GPW; ++j) av[j] = load_sc1(af + j * 64);
-                    drain_vmem();
-                    bool ok = true;
-#pragma unroll
-                    for (int j = 1; j < GPW; ++j) { asm volatile("" : "+v"(av[j])); ok &= frag_ready(av[j]); }
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
-                    if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
-                }
-            }
+            const bool fail = !wait_fragments<GPW>(af, av, a.spin_limit, a.err_flag);
             if (fail && lane == 0) {
                 __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_fail = 1;
@@ -374,28 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain_rt(const LstmFwdChain
         for (int rt = 0; rt < RT; ++rt) {
             f32x4 av[GPW];
             const f32x4* af = reinterpret_cast<const f32x4*>(a.HF + (size_t)t * hf_step) + ((size_t)rt * ngroups + wave * GPW) * 64 + lane;
-            bool fail = false;
-            for (int spins = 0;; ++spins) {
-                av[0] = load_sc1(af);
-                drain_vmem();
-                asm volatile("" : "+v"(av[0]));
-                if (__all(frag_ready(av[0]))) break;
-                __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
-                if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
-            }
-            if (GPW > 1 && !fail) {
-                for (int spins = 0;; ++spins) {
-#pragma unroll
-                    for (int j = 1; j < GPW; ++j) av[j] = load_sc1(af + j * 64);
-                    drain_vmem();
-                    bool ok = true;
-#pragma unroll
-                    for (int j = 1; j < GPW; ++j) { asm volatile("" : "+v"(av[j])); ok &= frag_ready(av[j]); }
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
-                    if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
-                }
-            }
+            const bool fail = !wait_fragments<GPW>(af, av, a.spin_limit, a.err_flag);
             if (fail && lane == 0) {
                 __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_fail = 1;
@@ -741,28 +728,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_bwd_chain(const LstmBwdChainArg
         if (t + 1 < a.T) {
             f32x4 av[GPW];
             const f32x4* af = reinterpret_cast<const f32x4*>(a.dzF_all + (size_t)(t + 1) * dz_step) + ((size_t)rt * ngroups + wave * GPW) * 64 + lane;
-            bool fail = false;
-            for (int spins = 0;; ++spins) {
-                av[0] = load_sc1(af);
-                drain_vmem();
-                asm volatile("" : "+v"(av[0]));
-                if (__all(frag_ready(av[0]))) break;
-                __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
-                if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
-            }
-            if (GPW > 1 && !fail) {
-                for (int spins = 0;; ++spins) {
-#pragma unroll
-                    for (int j = 1; j < GPW; ++j) av[j] = load_sc1(af + j * 64);
-                    drain_vmem();
-                    bool ok = true;
-#pragma unroll
-                    for (int j = 1; j < GPW; ++j) { asm volatile("" : "+v"(av[j])); ok &= frag_ready(av[j]); }
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
-                    if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
-                }
-            }
+            const bool fail = !wait_fragments<GPW>(af, av, a.spin_limit, a.err_flag);
             if (fail && lane == 0) {
                 __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_fail = 1;
