@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain(const LstmFwdChainArg
 // walks the row tiles with its GPW resident weight fragments, then wave w finishes the cell for row tiles w, w+4
 // (c stays in registers there).  The partial sums live in dynamic LDS, two copies alternating by time step.
 template <int GPW>
-__global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain_rt(const LstmFwdChainArgs a) {
+__global__ __launch_bounds__(256, 1) void k_lstm_fwd_chain_rt(const LstmFwdChainArgs a) {     // GPW = 16 needs > 256 registers
     extern __shared__ float red_rt[];                         // [2][RT][4 waves][16][17]
     __shared__ int s_fail;
     FSMG_STEP_PRIO;
@@ -379,13 +379,17 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain_rt(const LstmFwdChain
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi)
                 zin[e][gi] = eact[e] ? a.Z[((size_t)t * B + eb[e]) * G4 + 16 * nb + euu + 4 * gi] : 0.0f;
+        // row tile 0 pays the hop (poll); the fragments of row tile rt + 1 are requested before the MFMAs of row tile rt
+        // and checked after them -- by then their producers have long published, so the check almost never fails
+        const f32x4* af0 = reinterpret_cast<const f32x4*>(a.HF + (size_t)t * hf_step) + ((size_t)wave * GPW) * 64 + lane;
+        f32x4 av[GPW], nx[GPW];
+        bool fail = !wait_fragments<GPW>(af0, av, a.spin_limit, a.err_flag);
         for (int rt = 0; rt < RT; ++rt) {
-            f32x4 av[GPW];
-            const f32x4* af = reinterpret_cast<const f32x4*>(a.HF + (size_t)t * hf_step) + ((size_t)rt * ngroups + wave * GPW) * 64 + lane;
-            const bool fail = !wait_fragments<GPW>(af, av, a.spin_limit, a.err_flag);
-            if (fail && lane == 0) {
-                __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_fail = 1;
+            const bool more = rt + 1 < RT && !fail;
+            const f32x4* afn = af0 + (size_t)(rt + 1) * ngroups * 64;
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < GPW; ++j) nx[j] = load_sc1(afn + j * 64);
             }
             f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -398,7 +402,20 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_chain_rt(const LstmFwdChain
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) red(t & 1, rt, wave, 4 * q + r, l15) = acc0[r] + acc1[r];
+            if (more) {
+                drain_vmem();
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < GPW; ++j) { asm volatile("" : "+v"(nx[j])); ok &= frag_ready(nx[j]); }
+                if (!__all(ok)) fail = !wait_fragments<GPW>(afn, nx, a.spin_limit, a.err_flag);
+#pragma unroll
+                for (int j = 0; j < GPW; ++j) av[j] = nx[j];
+            }
             if (fail) break;
+        }
+        if (fail && lane == 0) {
+            __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_fail = 1;
         }
         __syncthreads();
         if (s_fail) return;
@@ -988,7 +1005,7 @@ bool lstm_fwd_chain_rt_supported(int B, int Hp) {
     if (gpw != 1 && gpw != 2 && gpw != 4 && gpw != 8 && gpw != 16) return false;
     const int rt = (B + 15) / 16;
     if (rt < 2 || rt > 4) return false;        // 7 row tiles (cfg-D) measured 12 us per step against 6.1 with one launch per step
-    return (long long)(4 * Hp / 16) <= (long long)256 * (gpw >= 16 ? 2 : 3) * 3 / 4;
+    return (long long)(4 * Hp / 16) <= (long long)256 * (gpw >= 16 ? 1 : 3);
 }
 
 template <int GPW>
