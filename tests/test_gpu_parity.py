@@ -500,10 +500,13 @@ def test_nccl_allreduce_runs_on_the_gradient_tensor_and_model_stream():
         dist.destroy_process_group()
 
 
-def test_full_size_cfg_b_gradients_match_oracle():
-    """One full cfg-B train episode (B=45, T=128, V1=10001, H=512): loss and EVERY gradient tensor vs the fp64
-    oracle (230 GFLOP in numpy; a few seconds on the GPU box's host cores), realistic Zipf/padded tokens."""
-    over, N, K, Q = FULL['cfg-B']
+@pytest.mark.parametrize('name', sorted(FULL))
+def test_full_size_gradients_match_oracle(name):
+    """One full train episode of every BASELINE config that fits one GPU -- cfg-B (B=45, T=128, V1=10001, H=512),
+    cfg-C (T=50, H=1024, L=2: the all-row-tiles forward kernel, k_lstm_bwd_rs<8>, the inter-layer dx path) and cfg-D
+    (B=100: 7 row tiles) -- loss and EVERY gradient tensor vs the fp64 oracle (231 / 249 / 513 GFLOP in numpy),
+    then one clip + Adam update, realistic Zipf/padded tokens."""
+    over, N, K, Q = FULL[name]
     cfg = small_config(**over)
     (sup, qry), = O.synthetic_episodes(1, N, K, Q, cfg['max_len'], cfg['input_size'], seed=8, realistic=True)
     model = new_model(cfg)
@@ -513,11 +516,37 @@ def test_full_size_cfg_b_gradients_match_oracle():
     tail = model.debug_read('tail', 16)
     assert abs(tail[1] - loss) <= NLL_RTOL * abs(loss)
     assert abs(tail[0] - aux['embedding_slices_sq']) <= 1e-4 * aux['embedding_slices_sq']
-    for name in grads:
-        assert rel_max(model.get_grad(name), grads[name]) < 2e-4, name
+    for name_ in grads:
+        assert rel_max(model.get_grad(name_), grads[name_]) < 2e-4, name_
     got = model.apply_update(1.0)
     opt = O.new_opt_state(params)
     O.apply_update(params, grads, aux, opt, cfg)
-    for name, ref in params.items():
-        assert rel_max(model.get_param(name), ref) < 1e-4, name      # one Adam step on 9.2 M parameters (update is sign-like: sensitive where |g| ~ eps)
+    for name_, ref in params.items():
+        assert rel_max(model.get_param(name_), ref) < 1e-4, name_      # one Adam step (update is sign-like: sensitive where |g| ~ eps)
     assert abs(got - loss) <= NLL_RTOL * abs(loss)
+
+
+def test_lr_decay_is_exercised_from_a_resumed_step():
+    """exponential_decay (reference src/models/lstm_baseline.py:77-81): lr_s = lr * 0.5 ** (global_step / n_decay),
+    continuous, global_step read BEFORE the update.  n_decay = 3 and a counter resumed at 7 make the factor
+    0.198 -> 0.025 over the ten updates: a wrong base, exponent or off-by-one moves the parameters by 20 %+ of an update,
+    far outside the tolerance (every other test uses n_decay = 10000, a factor 0.9993)."""
+    cfg = small_config(hidden_size=40, embedding_size=20, input_size=211, max_len=12, n_decay=3, lr=2e-2)
+    model = new_model(cfg)
+    params = f64_params(model)
+    start = {k: v.copy() for k, v in params.items()}
+    opt = O.new_opt_state(params)
+    # global_step drives the decay AND Adam's bias correction (TF's beta powers are beta ** global_step for this
+    # trainer: one apply_gradients per step); the slots start at zero here, as after set_step on a fresh handle
+    model.step = 7
+    opt['step'] = 7
+    for s in range(10):
+        sup, qry = _episode(cfg, 3, 3, 2, seed=300 + s)
+        want = O.train_step(params, opt, sup, qry, cfg)
+        got = model.train_step(sup, qry)
+        assert abs(got - want) <= NLL_RTOL * abs(want), (s, got, want)
+    assert model.step == 17
+    moved = max(rel_max(params[k], start[k]) for k in params)
+    for name, ref in params.items():
+        assert rel_max(model.get_param(name), ref) < 5e-4, name
+    assert moved > 0.02          # the parameters moved by far more than the tolerance: the check has teeth

@@ -104,3 +104,72 @@ def test_learning_rate_schedule_and_adam_first_step():
     alpha = 5e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
     m, v = 0.1 * 1e-3, 0.001 * 1e-6
     assert abs(params['w'][0] - (1.0 - alpha * m / (np.sqrt(v) + 1e-8))) < 1e-15
+
+
+def _torch_gate_perm(H):
+    """column blocks (i, j, f, o) of BasicLSTMCell -> torch.nn.LSTM's row blocks (i, f, g, o)  """
+    i, j, f, o = (np.arange(H) + k * H for k in range(4))
+    return np.concatenate([i, f, j, o])
+
+
+@pytest.mark.parametrize('L', [1, 2])
+def test_forward_matches_torch_nn_lstm(L):
+    """An implementation that shares NO formula with lstm_oracle.py: torch.nn.LSTM (ATen's fused cell) +
+    F.cross_entropy, fed the reference-layout weights through the SURVEY A.5 mapping
+    (weight_ih = reorder(K[:in]).T, weight_hh = reorder(K[in:]).T, bias_ih = reorder(b + forget_bias on f), bias_hh = 0).
+    Pins gate order, the run-time forget bias, the output row order b*T+t and the mean-over-all-tokens loss."""
+    import torch.nn.functional as F
+    cfg = small_config(n_layers=L, input_size=37, embedding_size=8, hidden_size=16, max_len=10)
+    d = O.model_dims(cfg)
+    H, T = d['H'], d['T']
+    params = O.glorot_init(cfg, 11, np.float64)
+    for l in range(L):       # non-zero biases so that a wrong forget-bias placement cannot hide
+        params['bias_%d' % l] = np.random.RandomState(l).uniform(-0.5, 0.5, 4 * H)
+    sup, qry = _episode(cfg, N=2, K=2, Q=1, seed=5)
+    X, Y = O.train_xy(sup, qry, cfg['input_size'])
+    want, cache = O.forward(params, X, Y, cfg)
+
+    perm = _torch_gate_perm(H)
+    lstm = torch.nn.LSTM(d['E'], H, num_layers=L, batch_first=True, dtype=torch.float64)
+    with torch.no_grad():
+        for l in range(L):
+            K, b = params['kernel_%d' % l], params['bias_%d' % l]
+            n_in = d['E'] if l == 0 else H
+            fb = np.zeros(4 * H); fb[2 * H:3 * H] = O.FORGET_BIAS
+            getattr(lstm, 'weight_ih_l%d' % l).copy_(torch.from_numpy(K[:n_in][:, perm].T.copy()))
+            getattr(lstm, 'weight_hh_l%d' % l).copy_(torch.from_numpy(K[n_in:][:, perm].T.copy()))
+            getattr(lstm, 'bias_ih_l%d' % l).copy_(torch.from_numpy((b + fb)[perm]))
+            getattr(lstm, 'bias_hh_l%d' % l).zero_()
+        emb = torch.from_numpy(params['embedding'])[torch.from_numpy(X.astype(np.int64))]      # [B,T,E]
+        out, (hn, cn) = lstm(emb)                                                              # zero initial state
+        logits = out.reshape(-1, H) @ torch.from_numpy(params['softmax_w']) + torch.from_numpy(params['softmax_b'])
+        got = F.cross_entropy(logits, torch.from_numpy(Y.reshape(-1).astype(np.int64)), reduction='mean')
+    assert abs(float(got) - float(want)) <= 1e-10 * abs(float(want))
+    np.testing.assert_allclose(out.numpy(), np.transpose(cache['layers'][-1]['hs'][1:], (1, 0, 2)), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(cn[-1].numpy(), cache['layers'][-1]['cs'][T], rtol=0, atol=1e-12)
+
+
+def test_adam_and_lr_decay_match_torch_optim_adam():
+    """torch.optim.Adam shares no code with apply_update.  TF1's Adam (reference lstm_baseline.py:82) is
+    theta -= lr_t * m / (sqrt(v) + eps), lr_t = lr_s sqrt(1-b2^t)/(1-b1^t): torch's update with eps_torch =
+    eps / sqrt(1-b2^t) (set per step below -> agreement to rounding).  The decayed learning rate lr * 0.5 ** (s / n_decay)
+    (continuous, s = global_step BEFORE the update; reference lstm_baseline.py:77-81) is fed to torch per step;
+    n_decay = 3 makes a wrong base / exponent / off-by-one visible at once (factor 0.79 per step)."""
+    cfg = small_config(lr=5e-3, n_decay=3, max_grad_norm=1e9)
+    rng = np.random.RandomState(0)
+    w0 = rng.uniform(-1, 1, 50)
+    params = {'w': w0.copy()}
+    opt = O.new_opt_state(params)
+    tw = torch.nn.Parameter(torch.from_numpy(w0.copy()))
+    topt = torch.optim.Adam([tw], lr=1.0, betas=(O.BETA1, O.BETA2), eps=0.0)
+    for s in range(6):
+        g = rng.uniform(0.5, 1.5, 50) * rng.choice([-1, 1], 50)
+        for grp in topt.param_groups:
+            grp['lr'] = 5e-3 * 0.5 ** (s / 3.0)
+            grp['eps'] = O.ADAM_EPS / np.sqrt(1.0 - O.BETA2 ** (s + 1))     # TF's epsilon placement in torch's terms
+        tw.grad = torch.from_numpy(g.copy())
+        topt.step()
+        O.apply_update(params, {'w': g}, {'embedding_slices_sq': 0.0}, opt, cfg, 'dense')
+        np.testing.assert_allclose(params['w'], tw.detach().numpy(), rtol=0, atol=1e-14)
+    assert opt['step'] == 6
+    assert np.abs(params['w'] - w0).max() > 5e-3          # the parameters moved by far more than the tolerance
