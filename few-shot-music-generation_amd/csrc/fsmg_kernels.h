@@ -130,6 +130,42 @@ hipError_t launch_lstm_bwd_rs(hipStream_t s, const LstmBwdRsArgs& a);
 // recurrent weights [Hp][4Hp] -> the forward and backward fragment-ordered copies (Hp*4Hp floats each)
 hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp);
 
+// ---------------------------------------------------------------- XCD-local recurrence (lstm_xcd.hip), hidden size 512
+// Rows are split over the 8 XCDs (ceil(B/8) each); every XCD holds a full register-resident copy of K_h and hands h_t /
+// the dh partials between its own 32 CUs through its L2.  grid = 256 blocks x 256 threads; roles come from the XCC id
+// plus a per-XCD ticket (tickets: 8 ints, ZERO before every launch).  Same bounded-spin / err_flag = 2 contract as the
+// column-split persistent kernels.
+struct LstmFwdXcdArgs {
+    const float* KhX;     // forward register image of K_h (launch_repack_kh_xcd)
+    float* HX;            // [T+1][8][4][RG][2][64][4] hand-off buffer; index 0 = zero state, t0+1 .. t1 = 0xFF fill
+    float* Z;             // [T][B][4Hp] in: x-part pre-activations (+bias); out: activated gates
+    float* Cs;            // [T+1][B][Hp]
+    float* Hs;            // [T+1][B][Hp]
+    int* tickets;
+    int* err_flag;
+    int B, T, t0, t1;
+    int spin_limit;
+};
+struct LstmBwdXcdArgs {
+    const float* KhXb;    // backward register image of K_h
+    float* inbox;         // [2][8][32][32][RG][16][4], every word 0xFFFFFFFF before the first launch of a pass
+    float* Z;             // [T][B][4Hp] in: activated gates; out: dz
+    const float* Cs;      // [T+1][B][Hp]
+    float* dc;            // [B][Hp]
+    const float* dH;      // [T][B][Hp]
+    int* tickets;
+    int* err_flag;
+    int B, T, t0, t1;
+    int spin_limit;
+};
+bool lstm_xcd_supported(int B, int Hp);
+long long lstm_xcd_hx_floats(int B, int T);
+long long lstm_xcd_inbox_floats(int B);
+long long lstm_xcd_weight_floats();           // floats per register image
+hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd);
+hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a);
+hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);
+
 // ---------------------------------------------------------------- everything else (elementwise.hip)
 // tokens [nseq][T] (support rows then query rows) -> time-major input ids X[t][b] (start word at t=0)
 // and targets Y[t][b]; sets *err_flag if any id is outside [0, vocab).
