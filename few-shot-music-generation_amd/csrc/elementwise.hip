@@ -273,8 +273,9 @@ __global__ __launch_bounds__(256) void k_sqnorm_partials(const float* __restrict
 __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
     __shared__ double sh[4];
     __shared__ float s_scale, s_alpha;
-    // the gradients of a step whose persistent recurrent kernel timed out are garbage: keep the parameters
-    if ((a.err_flag != nullptr && *a.err_flag == 2) || a.tail[2] != 0.0f) return;
+    // the gradients of a step whose persistent recurrent kernel timed out are garbage, and a batch with an out-of-range
+    // token is rejected as a whole (the reference would fail the feed): keep the parameters
+    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;
     for (int i = tid; i < a.n_partials; i += 256) s += a.partials[i];
@@ -317,11 +318,25 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
     }
 }
 
+// Last kernel of a train step.  A step that must not count -- a persistent recurrent kernel timed out on this rank
+// (*err_flag == 2) or on another one (tail[2], all-reduced), or a token id was out of range (*err_flag == 1) -- is
+// tallied in `counters` (host-mapped: [0] time-outs, [1] token-range rejections; the host compares them with what it has
+// seen, no read-back needed) and the flag is CLEARED, so that the next step starts clean instead of every later launch
+// bailing out on a stale flag.
 __global__ void k_step_increment(long long* step, const float* loss_src, float loss_scale, float* ring,
-                                 int ring_cap, const int* err_flag) {
-    // loss_src is tail[1]; tail[2] is the (all-reduced) time-out indicator
-    if ((err_flag != nullptr && *err_flag == 2) || (loss_src != nullptr && loss_src[1] != 0.0f)) return;
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+                                 int ring_cap, int* err_flag, long long* counters) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int e = err_flag != nullptr ? *err_flag : 0;
+    const bool peer_timeout = loss_src != nullptr && loss_src[1] != 0.0f;      // loss_src is tail[1]; tail[2] is the indicator
+    if (e != 0 || peer_timeout) {
+        if (counters != nullptr) {
+            if (e == 2 || peer_timeout) counters[0] += 1; else counters[1] += 1;
+            __threadfence_system();
+        }
+        if (err_flag != nullptr) *err_flag = 0;
+        return;
+    }
+    {
         const long long s = *step;
         if (ring != nullptr && loss_src != nullptr) ring[s % ring_cap] = *loss_src * loss_scale;
         *step = s + 1;
@@ -476,8 +491,8 @@ hipError_t launch_adam_update(hipStream_t s, const UpdateArgs& a) {
 }
 
 hipError_t launch_step_increment(hipStream_t s, long long* step, const float* loss_src, float loss_scale,
-                                 float* loss_ring, int ring_cap, const int* err_flag) {
-    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(64), 0, s, step, loss_src, loss_scale, loss_ring, ring_cap, err_flag);
+                                 float* loss_ring, int ring_cap, int* err_flag, long long* counters) {
+    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(64), 0, s, step, loss_src, loss_scale, loss_ring, ring_cap, err_flag, counters);
     return hipGetLastError();
 }
 

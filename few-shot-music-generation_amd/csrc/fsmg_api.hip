@@ -85,10 +85,27 @@ struct fsmg_model {
     bool bwd_rs = true;                 // FSMG_BWD_RS=0 selects the all-gather form
     int chain_spin_limit = 1 << 18;     // FSMG_CHAIN_SPIN_LIMIT (0 forces the timeout + fallback path: tests)
     bool persist_timed_out = false;     // set when a persistent kernel gave up (the handle has switched to per-step launches)
+    bool persist_cfg = true;            // what the configuration asked for; `persist` is what is in force right now
+    int fallback_steps = 200;           // FSMG_FALLBACK_STEPS: train steps on per-step launches after a time-out, then the persistent path is tried again
+    int fallback_left = 0;
+    long long* host_counters = nullptr; // host-mapped tallies written by k_step_increment: [0] steps skipped after a time-out, [1] after a token-range error
+    long long* d_counters = nullptr;    // the same memory as the device sees it
+    long long seen_timeouts = 0, seen_token_errors = 0;
     bool force_fwd_rt = false;          // FSMG_FWD_RT=1: take the all-row-tiles forward kernel wherever it applies (tests)
     bool persist_fwd = true, persist_bwd = true;   // FSMG_PERSIST_FWD / FSMG_PERSIST_BWD = 0: that direction launches per step
     bool persist = true;                // FSMG_PERSISTENT=0: one launch per time step instead of one persistent launch per chain chunk
     float* khf = nullptr;               // fragment-ordered recurrent weights: per layer fwd copy, bwd copy
+    // XCD-local recurrence (lstm_xcd.hip; hidden size 512): per layer the forward and backward register images of K_h,
+    // the h hand-off buffer, the dh-partial inboxes and the per-launch ticket counters
+    bool xcd = true;                    // FSMG_XCD=0: keep the column-split persistent kernels
+    int xcd_max_rows = 128;             // FSMG_XCD_MAX_ROWS: largest sequence count that takes the XCD-local kernels
+    float* khx = nullptr;
+    float* HX = nullptr; int64_t hx_floats = 0;
+    float* inboxX = nullptr; int64_t inboxx_floats = 0;
+    int* tickets = nullptr;             // [TICKET_LAUNCHES][8]
+    static constexpr int TICKET_LAUNCHES = 64;
+    int ticket_next = 0;
+    int64_t n_timeouts = 0, n_persist_launches = 0, n_xcd_launches = 0, n_step_launches = 0;   // fsmg_get_stats
     bool khf_dirty = true;              // host wrote parameters since the last repack
     float* slabs = nullptr;             // split-K partial outputs of the GEMMs on the main stream
     float* colsum_slabs = nullptr;
@@ -353,6 +370,10 @@ int ensure_scratch(fsmg_model* h, int B) {
     const int64_t o_dzfa = place(want_dzfa ? 4 * n_dzfa : 256);
     const int64_t n_inbox = want_inbox ? lstm_bwd_rs_inbox_floats(rows_rs, (int)Hp) : 0;
     const int64_t o_inbox = place(want_inbox ? 4 * n_inbox : 256);
+    // XCD-local kernels: sized for the largest row count they take (not for B, same reason)
+    const int xrows = (h->persist && h->xcd && lstm_xcd_supported(h->xcd_max_rows, (int)Hp)) ? h->xcd_max_rows : 0;
+    const int64_t n_hx = xrows ? lstm_xcd_hx_floats(xrows, (int)T) : 0, n_inx = xrows ? lstm_xcd_inbox_floats(xrows) : 0;
+    const int64_t o_hx = place(xrows ? 4 * n_hx : 256), o_inx = place(xrows ? 4 * n_inx : 256);
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
     const int64_t o_lg = place(4 * rows * h->V1p), o_dlg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
     const int64_t o_dx = place(4 * rows * h->Ep);
@@ -404,6 +425,8 @@ int ensure_scratch(fsmg_model* h, int B) {
     h->dzF = (float*)(s + o_dzf);
     h->dzF_all = want_dzfa ? (float*)(s + o_dzfa) : nullptr; h->dzfa_floats = n_dzfa;
     h->inbox = want_inbox ? (float*)(s + o_inbox) : nullptr; h->inbox_floats = n_inbox;
+    h->HX = xrows ? (float*)(s + o_hx) : nullptr; h->hx_floats = n_hx;
+    h->inboxX = xrows ? (float*)(s + o_inx) : nullptr; h->inboxx_floats = n_inx;
     // pad rows of the fragment buffers are never written: clear once so they hold finite values
     HIPCK(h, hipMemsetAsync(s + o_hf[0], 0, (size_t)(o_dc - o_hf[0]), h->stream));
     h->dC = (float*)(s + o_dc); h->dH = (float*)(s + o_dh); h->logits = (float*)(s + o_lg);
@@ -487,8 +510,12 @@ int run_graphed(fsmg_model* h, const std::string& key, F&& body) {
 int ensure_khf(fsmg_model* h) {
     if (!h->khf_dirty) return FSMG_OK;
     for (int l = 0; l < h->L; ++l)
+    {
         HIPCK(h, launch_repack_kh(h->stream, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
                                   h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
+        if (h->khx) HIPCK(h, launch_repack_kh_xcd(h->stream, h->P + h->off_kh[l], h->khx + (size_t)(2 * l) * h->Hp * h->G4,
+                                                  h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4));
+    }
     h->khf_dirty = false;
     return FSMG_OK;
 }
@@ -544,6 +571,18 @@ static void phase_report(fsmg_model* h) {
 #define PHASE(i) ((void)0)
 #endif
 
+// the XCD-local kernels take this row count at this hidden size (and their buffers exist)
+inline bool use_xcd(const fsmg_model* h, int B) {
+    return h->persist && h->xcd && h->khx != nullptr && h->HX != nullptr && B <= h->xcd_max_rows && lstm_xcd_supported(B, h->Hp) &&
+           lstm_xcd_hx_floats(B, h->T) <= h->hx_floats && lstm_xcd_inbox_floats(B) <= h->inboxx_floats;
+}
+// every XCD-local launch of a pass gets its own 8 zeroed ticket counters
+inline int* next_tickets(fsmg_model* h) {
+    int* t = h->tickets + 8 * (h->ticket_next % fsmg_model::TICKET_LAUNCHES);
+    ++h->ticket_next;
+    return t;
+}
+
 int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t rows_total, bool want_dlogits) {
     const int Hp = h->Hp;
     const int64_t r0 = (int64_t)t0 * B, m = (int64_t)(t1 - t0) * B;
@@ -582,10 +621,11 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
-    const bool chain1 = h->persist && h->persist_fwd && !h->force_fwd_rt && lstm_fwd_chain_supported(B, Hp);
-    const bool chain_rt = h->persist && h->persist_fwd && !chain1 && lstm_fwd_chain_rt_supported(B, Hp);   // all row tiles per block
+    const bool xcd = use_xcd(h, B) && h->persist_fwd;
+    const bool chain1 = !xcd && h->persist && h->persist_fwd && !h->force_fwd_rt && lstm_fwd_chain_supported(B, Hp);
+    const bool chain_rt = !xcd && h->persist && h->persist_fwd && !chain1 && lstm_fwd_chain_rt_supported(B, Hp);   // all row tiles per block
     const bool chain = chain1 || chain_rt;
-    const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
+    const int nch = ov ? ((chain || xcd) ? h->nchunk_persist : h->nchunk) : 1;
     PHASE(0);
     for (int l = 0; l < h->L; ++l) {
         const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
@@ -606,14 +646,29 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
         PHASE(1);
         if (chain)       // "not written yet" fill pattern of the h fragments of time indices 1..T (index 0 is the zero state)
             HIPCK(h, hipMemsetAsync(h->HF[l] + Bp16 * Hp, 0xFF, sizeof(float) * (size_t)T * Bp16 * Hp, s));
+        if (xcd) {       // the same for the XCD-local hand-off buffer, and fresh ticket counters for this layer's launches
+            HIPCK(h, hipMemsetAsync(h->tickets, 0, sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES, s));
+            h->ticket_next = 0;
+            const size_t step_f = (size_t)lstm_xcd_hx_floats(B, 0);
+            HIPCK(h, hipMemsetAsync(h->HX, 0, sizeof(float) * step_f, s));
+            HIPCK(h, hipMemsetAsync(h->HX + step_f, 0xFF, sizeof(float) * step_f * T, s));
+        }
         for (int c = 0; c < nch; ++c) {
             const int t0 = chunk_begin(h, c, nch), t1 = chunk_begin(h, c + 1, nch);
-            if (chain) {
+            if (xcd) {
+                ScopedTimer tm(h, "lstm_fwd");
+                LstmFwdXcdArgs a{};
+                a.KhX = h->khx + (size_t)(2 * l) * Hp * G4; a.HX = h->HX; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
+                a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
+                HIPCK(h, launch_lstm_fwd_xcd(s, a));
+                ++h->n_xcd_launches;
+            } else if (chain) {
                 ScopedTimer tm(h, "lstm_fwd");
                 LstmFwdChainArgs a{};
                 a.KhF = h->khf + (size_t)(2 * l) * Hp * G4; a.HF = h->HF[l]; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
                 a.err_flag = h->d_err; a.B = B; a.Hp = Hp; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, chain_rt ? launch_lstm_fwd_chain_rt(s, a) : launch_lstm_fwd_chain(s, a));
+                ++h->n_persist_launches;
             } else {
                 ScopedTimer tm(h, "lstm_fwd");
                 for (int t = t0; t < t1; ++t) {
@@ -628,11 +683,12 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
                     a.B = B; a.Hp = Hp;
                     HIPCK(h, launch_lstm_fwd_step(s, a));
                 }
+                h->n_step_launches += t1 - t0;
             }
             if (top && ov) {      // projection + CE of this chunk on the auxiliary stream
                 HIPCK(h, hipEventRecord(h->ev_chunk[c], s));
                 HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_chunk[c], 0));
-                GEMMCK(logits_and_ce(h, aux_lane(h, !want_dlogits, chain), B, t0, t1, rows, want_dlogits));
+                GEMMCK(logits_and_ce(h, aux_lane(h, !want_dlogits, chain || xcd), B, t0, t1, rows, want_dlogits));
             }
         }
     }
@@ -675,8 +731,9 @@ int backward(fsmg_model* h, int B) {
     const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
-    const bool rs = h->persist && h->persist_bwd && h->inbox != nullptr && lstm_bwd_rs_supported(B, Hp) && lstm_bwd_rs_inbox_floats(B, Hp) <= h->inbox_floats;
-    const bool chain = rs || (h->persist && h->persist_bwd && h->dzF_all != nullptr && lstm_bwd_chain_supported(B, Hp) &&
+    const bool xcd = use_xcd(h, B) && h->persist_bwd;
+    const bool rs = !xcd && h->persist && h->persist_bwd && h->inbox != nullptr && lstm_bwd_rs_supported(B, Hp) && lstm_bwd_rs_inbox_floats(B, Hp) <= h->inbox_floats;
+    const bool chain = xcd || rs || (h->persist && h->persist_bwd && h->dzF_all != nullptr && lstm_bwd_chain_supported(B, Hp) &&
                               (int64_t)T * ((B + 15) / 16 * 16) * G4 <= h->dzfa_floats);
     const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
     const Lane auxl = aux_lane(h, false, chain);
@@ -703,7 +760,11 @@ int backward(fsmg_model* h, int B) {
         HIPCK(h, hipMemsetAsync(h->dC, 0, sizeof(float) * (size_t)B * Hp, s));
         if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[nch - 1], 0));
         PHASE(4);
-        if (rs) {        // "not written yet" fill pattern of the dh partial inboxes
+        if (xcd) {
+            HIPCK(h, hipMemsetAsync(h->inboxX, 0xFF, sizeof(float) * (size_t)lstm_xcd_inbox_floats(B), s));
+            HIPCK(h, hipMemsetAsync(h->tickets, 0, sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES, s));
+            h->ticket_next = 0;
+        } else if (rs) {        // "not written yet" fill pattern of the dh partial inboxes
             HIPCK(h, hipMemsetAsync(h->inbox, 0xFF, sizeof(float) * (size_t)lstm_bwd_rs_inbox_floats(B, Hp), s));
         } else if (chain) {     // ... or of the dz fragments of every time step
             const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
@@ -713,11 +774,20 @@ int backward(fsmg_model* h, int B) {
             const int t0 = chunk_begin(h, c, nch), t1 = chunk_begin(h, c + 1, nch);
             if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[c], 0));
             ScopedTimer tm(h, "lstm_bwd");
+            if (xcd) {
+                LstmBwdXcdArgs a{};
+                a.KhXb = h->khx + (size_t)(2 * l + 1) * Hp * G4; a.inbox = h->inboxX; a.Z = h->Z[l]; a.Cs = h->Cs[l];
+                a.dc = h->dC; a.dH = h->dH; a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
+                HIPCK(h, launch_lstm_bwd_xcd(s, a));
+                ++h->n_xcd_launches;
+                continue;
+            }
             if (rs) {
                 LstmBwdRsArgs a{};
                 a.KhF = h->khf + (size_t)(2 * l + 1) * Hp * G4; a.inbox = h->inbox; a.Z = h->Z[l]; a.Cs = h->Cs[l];
                 a.dc = h->dC; a.dH = h->dH; a.err_flag = h->d_err; a.B = B; a.Hp = Hp; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_bwd_rs(s, a));
+                ++h->n_persist_launches;
                 continue;
             }
             if (chain) {
@@ -725,6 +795,7 @@ int backward(fsmg_model* h, int B) {
                 a.KhF = h->khf + (size_t)(2 * l + 1) * Hp * G4; a.dzF_all = h->dzF_all; a.Z = h->Z[l]; a.Cs = h->Cs[l];
                 a.dc = h->dC; a.dH = h->dH; a.err_flag = h->d_err; a.B = B; a.Hp = Hp; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_bwd_chain(s, a));
+                ++h->n_persist_launches;
                 continue;
             }
             for (int t = t1 - 1; t >= t0; --t) {
@@ -741,6 +812,7 @@ int backward(fsmg_model* h, int B) {
                 a.B = B; a.Hp = Hp;
                 HIPCK(h, launch_lstm_bwd_step(s, a));
             }
+            h->n_step_launches += t1 - t0;
         }
         const int in_p = h->in_dim[l];
         PHASE(5);
@@ -794,10 +866,13 @@ int apply_update(fsmg_model* h, float grad_scale) {
     a.grad_scale = grad_scale; a.lr = h->cfg.lr; a.n_decay = h->cfg.n_decay; a.clip = h->cfg.max_grad_norm;
     a.step = h->d_step; a.gnorm_out = h->d_gnorm; a.err_flag = h->d_err;
     HIPCK(h, launch_adam_update(s, a));
-    for (int l = 0; l < h->L; ++l)           // refresh the fragment-ordered recurrent weights
+    for (int l = 0; l < h->L; ++l) {         // refresh the fragment-ordered recurrent weights
         HIPCK(h, launch_repack_kh(s, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
                                   h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
-    HIPCK(h, launch_step_increment(s, h->d_step, h->G + h->n_flat + 1, grad_scale, h->d_ring, RING_CAP, h->d_err));
+        if (h->khx) HIPCK(h, launch_repack_kh_xcd(s, h->P + h->off_kh[l], h->khx + (size_t)(2 * l) * h->Hp * h->G4,
+                                                  h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4));
+    }
+    HIPCK(h, launch_step_increment(s, h->d_step, h->G + h->n_flat + 1, grad_scale, h->d_ring, RING_CAP, h->d_err, h->d_counters));
     PHASE(7);
 #ifdef FSMG_PHASE_DEBUG
     phase_report(h);
@@ -806,28 +881,50 @@ int apply_update(fsmg_model* h, float grad_scale) {
     return FSMG_OK;
 }
 
+// a persistent recurrent kernel gave up waiting for its peers (its blocks were not co-resident): one launch per time step
+// for the next `fallback_steps` train steps, then the persistent path is tried again
+void on_timeout(fsmg_model* h) {
+    ++h->n_timeouts;
+    h->persist_timed_out = true;
+    if (h->persist) { h->persist = false; drop_graphs(h); }
+    h->fallback_left = h->fallback_steps;
+}
+
+// Compares the host-mapped tallies of k_step_increment with what this handle has already seen (no synchronisation: the
+// caller decides whether the stream has been drained).  0 = nothing new, 2 = a train step was skipped after a time-out,
+// 1 = after a token-range error.
+int poll_skipped(fsmg_model* h) {
+    if (!h->host_counters) return 0;
+    const long long to = h->host_counters[0], tk = h->host_counters[1];
+    int what = 0;
+    if (tk != h->seen_token_errors) { h->seen_token_errors = tk; what = 1; }
+    if (to != h->seen_timeouts) { h->seen_timeouts = to; on_timeout(h); what = 2; }
+    return what;
+}
+
+int report(fsmg_model* h, int what) {
+    if (what == 2)
+        return fail(h, FSMG_ERR_HIP, "persistent recurrent kernel timed out waiting for a peer block (blocks not co-resident); "
+                                     "this handle now uses one launch per time step");
+    if (what == 1) return fail(h, FSMG_ERR_TOKEN_RANGE, "token id outside [0, input_size)");
+    return FSMG_OK;
+}
+
 int check_tokens_and_read(fsmg_model* h, const float* d_src, float scale, float* host_out, int n, bool train_tail = false) {
-    // one synchronising readback: loss value(s) + the token-range / time-out flag (+ for a train step the time-out
-    // indicator of the gradient tail, which after an all-reduce also reports OTHER ranks' time-outs)
+    // one synchronising readback: the loss value(s), then what went wrong.  After a train step k_step_increment has
+    // already tallied a skipped step (own or a peer rank's time-out, token-range error) in host-mapped memory and cleared
+    // the device flag; a forward-only pass leaves the flag for this function to read and clear.
     std::vector<float> tmp(n);
     int err = 0;
-    float peer_timeout = 0.0f;
     HIPCK(h, hipMemcpyAsync(tmp.data(), d_src, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipMemcpyAsync(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    if (train_tail) HIPCK(h, hipMemcpyAsync(&peer_timeout, h->G + h->n_flat + 2, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (!train_tail) HIPCK(h, hipMemcpyAsync(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
-    if (err == 0 && peer_timeout != 0.0f) err = 2;
-    if (err) {
+    if (train_tail) err = poll_skipped(h);
+    else if (err) {
         HIPCK(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
-        if (err == 2) {      // a persistent step kernel gave up waiting for its peers: fall back to one launch per step
-            h->persist = false;
-            h->persist_timed_out = true;
-            drop_graphs(h);
-            return fail(h, FSMG_ERR_HIP, "persistent recurrent kernel timed out waiting for a peer block (blocks not co-resident); "
-                                         "this handle now uses one launch per time step");
-        }
-        return fail(h, FSMG_ERR_TOKEN_RANGE, "token id outside [0, input_size)");
+        if (err == 2) on_timeout(h);
     }
+    if (err) return report(h, err);
     for (int i = 0; i < n; ++i) host_out[i] = tmp[i] * scale;
     return FSMG_OK;
 }
@@ -900,7 +997,11 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         const char* env = std::getenv("FSMG_OVERLAP");
         h->overlap = env ? (env[0] != '0') : ((int64_t)h->V1 >= 8LL * h->H * h->L);
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
+        h->persist_cfg = h->persist;
+        if (const char* e = std::getenv("FSMG_FALLBACK_STEPS")) h->fallback_steps = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("FSMG_BWD_RS")) h->bwd_rs = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_XCD")) h->xcd = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_XCD_MAX_ROWS")) h->xcd_max_rows = std::max(1, std::min(128, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_PERSIST_FWD")) h->persist_fwd = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_FWD_RT")) h->force_fwd_rt = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_PERSIST_BWD")) h->persist_bwd = (e[0] != '0');
@@ -939,11 +1040,16 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     if (hipMemsetAsync(h->state, 0, sb, h->stream) != hipSuccess) return bail(FSMG_ERR_HIP, "memset(state) failed");
 
     char* small = nullptr;
-    const size_t small_bytes = 256 * 4 + sizeof(float) * RING_CAP;
+    const size_t small_bytes = 256 * 4 + sizeof(float) * RING_CAP + sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES;
     if (hipMalloc((void**)&small, small_bytes) != hipSuccess) return bail(FSMG_ERR_NOMEM, "hipMalloc(scalars) failed");
     hipMemsetAsync(small, 0, small_bytes, h->stream);
     h->d_step = (long long*)small; h->d_err = (int*)(small + 256); h->d_gnorm = (float*)(small + 512);
     h->d_ring = (float*)(small + 1024);
+    if (hipHostMalloc((void**)&h->host_counters, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->d_counters, h->host_counters, 0) != hipSuccess)
+        return bail(FSMG_ERR_NOMEM, "hipHostMalloc(mapped step counters) failed");
+    std::memset(h->host_counters, 0, 64);
+    h->tickets = (int*)(small + 1024 + sizeof(float) * RING_CAP);
 
     // decode scratch: per layer h ping/pong + c, plus x and argmax block scratch
     {
@@ -953,6 +1059,10 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     }
     if (hipMalloc((void**)&h->khf, sizeof(float) * (size_t)h->L * 2 * h->Hp * h->G4) != hipSuccess)
         return bail(FSMG_ERR_NOMEM, "hipMalloc(fragment weights) failed");
+    if (h->persist && h->xcd && lstm_xcd_supported(1, h->Hp)) {
+        if (hipMalloc((void**)&h->khx, sizeof(float) * (size_t)h->L * 2 * lstm_xcd_weight_floats()) != hipSuccess)
+            return bail(FSMG_ERR_NOMEM, "hipMalloc(XCD-local weight images) failed");
+    }
     const int b0 = cfg->max_sequences > 0 ? cfg->max_sequences : 45;
     if (ensure_scratch(h, b0) != FSMG_OK) { std::string e = h->err; return bail(FSMG_ERR_NOMEM, e); }
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(FSMG_ERR_HIP, "stream sync failed");
@@ -971,7 +1081,9 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->d_step) hipFree(h->d_step);
     if (h->dec) hipFree(h->dec);
     if (h->khf) hipFree(h->khf);
+    if (h->khx) hipFree(h->khx);
     if (h->d_eval) hipFree(h->d_eval);
+    if (h->host_counters) hipHostFree(h->host_counters);
     if (h->own_state && h->state) hipFree(h->state);
     for (int c = 0; c < fsmg_model::NCHUNK; ++c) if (h->ev_chunk[c]) hipEventDestroy(h->ev_chunk[c]);
     if (h->ev_bucket[0]) hipEventDestroy(h->ev_bucket[0]);
@@ -1065,6 +1177,7 @@ int fsmg_get_step(fsmg_handle h, int64_t* global_step) {
     long long v = 0;
     HIPCK(h, hipStreamSynchronize(h->stream));
     HIPCK(h, hipMemcpy(&v, h->d_step, sizeof(v), hipMemcpyDeviceToHost));
+    poll_skipped(h);
     *global_step = v;
     return FSMG_OK;
 }
@@ -1081,6 +1194,10 @@ int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* 
     int rc = validate_shape(h, N, K, Q);
     if (rc != FSMG_OK) return rc;
     const int B = N * (K + Q);
+    if (h->fallback_left > 0 && --h->fallback_left == 0 && h->persist != h->persist_cfg) {   // try the persistent path again
+        h->persist = h->persist_cfg;
+        drop_graphs(h);
+    }
     if ((rc = ensure_scratch(h, B)) != FSMG_OK) return rc;
     if ((rc = ensure_khf(h)) != FSMG_OK) return rc;
     if ((rc = stage_tokens(h, support, N * K, query, N * Q, tokens_on_device)) != FSMG_OK) return rc;
@@ -1134,6 +1251,10 @@ int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss) {
     if (rc != FSMG_OK) return rc;
     h->have_grads = false;
     if (loss) return check_tokens_and_read(h, h->G + h->n_flat + 1, grad_scale, loss, 1, true);
+    // no read-back: skipped steps of EARLIER calls that have retired by now are noticed here (a time-out switches the
+    // handle to per-step launches; the skipped episodes stay skipped -- fsmg_get_stats counts them)
+    const int what = poll_skipped(h);
+    if (what == 1) return report(h, 1);
     return FSMG_OK;
 }
 
@@ -1173,6 +1294,7 @@ int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, i
         HIPCK(h, hipMalloc((void**)&h->d_eval, sizeof(float) * chunk_eps));
         h->eval_cap = chunk_eps;
     }
+    bool retried = false;
     for (int e0 = 0; e0 < n_episodes; e0 += chunk_eps) {
         const int ne = std::min(chunk_eps, n_episodes - e0);
         const int B = ne * per;
@@ -1185,7 +1307,17 @@ int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, i
         });
         if (rc != FSMG_OK) return rc;
         h->lastB = B;
-        if ((rc = check_tokens_and_read(h, h->d_eval, 1.0f, nll + e0, ne)) != FSMG_OK) return rc;
+        rc = check_tokens_and_read(h, h->d_eval, 1.0f, nll + e0, ne);
+        if (rc == FSMG_ERR_HIP && h->persist_timed_out && !retried) {
+            // a persistent kernel could not get its blocks resident: the handle has switched to one launch per time
+            // step; repeat this chunk that way (validation must not abort a training run, nor leave peer ranks hanging)
+            h->persist_timed_out = false;
+            retried = true;
+            e0 -= chunk_eps;
+            continue;
+        }
+        if (rc != FSMG_OK) return rc;
+        retried = false;
     }
     return FSMG_OK;
 }
@@ -1241,8 +1373,26 @@ int fsmg_read_losses(fsmg_handle h, float* out, int32_t n) {
     HIPCK(h, hipStreamSynchronize(h->stream));
     HIPCK(h, hipMemcpy(ring.data(), h->d_ring, sizeof(float) * RING_CAP, hipMemcpyDeviceToHost));
     HIPCK(h, hipMemcpy(&step, h->d_step, sizeof(step), hipMemcpyDeviceToHost));
+    poll_skipped(h);
     if (step < n) return fail(h, FSMG_ERR_INVALID, "fewer train steps than requested losses");
     for (int i = 0; i < n; ++i) out[i] = ring[(step - n + i) % RING_CAP];
+    return FSMG_OK;
+}
+
+int fsmg_get_stats(fsmg_handle h, fsmg_stats* out) {
+    if (!h || !out) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    poll_skipped(h);
+    std::memset(out, 0, sizeof(*out));
+    out->timeouts = h->n_timeouts;
+    out->steps_skipped_timeout = h->host_counters ? h->host_counters[0] : 0;
+    out->steps_skipped_token_range = h->host_counters ? h->host_counters[1] : 0;
+    out->xcd_launches = h->n_xcd_launches;
+    out->persistent_launches = h->n_persist_launches;
+    out->step_launches = h->n_step_launches;
+    out->persistent_path = h->persist ? 1 : 0;
+    out->fallback_steps_left = h->fallback_left;
     return FSMG_OK;
 }
 

@@ -145,6 +145,7 @@ struct LstmFwdXcdArgs {
     int* err_flag;
     int B, T, t0, t1;
     int spin_limit;
+    unsigned long long* prof;   // != nullptr: instrumented build, [256 blocks][4 waves][8] tick sums per phase (RG = 2 only)
 };
 struct LstmBwdXcdArgs {
     const float* KhXb;    // backward register image of K_h
@@ -157,6 +158,7 @@ struct LstmBwdXcdArgs {
     int* err_flag;
     int B, T, t0, t1;
     int spin_limit;
+    unsigned long long* prof;
 };
 bool lstm_xcd_supported(int B, int Hp);
 long long lstm_xcd_hx_floats(int B, int T);
@@ -195,11 +197,14 @@ struct UpdateArgs {
     float lr, n_decay, clip;
     const long long* step;                        // global_step BEFORE this update (device)
     float* gnorm_out;                             // optional: pre-clip global norm
-    const int* err_flag;                          // optional: *err_flag == 2 (a persistent step kernel gave up) -> no update
+    const int* err_flag;                          // optional: *err_flag != 0 (a persistent step kernel gave up / a token id was out of range) -> no update
 };
 hipError_t launch_adam_update(hipStream_t s, const UpdateArgs& a);
+// last kernel of a train step: counts the step (ring[step % cap] = loss, ++step) or, when *err_flag != 0 or the
+// all-reduced time-out indicator tail[2] is set, tallies it in counters ([0] time-outs, [1] token-range rejections;
+// host-mapped memory) and clears the flag
 hipError_t launch_step_increment(hipStream_t s, long long* step, const float* loss_src, float loss_scale,
-                                 float* loss_ring, int ring_cap, const int* err_flag = nullptr);
+                                 float* loss_ring, int ring_cap, int* err_flag, long long* counters);
 // dst[0] = (float) sum of partials[0..n) (fixed order)
 hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst, const int* flag_src = nullptr);
 // greedy decode step pieces (sample)

@@ -82,7 +82,10 @@ __device__ __forceinline__ bool take_role(int* tickets, int* err_flag, int* s_ro
 //     (w = c/8, q = (c/4)%2) as 256 contiguous bytes.  Index 0 is the zero state, indices t0+1 .. t1 are pre-filled
 //     with the "not written" pattern.
 // KhX [32 cu][4 w][32][64 lanes][4]: register image of the weights, see k_repack_kh_xcd.
-template <int RG>
+// PROF: per (block, wave) sums of s_memtime ticks over the steps: [0] wait for h_t, [1] MFMAs, [2] partials -> LDS + barrier,
+// [3] cell update up to the hand-off store, [4] rest of the step (diagnostic build, tools/xcd_chain_bench.cpp)
+#define XCD_STAMP(i) if (PROF) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc[i] += n_ - plast; plast = n_; }
+template <int RG, bool PROF>
 __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd(const LstmFwdXcdArgs a) {
     __shared__ float red[2][4][RG][4 * PLANE];
     __shared__ int s_role[2];
@@ -114,8 +117,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd(const LstmFwdXcdArgs a)
     f32x4* hx_out = reinterpret_cast<f32x4*>(a.HX) + ((((size_t)xcd * 4 + (cu >> 3)) * RG + wave) * 2 + ((cu >> 2) & 1)) * 64 +
                     16 * (cu & 3) + 4 * cbb + ci;
     const int wofs = ((lane >> 2) & 3) * PLANE + (lane >> 4) * 4 + (lane & 3);   // writer: gate plane, unit block, unit%4
+    unsigned long long pacc[5] = {0, 0, 0, 0, 0}, plast = PROF ? __builtin_amdgcn_s_memtime() : 0;
 
     for (int t = a.t0; t < a.t1; ++t) {
+        XCD_STAMP(4)
         float zin[4] = {0.f, 0.f, 0.f, 0.f};
         float* zp = a.Z + ((size_t)t * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
         if (act) {
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd(const LstmFwdXcdArgs a)
                 s_fail = 1;
             }
         }
+        XCD_STAMP(0)
         f32x4 acc[RG];
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -141,6 +147,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd(const LstmFwdXcdArgs a)
             XCD_FWD_B(8) XCD_FWD_B(9) XCD_FWD_B(10) XCD_FWD_B(11) XCD_FWD_B(12) XCD_FWD_B(13) XCD_FWD_B(14) XCD_FWD_B(15)
         }
 #undef XCD_FWD_B
+        if (PROF) { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); acc[0][0] += 0.0f; }
+        XCD_STAMP(1)
         // D layout of a 4x4 block: lane = 4*block + column, register = row
         {
             float* rp = &red[t & 1][wave][0][0];
@@ -151,6 +159,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd(const LstmFwdXcdArgs a)
         }
         __syncthreads();
         if (s_fail) return;
+        XCD_STAMP(2)
 
         if (cellw) {
             float hn = 0.0f, g_si = 0.f, g_tj = 0.f, g_sf = 0.f, g_so = 0.f;
@@ -172,12 +181,17 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd(const LstmFwdXcdArgs a)
             f32x4 hv;
             hv[0] = quad_bcast<0>(hn); hv[1] = quad_bcast<1>(hn); hv[2] = quad_bcast<2>(hn); hv[3] = quad_bcast<3>(hn);
             if (ce == 0) store_l2(hx_out + (size_t)(t + 1) * hx_step, hv);
+            XCD_STAMP(3)
             if (act) {
                 a.Cs[((size_t)(t + 1) * B + row) * XH + unit] = cp;
                 a.Hs[((size_t)(t + 1) * B + row) * XH + unit] = hn;
                 zp[0] = g_si; zp[4] = g_tj; zp[8] = g_sf; zp[12] = g_so;       // activated gates kept for BPTT
             }
         }
+    }
+    if (PROF && lane == 0 && a.prof) {
+        XCD_STAMP(4)
+        for (int i = 0; i < 5; ++i) a.prof[((size_t)(xcd * NCU + cu) * 4 + wave) * 8 + i] = pacc[i];
     }
 }
 
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd(const LstmFwdXcdArgs a)
 //      stores: same XCD).  The resets of phase A are drained before these stores; two slots suffice because progress
 //      of every block depends on every other block's publish (same argument as k_lstm_bwd_rs).
 // inbox [2 slots][8 xcd][32 dest][32 producer][RG][16 units][4 rows].
-template <int RG>
+template <int RG, bool PROF>
 __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd(const LstmBwdXcdArgs a) {
     constexpr int NG = 4 / RG;                    // lane groups of a wave that read different producers of one row group
     constexpr int LPW = 2 * RG;                   // inbox words per lane: 8 producers x RG x 16 units / 64 lanes
@@ -231,8 +245,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd(const LstmBwdXcdArgs a)
     for (int cg = 0; cg < 2; ++cg)
         out_ofs[cg] = ((((size_t)xcd * NCU + 8 * wave + 4 * cg + (lane >> 4)) * NCU + cu) * RG) * 16 + (lane & 15);
     const f32x4 fill = f32x4{__uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu)};
+    unsigned long long pacc[5] = {0, 0, 0, 0, 0}, plast = PROF ? __builtin_amdgcn_s_memtime() : 0;
 
     for (int t = a.t1 - 1; t >= a.t0; --t) {
+        XCD_STAMP(4)
         float si = 0.f, tj = 0.f, sf = 0.f, so = 0.f, ct = 0.f, cpv = 0.f, dht = 0.f;
         float* gp = a.Z + ((size_t)t * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
         if (act) {
@@ -267,9 +283,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd(const LstmBwdXcdArgs a)
                 wsum = (k == 0) ? v[0] : wsum + v[k];
             }
         }
+        XCD_STAMP(0)
         *reinterpret_cast<f32x4*>(&psum[(wave * 64 + lane) * 4]) = wsum;
         __syncthreads();
         if (s_fail) return;
+        XCD_STAMP(1)
 
         // ---- B: gate gradients (wave rg < RG: lane = 16 i + 4 bb + e)
         if (cellw) {
@@ -291,6 +309,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd(const LstmBwdXcdArgs a)
             f[0] = di; f[16 * 4] = dj; f[32 * 4] = df; f[48 * 4] = dg;
         }
         __syncthreads();
+        XCD_STAMP(2)
 
         // ---- C: produce the partials of dh_{t-1}
         if (t > 0) {
@@ -316,6 +335,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd(const LstmBwdXcdArgs a)
             // are inserted by hand
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            XCD_STAMP(3)
             drain_vmem();                                             // the resets of phase A have landed
             f32x4* out = inbox + (size_t)(t & 1) * slot_w;
 #pragma unroll
@@ -326,7 +346,12 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd(const LstmBwdXcdArgs a)
         }
     }
     if (act) a.dc[hi] = dcv;
+    if (PROF && lane == 0 && a.prof) {
+        XCD_STAMP(4)
+        for (int i = 0; i < 5; ++i) a.prof[((size_t)(xcd * NCU + cu) * 4 + wave) * 8 + i] = pacc[i];
+    }
 }
+#undef XCD_STAMP
 
 // Kh [512][2048] (packed gate columns) -> the register images of the two XCD-local kernels:
 //   fwd word i (= 16q + b), component e of (cu, w), lane l:  Kh[128w + 64q + 16(b/4) + 4(b%4) + e][64cu + l]
@@ -373,10 +398,15 @@ hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, floa
 hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {
     if (a.t1 <= a.t0) return hipSuccess;
     const dim3 grid(NXCD * NCU), block(256);
+    if (a.prof) {
+        if (xcd_row_groups(a.B) != 2) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_lstm_fwd_xcd<2, true>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     switch (xcd_row_groups(a.B)) {
-        case 1: hipLaunchKernelGGL((k_lstm_fwd_xcd<1>), grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_lstm_fwd_xcd<2>), grid, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL((k_lstm_fwd_xcd<4>), grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_lstm_fwd_xcd<1, false>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_lstm_fwd_xcd<2, false>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_lstm_fwd_xcd<4, false>), grid, block, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -385,10 +415,15 @@ hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {
 hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a) {
     if (a.t1 <= a.t0) return hipSuccess;
     const dim3 grid(NXCD * NCU), block(256);
+    if (a.prof) {
+        if (xcd_row_groups(a.B) != 2) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_lstm_bwd_xcd<2, true>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     switch (xcd_row_groups(a.B)) {
-        case 1: hipLaunchKernelGGL((k_lstm_bwd_xcd<1>), grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_lstm_bwd_xcd<2>), grid, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL((k_lstm_bwd_xcd<4>), grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_lstm_bwd_xcd<1, false>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_lstm_bwd_xcd<2, false>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_lstm_bwd_xcd<4, false>), grid, block, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -31,6 +31,12 @@ class FsmgConfig(C.Structure):
                 ('stream', C.c_void_p), ('state_arena', C.c_void_p), ('state_arena_bytes', C.c_uint64)]
 
 
+class FsmgStats(C.Structure):
+    _fields_ = [('timeouts', C.c_int64), ('steps_skipped_timeout', C.c_int64), ('steps_skipped_token_range', C.c_int64),
+                ('xcd_launches', C.c_int64), ('persistent_launches', C.c_int64), ('step_launches', C.c_int64),
+                ('persistent_path', C.c_int32), ('fallback_steps_left', C.c_int32)]
+
+
 _P = C.c_void_p
 _I32P = C.POINTER(C.c_int32)
 _F32P = C.POINTER(C.c_float)
@@ -62,6 +68,7 @@ SIGNATURES = {
     'fsmg_eval_batch': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F32P]),
     'fsmg_sample': (C.c_int, [_P, C.c_int32, _I32P]),
     'fsmg_read_losses': (C.c_int, [_P, _F32P, C.c_int32]),
+    'fsmg_get_stats': (C.c_int, [_P, C.POINTER(FsmgStats)]),
     'fsmg_debug_read': (C.c_int, [_P, C.c_char_p, _F32P, C.c_int64]),
     'fsmg_debug_dims': (C.c_int, [_P, _I32P]),
     'fsmg_debug_step_profile': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint64), C.c_int64, _I32P, _I32P]),
@@ -291,6 +298,11 @@ class FsmgModel(object):
         out = np.empty(n, np.float32)
         self._ck(self._lib.fsmg_read_losses(self._h, _f32p(out), n))
         return out
+
+    def stats(self):
+        st = FsmgStats()
+        self._ck(self._lib.fsmg_get_stats(self._h, C.byref(st)))
+        return {name: int(getattr(st, name)) for name, _ in FsmgStats._fields_}
 
     def synchronize(self):
         self._ck(self._lib.fsmg_synchronize(self._h))

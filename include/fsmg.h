@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FSMG_VERSION 100 /* 0.1.0 */
+#define FSMG_VERSION 200 /* 0.2.0 */
 
 enum {
     FSMG_OK = 0,
@@ -152,6 +152,24 @@ int fsmg_sample(fsmg_handle h, int32_t num, int32_t* out_tokens);
 
 /* last n train losses (oldest first), n <= 1024; synchronises the stream */
 int fsmg_read_losses(fsmg_handle h, float* out, int32_t n);
+
+/* What the handle has been doing (synchronises the stream).  A train step whose persistent recurrent kernel timed out
+ * (its blocks were not co-resident: another workload held the CUs) or whose batch held an out-of-range token is SKIPPED
+ * on the device -- parameters, Adam state, global_step untouched -- and tallied here; after a time-out the handle runs
+ * `fallback` train steps with one launch per time step and then tries the persistent kernels again.  With loss != NULL
+ * fsmg_train_step repeats a timed-out step itself; with loss == NULL the episode stays skipped, so a throughput loop
+ * must compare fsmg_get_step / these counters with the number of steps it issued (bench.py does). */
+typedef struct fsmg_stats {
+    int64_t timeouts;                   /* time-outs noticed by the host (each one starts a fallback period)        */
+    int64_t steps_skipped_timeout;      /* train steps the device skipped because of a time-out (own or a peer rank) */
+    int64_t steps_skipped_token_range;  /* train steps the device skipped because a token id was out of range        */
+    int64_t xcd_launches;               /* launches of the XCD-local persistent kernels (hidden size 512)            */
+    int64_t persistent_launches;        /* launches of the column-split persistent kernels                           */
+    int64_t step_launches;              /* one-launch-per-time-step recurrent launches                               */
+    int32_t persistent_path;            /* 1: persistent kernels are in force right now                              */
+    int32_t fallback_steps_left;
+} fsmg_stats;
+int fsmg_get_stats(fsmg_handle h, fsmg_stats* out);
 
 /* ---- introspection for kernel-level parity tests and bench.py --------------------------- */
 /* copy an internal activation buffer of the last forward to the host, float32:

@@ -27,7 +27,10 @@ SHAPES = [
     (dict(hidden_size=128, embedding_size=24, input_size=90, max_len=7), 5, 5, 4),               # Hp = 128, 3 row tiles: 2 k-groups per wave
     (dict(hidden_size=128, embedding_size=16, input_size=80, max_len=5), 20, 1, 4),               # 100 rows = 7 row tiles (cfg-D's episode shape) on the persistent kernels
     (dict(hidden_size=256, embedding_size=16, input_size=70, max_len=5), 4, 3, 2),                # Hp = 256: reduce-scatter BPTT kernel with 2 destination tiles per wave
-    (dict(hidden_size=512, embedding_size=16, input_size=60, max_len=4), 2, 1, 1),                # Hp = 512 (cfg-B's recurrent shape): 4 per wave
+    (dict(hidden_size=512, embedding_size=16, input_size=60, max_len=4), 2, 1, 1),                # Hp = 512 (cfg-B's recurrent shape): XCD-local kernels, 1 row group (4 rows on 4 XCDs)
+    (dict(hidden_size=512, embedding_size=16, input_size=60, max_len=6), 5, 5, 4),                # ... 45 rows = 6 per XCD (3 on the last): 2 row groups, cfg-B's episode shape
+    (dict(hidden_size=512, embedding_size=16, input_size=60, max_len=5), 20, 1, 4),               # ... 100 rows = 13 per XCD (9 on the last): 4 row groups, cfg-D's episode shape
+    (dict(hidden_size=512, embedding_size=16, input_size=60, max_len=5, n_layers=2), 3, 3, 2),    # ... stacked: 15 rows = 2 per XCD (1 on the last)
     (dict(hidden_size=1024, embedding_size=16, input_size=60, max_len=4, n_layers=2), 2, 1, 1),   # Hp = 1024 (cfg-C's): 8 per wave, forward per step
     (dict(hidden_size=16, embedding_size=8, input_size=12500, max_len=4), 2, 1, 1),   # vocab rows > 12288 floats: 3-pass CE kernel
     (dict(hidden_size=16, embedding_size=8, input_size=7000, max_len=4), 2, 1, 1),    # 6144 < row <= 12288: 12-register CE kernel
@@ -273,6 +276,39 @@ def test_persistent_kernel_timeout_falls_back_and_repeats_the_step(monkeypatch):
     assert model2.step == 0
     model2.forward_backward(*eps[0])
     assert model2.apply_update(1.0) == want[0]
+
+
+def test_xcd_local_and_column_split_kernels_agree_and_fall_back(monkeypatch):
+    """Hidden size 512 takes the XCD-local recurrence (csrc/lstm_xcd.hip) by default.  FSMG_XCD=0 keeps the column-split
+    persistent kernels: a different summation order (K split 4 x 128 per wave in both, but 16-wide k groups in another
+    order), so not the same bits -- both within the bar of the oracle and 1e-5 of each other after three updates.  A forced
+    time-out (FSMG_CHAIN_SPIN_LIMIT=0) makes the handle repeat the step with one launch per time step."""
+    cfg = small_config(hidden_size=512, embedding_size=32, input_size=150, max_len=12)
+    eps = O.synthetic_episodes(3, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=31)
+    out = {}
+    for xcd in ('1', '0'):
+        monkeypatch.setenv('FSMG_XCD', xcd)
+        model = new_model(cfg)
+        params = f64_params(model)
+        opt = O.new_opt_state(params)
+        losses = []
+        for s_, q_ in eps:
+            want = O.train_step(params, opt, s_, q_, cfg)
+            got = model.train_step(s_, q_)
+            assert abs(got - want) <= NLL_RTOL * abs(want)
+            losses.append(got)
+        stats = model.stats()
+        assert (stats['xcd_launches'] > 0) == (xcd == '1') and stats['timeouts'] == 0
+        out[xcd] = (losses, model.get_params())
+    for a, b in zip(out['1'][0], out['0'][0]):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    monkeypatch.setenv('FSMG_XCD', '1')
+    monkeypatch.setenv('FSMG_CHAIN_SPIN_LIMIT', '0')
+    model = new_model(cfg)
+    got = [model.train_step(s_, q_) for s_, q_ in eps]
+    assert model.step == 3 and model.stats()['timeouts'] == 1
+    for a, b in zip(got, out['1'][0]):
+        assert abs(a - b) <= 1e-5 * abs(b)
 
 
 def test_training_keeps_the_persistent_path_after_a_large_validation_batch():

@@ -327,7 +327,7 @@ static int run_case(int B, int Tcheck, int Ttime) {
     {
         const int T = Ttime;
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        const double mflop = 2.0 * B * H * G4 / 1e6;
+        const double mflop = 2.0 * B * H * G4 / 1e6 * 1e3;   // so that mflop * T / ms / 1e6 = TFLOP/s
         for (int nchunk : {1, 4}) {
             float best_f = 1e9f, best_b = 1e9f;
             for (int rep = 0; rep < 6; ++rep) {
@@ -354,8 +354,42 @@ static int run_case(int B, int Tcheck, int Ttime) {
             }
             const int e = read_err();
             printf("[4] B=%d xcd-local, %d launch(es) per chain, T=%d: fwd %.3f ms = %.2f us/step = %.1f TFLOP/s (%.1f%% of 157.3) | bwd %.3f ms = %.2f us/step = %.1f TFLOP/s (%.1f%%)  err_flag %d\n",
-                   B, nchunk, T, best_f, best_f * 1e3 / T, mflop * T / best_f / 1e3 / 1e3, mflop * T / best_f / 1e6 / 157.3 * 100, best_b, best_b * 1e3 / T,
+                   B, nchunk, T, best_f, best_f * 1e3 / T, mflop * T / best_f / 1e6, mflop * T / best_f / 1e6 / 157.3 * 100, best_b, best_b * 1e3 / T,
                    mflop * T / best_b / 1e6, mflop * T / best_b / 1e6 / 157.3 * 100, e);
+            CK(hipMemset(d.err, 0, 4));
+        }
+        if (B == 45) {       // phase profile of the instrumented build (RG = 2)
+            unsigned long long* prof; CK(hipMalloc(&prof, 8ull * 256 * 4 * 8));
+            std::vector<unsigned long long> hp(256 * 4 * 8);
+            for (int dir = 0; dir < 2; ++dir) {
+                CK(hipMemset(prof, 0, 8ull * 256 * 4 * 8));
+                if (dir == 0) {
+                    fwd_xcd(T, 0);
+                    LstmFwdXcdArgs a{};
+                    a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof;
+                    CK(launch_lstm_fwd_xcd(s, a));
+                } else {
+                    bwd_xcd(T, 0);
+                    LstmBwdXcdArgs a{};
+                    a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof;
+                    CK(launch_lstm_bwd_xcd(s, a));
+                }
+                CK(hipStreamSynchronize(s));
+                CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
+                const char* names_f[5] = {"wait h_t", "MFMA", "LDS+barrier", "cell->store", "rest"};
+                const char* names_b[5] = {"wait inbox", "psum+barrier", "cell+dzA+barrier", "LDS read+MFMA", "drain+stores+rest"};
+                for (int wc = 0; wc < 2; ++wc) {        // cell waves (0,1) vs the others (2,3)
+                    double m[5] = {0, 0, 0, 0, 0};
+                    for (int b = 0; b < 256; ++b) for (int w = 2 * wc; w < 2 * wc + 2; ++w) for (int i = 0; i < 5; ++i) m[i] += (double)hp[((size_t)b * 4 + w) * 8 + i];
+                    printf("[4] %s phase ticks per step, waves %d-%d:", dir ? "bwd" : "fwd", 2 * wc, 2 * wc + 1);
+                    double tot = 0;
+                    for (int i = 0; i < 5; ++i) { printf("  %s %.0f", dir ? names_b[i] : names_f[i], m[i] / 512 / T); tot += m[i] / 512 / T; }
+                    printf("  | total %.0f\n", tot);
+                }
+            }
+            hipFree(prof);
             CK(hipMemset(d.err, 0, 4));
         }
         if (lstm_fwd_chain_supported(B, H)) {
