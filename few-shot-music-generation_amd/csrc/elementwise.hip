@@ -23,6 +23,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---------------------------------------------------------------- fill
+// 32-bit pattern fill with 16-byte stores.  Used instead of hipMemsetAsync inside the step: a step is captured into a
+// hipGraph, and on ROCm 7.2 a replayed graph with this step's memset nodes left 16-byte garbage patterns in the zero
+// state block of the hidden states from the second launch on (tools/race_hunt2.py) -- a kernel node has no such surprises.
+__global__ __launch_bounds__(256) void k_fill32(uint32_t* __restrict__ p, uint32_t word, long long n) {
+    const long long n4 = n >> 2;
+    const uint4 w4 = make_uint4(word, word, word, word);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        reinterpret_cast<uint4*>(p)[i] = w4;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = word;
+}
+
 // ---------------------------------------------------------------- token prep (K0)
 // Reference: convert_tokens_to_input_and_target + concat (src/models/base_model.py:63-86,
 // src/models/lstm_baseline.py:91-96).  One thread per (sequence b, step t): coalesced reads
@@ -469,6 +481,15 @@ hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX
     if (n <= 0) return hipSuccess;
     if (Ep > 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_embed_grad, dim3(n), dim3(256), 0, s, X, n, dX, Ep, dEmb);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill32(hipStream_t s, void* p, uint32_t word, long long n_words) {
+    if (n_words <= 0) return hipSuccess;
+    long long blocks = (n_words / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_fill32, dim3((int)blocks), dim3(256), 0, s, (uint32_t*)p, word, n_words);
     return hipGetLastError();
 }
 

@@ -123,6 +123,8 @@ struct fsmg_model {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_bucket[2] = {};       // [0] softmax gradients final, [1] backward complete
     bool overlap = true;                // FSMG_OVERLAP=0 disables the two-stream schedule
+    bool overlap_forced = false;        // FSMG_OVERLAP was set: no per-call decision
+    bool ov_call = false;               // the decision for the call in progress (choose_schedule)
     int64_t slab_cap = 0;
     // whole-phase hipGraphs, keyed by the shape of the call; dropped when scratch moves
     std::map<std::string, hipGraphExec_t> graphs;
@@ -317,6 +319,8 @@ int download_tensor(fsmg_model* h, const float* flat, const char* name, float* h
 // slot efficiency of tiles*S blocks over the resident-block slots, plus S slabs of C written and read back.
 constexpr int MAX_SPLIT = 16;
 int pick_split(int64_t M, int64_t N, int64_t K, int64_t slots = 0) {
+    static const int max_split_env = std::getenv("FSMG_MAX_SPLIT") ? std::max(1, std::atoi(std::getenv("FSMG_MAX_SPLIT"))) : MAX_SPLIT;   // debugging knob
+    if (max_split_env <= 1) return 1;
     if (slots <= 0) slots = gemm_block_slots();
     const int64_t tm = gemm_tile_m();
     const int64_t tiles = ((M + tm - 1) / tm) * ((N + 127) / 128);
@@ -485,7 +489,7 @@ template <class F>
 int run_graphed(fsmg_model* h, const std::string& key, F&& body) {
     // hipGraph (ROCm 7.2) runs captured cross-stream branches one after the other, so the two-stream
     // schedule only overlaps with eager launches
-    if (!h->cfg.use_graph || h->timing || h->overlap) return body();
+    if (!h->cfg.use_graph || h->timing || h->ov_call) return body();
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -548,7 +552,7 @@ inline int chunk_begin(const fsmg_model* h, int c, int nch) {
     if (!h->chunk_edges.empty() && (int)h->chunk_edges.size() == nch + 1) return h->chunk_edges[c];
     return (int)((int64_t)c * h->T / nch);
 }
-inline bool use_overlap(const fsmg_model* h) { return h->overlap && !h->timing && h->aux != nullptr && h->T >= std::max(h->nchunk, h->nchunk_persist); }
+inline bool use_overlap(const fsmg_model* h) { return h->ov_call && !h->timing && h->aux != nullptr && h->T >= std::max(h->nchunk, h->nchunk_persist); }
 
 #ifdef FSMG_PHASE_DEBUG
 // compile-time debugging aid (make EXTRA=-DFSMG_PHASE_DEBUG): GPU time of the phases of the eager overlap
@@ -576,6 +580,12 @@ inline bool use_xcd(const fsmg_model* h, int B) {
     return h->persist && h->xcd && h->khx != nullptr && h->HX != nullptr && B <= h->xcd_max_rows && lstm_xcd_supported(B, h->Hp) &&
            lstm_xcd_hx_floats(B, h->T) <= h->hx_floats && lstm_xcd_inbox_floats(B) <= h->inboxx_floats;
 }
+// Two-stream (eager) or single-stream (hipGraph replay) order for a pass over B sequences.  The XCD-local recurrent kernels
+// put a high-priority wave on every SIMD of the chip and spend half of their time in hand-offs; GEMM waves beside them
+// stretch both (measured at cfg-B: 374-379 episodes/s two-stream with 1-4 chunks against 383-385 single-stream), so a pass
+// that takes them runs single-stream; the per-step kernels of big validation batches keep the overlap.
+inline void choose_schedule(fsmg_model* h, int B) { h->ov_call = h->overlap && (h->overlap_forced || !use_xcd(h, B)); }
+
 // every XCD-local launch of a pass gets its own 8 zeroed ticket counters
 inline int* next_tickets(fsmg_model* h) {
     int* t = h->tickets + 8 * (h->ticket_next % fsmg_model::TICKET_LAUNCHES);
@@ -630,9 +640,9 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     for (int l = 0; l < h->L; ++l) {
         const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
         const bool top = l == h->L - 1;
-        HIPCK(h, hipMemsetAsync(h->Hs[l], 0, sizeof(float) * (size_t)B * Hp, s));
-        HIPCK(h, hipMemsetAsync(h->HF[l], 0, sizeof(float) * Bp16 * Hp, s));
-        HIPCK(h, hipMemsetAsync(h->Cs[l], 0, sizeof(float) * (size_t)B * Hp, s));
+        HIPCK(h, launch_fill32(s, h->Hs[l], 0u, (long long)((sizeof(float) * (size_t)B * Hp) / 4)));
+        HIPCK(h, launch_fill32(s, h->HF[l], 0u, (long long)((sizeof(float) * Bp16 * Hp) / 4)));
+        HIPCK(h, launch_fill32(s, h->Cs[l], 0u, (long long)((sizeof(float) * (size_t)B * Hp) / 4)));
         {
             ScopedTimer tm(h, "gemm_zx");
             GemmArgs g{};
@@ -645,13 +655,13 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
         }
         PHASE(1);
         if (chain)       // "not written yet" fill pattern of the h fragments of time indices 1..T (index 0 is the zero state)
-            HIPCK(h, hipMemsetAsync(h->HF[l] + Bp16 * Hp, 0xFF, sizeof(float) * (size_t)T * Bp16 * Hp, s));
+            HIPCK(h, launch_fill32(s, h->HF[l] + Bp16 * Hp, 0xFFFFFFFFu, (long long)((sizeof(float) * (size_t)T * Bp16 * Hp) / 4)));
         if (xcd) {       // the same for the XCD-local hand-off buffer, and fresh ticket counters for this layer's launches
-            HIPCK(h, hipMemsetAsync(h->tickets, 0, sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES, s));
+            HIPCK(h, launch_fill32(s, h->tickets, 0u, (long long)((sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES) / 4)));
             h->ticket_next = 0;
             const size_t step_f = (size_t)lstm_xcd_hx_floats(B, 0);
-            HIPCK(h, hipMemsetAsync(h->HX, 0, sizeof(float) * step_f, s));
-            HIPCK(h, hipMemsetAsync(h->HX + step_f, 0xFF, sizeof(float) * step_f * T, s));
+            HIPCK(h, launch_fill32(s, h->HX, 0u, (long long)((sizeof(float) * step_f) / 4)));
+            HIPCK(h, launch_fill32(s, h->HX + step_f, 0xFFFFFFFFu, (long long)((sizeof(float) * step_f * T) / 4)));
         }
         for (int c = 0; c < nch; ++c) {
             const int t0 = chunk_begin(h, c, nch), t1 = chunk_begin(h, c + 1, nch);
@@ -738,7 +748,7 @@ int backward(fsmg_model* h, int B) {
     const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
     const Lane auxl = aux_lane(h, false, chain);
     PHASE(3);
-    HIPCK(h, hipMemsetAsync(h->G + h->off_emb, 0, sizeof(float) * (size_t)h->V1 * h->Ep, s));
+    HIPCK(h, launch_fill32(s, h->G + h->off_emb, 0u, (long long)((sizeof(float) * (size_t)h->V1 * h->Ep) / 4)));
     if (ov) {
         // aux: dH chunks in the order BPTT consumes them (last chunk first), then dW
         HIPCK(h, hipEventRecord(h->ev_fork, s));
@@ -757,18 +767,18 @@ int backward(fsmg_model* h, int B) {
     }
     for (int l = h->L - 1; l >= 0; --l) {
         const bool top = l == h->L - 1;
-        HIPCK(h, hipMemsetAsync(h->dC, 0, sizeof(float) * (size_t)B * Hp, s));
+        HIPCK(h, launch_fill32(s, h->dC, 0u, (long long)((sizeof(float) * (size_t)B * Hp) / 4)));
         if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[nch - 1], 0));
         PHASE(4);
         if (xcd) {
-            HIPCK(h, hipMemsetAsync(h->inboxX, 0xFF, sizeof(float) * (size_t)lstm_xcd_inbox_floats(B), s));
-            HIPCK(h, hipMemsetAsync(h->tickets, 0, sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES, s));
+            HIPCK(h, launch_fill32(s, h->inboxX, 0xFFFFFFFFu, (long long)((sizeof(float) * (size_t)lstm_xcd_inbox_floats(B)) / 4)));
+            HIPCK(h, launch_fill32(s, h->tickets, 0u, (long long)((sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES) / 4)));
             h->ticket_next = 0;
         } else if (rs) {        // "not written yet" fill pattern of the dh partial inboxes
-            HIPCK(h, hipMemsetAsync(h->inbox, 0xFF, sizeof(float) * (size_t)lstm_bwd_rs_inbox_floats(B, Hp), s));
+            HIPCK(h, launch_fill32(s, h->inbox, 0xFFFFFFFFu, (long long)((sizeof(float) * (size_t)lstm_bwd_rs_inbox_floats(B, Hp)) / 4)));
         } else if (chain) {     // ... or of the dz fragments of every time step
             const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
-            HIPCK(h, hipMemsetAsync(h->dzF_all, 0xFF, sizeof(float) * (size_t)T * Bp16 * G4, s));
+            HIPCK(h, launch_fill32(s, h->dzF_all, 0xFFFFFFFFu, (long long)((sizeof(float) * (size_t)T * Bp16 * G4) / 4)));
         }
         for (int c = nch - 1; c >= 0; --c) {
             const int t0 = chunk_begin(h, c, nch), t1 = chunk_begin(h, c + 1, nch);
@@ -996,6 +1006,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         // shapes; FSMG_OVERLAP=0/1 forces the single-stream (hipGraph-replayed) / two-stream (eager) order
         const char* env = std::getenv("FSMG_OVERLAP");
         h->overlap = env ? (env[0] != '0') : ((int64_t)h->V1 >= 8LL * h->H * h->L);
+        h->overlap_forced = env != nullptr;
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
         h->persist_cfg = h->persist;
         if (const char* e = std::getenv("FSMG_FALLBACK_STEPS")) h->fallback_steps = std::max(1, std::atoi(e));
@@ -1199,6 +1210,7 @@ int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* 
         drop_graphs(h);
     }
     if ((rc = ensure_scratch(h, B)) != FSMG_OK) return rc;
+    choose_schedule(h, B);
     if ((rc = ensure_khf(h)) != FSMG_OK) return rc;
     if ((rc = stage_tokens(h, support, N * K, query, N * Q, tokens_on_device)) != FSMG_OK) return rc;
     const int n_sup = N * K, n_qry = N * Q;
@@ -1298,6 +1310,7 @@ int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, i
     for (int e0 = 0; e0 < n_episodes; e0 += chunk_eps) {
         const int ne = std::min(chunk_eps, n_episodes - e0);
         const int B = ne * per;
+        choose_schedule(h, B);
         const int32_t* q = queries + (size_t)e0 * per * h->T;
         if ((rc = stage_tokens(h, q, 0, q, B, tokens_on_device)) != FSMG_OK) return rc;
         rc = run_graphed(h, "ev:" + std::to_string(per) + ":" + std::to_string(ne), [&]() -> int {
@@ -1334,7 +1347,7 @@ int fsmg_sample(fsmg_handle h, int32_t num, int32_t* out_tokens) {
     float* hb = h->dec;                       // [L][2][Hp]
     float* cb = h->dec + (size_t)L * 2 * Hp;  // [L][Hp]
     float* arg_scratch = cb + (size_t)L * Hp;
-    HIPCK(h, hipMemsetAsync(h->dec, 0, sizeof(float) * (size_t)L * 3 * Hp, s));
+    HIPCK(h, launch_fill32(s, h->dec, 0u, (long long)((sizeof(float) * (size_t)L * 3 * Hp) / 4)));
     std::vector<int> toks(num);
     int word = h->V;                          // start word
     int* d_hist = nullptr;

@@ -145,7 +145,7 @@ struct LstmFwdXcdArgs {
     int* err_flag;
     int B, T, t0, t1;
     int spin_limit;
-    unsigned long long* prof;   // != nullptr: instrumented build, [256 blocks][8 waves][8] tick sums per phase (RG = 2 only)
+    unsigned long long* prof;   // != nullptr: instrumented build, [256 blocks][4 waves][8] tick sums per phase (RG = 2 only)
     int flags;                  // experiment switches (tools/xcd_chain_bench.cpp); 0 in production
 };
 struct LstmBwdXcdArgs {
@@ -170,6 +170,8 @@ hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a);
 hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);
 
 // ---------------------------------------------------------------- everything else (elementwise.hip)
+// p[0 .. n_words) = word (p 16-byte aligned); the step uses this instead of hipMemsetAsync so that its hipGraph holds kernel nodes only
+hipError_t launch_fill32(hipStream_t s, void* p, uint32_t word, long long n_words);
 // tokens [nseq][T] (support rows then query rows) -> time-major input ids X[t][b] (start word at t=0)
 // and targets Y[t][b]; sets *err_flag if any id is outside [0, vocab).
 hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, const int* query, int n_query,

@@ -470,6 +470,29 @@ def test_full_size_properties(name):
     assert [again.train_step(sup, qry) for _ in range(4)] == losses
 
 
+def test_graph_replay_equals_eager_launches_at_full_size(monkeypatch):
+    """cfg-B runs single-stream from a hipGraph (captured at the first step, replayed afterwards).  Three steps on
+    different episodes -- i.e. one capture and two REPLAYS -- must give the bits of the same launches issued eagerly.  (A
+    replayed graph holding hipMemsetAsync nodes left garbage in the zero-state block of the hidden states from the second
+    launch on; the step now fills with a kernel.  Found by the fresh-handle screen below.)"""
+    over, N, K, Q = FULL['cfg-B']
+    cfg = small_config(**over)
+    eps = O.synthetic_episodes(3, N, K, Q, cfg['max_len'], cfg['input_size'], seed=23)
+    out = []
+    for graph in ('1', '0'):
+        monkeypatch.setenv('FSMG_GRAPH', graph)
+        model = new_model(cfg)
+        losses = [model.train_step(s_, q_) for s_, q_ in eps]
+        model.forward_backward(*eps[0])
+        grads = {k: model.get_grad(k) for k in model.param_shapes}
+        out.append((losses, grads, model.get_params()))
+        assert all(np.isfinite(v).all() and np.abs(v).max() < 1.0 for v in grads.values())
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        np.testing.assert_array_equal(out[0][1][k], out[1][1][k])
+        np.testing.assert_array_equal(out[0][2][k], out[1][2][k])
+
+
 def test_fresh_handles_reproduce_each_other_bit_for_bit_at_cfg_b():
     """Race screen (tools/race_hunt2.py in small): 100 fresh handles, two train steps each on DIFFERENT episodes (so a
     stale buffer of the previous handle or step would carry different data), every gradient and parameter identical

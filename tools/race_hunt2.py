@@ -37,6 +37,12 @@ for r in range(reps):
         if msgs:
             bad += 1
             print('rep %d DIFFERS | ' % r + ' | '.join(msgs))
+            for c, q in zip(cur[1:], ref[1:]):
+                for k in diff(c, q):
+                    x, y = c[k], q[k]
+                    ne = np.argwhere(x != y)
+                    print('    %s %s: %d elements differ, rows %d..%d cols %d..%d, max |d| %.3g (|ref| max %.3g)' % (
+                        k, x.shape, len(ne), ne[:, 0].min(), ne[:, 0].max(), ne[:, -1].min(), ne[:, -1].max(), float(np.abs(x - y).max()), float(np.abs(y).max())))
             a = cur[0]['h'].reshape(T + 1, B, Hp); b = ref[0]['h'].reshape(T + 1, B, Hp)
             ne = a != b
             if ne.any():
@@ -45,5 +51,7 @@ for r in range(reps):
                 print('    h: time indices %d..%d differ (%d of them); at %d: rows %s, cols %s%s, max |d| %.3g, sample %r vs %r' % (
                     ts[0], ts[-1], len(ts), t, rows[:10].tolist(), cols[:16].tolist(), '...' if len(cols) > 16 else '',
                     float(np.abs(a[t] - b[t]).max()), a[t][ne[t]][:3].tolist(), b[t][ne[t]][:3].tolist()))
+    st_ = m.stats()
+    if st_['timeouts'] or st_['steps_skipped_timeout']: print('rep %d: stats %r' % (r, st_))
     m.close()
 print('reps', reps, 'mismatching', bad)

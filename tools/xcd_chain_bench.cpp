@@ -358,28 +358,11 @@ static int run_case(int B, int Tcheck, int Ttime) {
                    mflop * T / best_b / 1e6, mflop * T / best_b / 1e6 / 157.3 * 100, e);
             CK(hipMemset(d.err, 0, 4));
         }
-        if (B == 45 || B == 100) {       // forward hand-off variants
-            const char* vn[] = {"1-phase poll + drain (=P)", "P, no x-part loads", "P, no output stores", "P, neither", "P, no loads, no MFMA", "P, neither, no MFMA", "P, neither, no MFMA, no cell", "1-phase, neither"};
-            const int vf[] = {5, 5 + 128, 5 + 256, 5 + 384, 5 + 128 + 32, 5 + 384 + 32, 5 + 384 + 96, 4 + 384};
-            for (int vi = 0; vi < 8; ++vi) {
-                float best = 1e9f;
-                for (int rep = 0; rep < 4; ++rep) {
-                    fwd_xcd(T, 0);
-                    LstmFwdXcdArgs a{};
-                    a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.flags = vf[vi];
-                    CK(hipEventRecord(e0, s)); CK(launch_lstm_fwd_xcd(s, a)); CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
-                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
-                }
-                printf("[5] fwd variant %-26s %.2f us/step  err_flag %d\n", vn[vi], best * 1e3 / T, read_err());
-                CK(hipMemset(d.err, 0, 4));
-            }
-        }
         if (B == 45) {       // phase profile of the instrumented build (RG = 2)
-            unsigned long long* prof; CK(hipMalloc(&prof, 8ull * (256 * 8 * 8 + 8 * 8 * 2 * 4)));
-            std::vector<unsigned long long> hp(256 * 8 * 8 + 8 * 8 * 2 * 4);
+            unsigned long long* prof; CK(hipMalloc(&prof, 8ull * 256 * 4 * 8));
+            std::vector<unsigned long long> hp(256 * 4 * 8);
             for (int dir = 0; dir < 2; ++dir) {
-                CK(hipMemset(prof, 0, 8ull * (256 * 8 * 8 + 8 * 8 * 2 * 4)));
+                CK(hipMemset(prof, 0, 8ull * 256 * 4 * 8));
                 if (dir == 0) {
                     fwd_xcd(T, 0);
                     LstmFwdXcdArgs a{};
@@ -395,39 +378,15 @@ static int run_case(int B, int Tcheck, int Ttime) {
                 }
                 CK(hipStreamSynchronize(s));
                 CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
-                const char* names_f[5] = {"wait h_t", "MFMA + LDS hand-over", "wait partials", "cell -> hand-off store", "other stores"};
-                const char* names_b[5] = {"wait dz", "MFMA + stores", "wait inbox", "sums + cell + LDS", "other stores"};
-                for (int wc = 0; wc < 2; ++wc) {        // MFMA waves (0-3) vs cell waves (4-5)
+                const char* names_f[5] = {"wait h_t", "MFMA", "LDS+barrier", "cell->store", "rest"};
+                const char* names_b[5] = {"wait inbox", "psum+barrier", "cell+dzA+barrier", "LDS read+MFMA", "drain+stores+rest"};
+                for (int wc = 0; wc < 2; ++wc) {        // cell waves (0,1) vs the others (2,3)
                     double m[5] = {0, 0, 0, 0, 0};
-                    const int w0 = wc ? 4 : 0, w1 = wc ? 6 : 4;
-                    for (int b = 0; b < 256; ++b) for (int w = w0; w < w1; ++w) for (int i = 0; i < 5; ++i) m[i] += (double)hp[((size_t)b * 8 + w) * 8 + i];
-                    printf("[4] %s phase ticks per time step (both row groups), %s waves:", dir ? "bwd" : "fwd", wc ? "cell" : "MFMA");
+                    for (int b = 0; b < 256; ++b) for (int w = 2 * wc; w < 2 * wc + 2; ++w) for (int i = 0; i < 5; ++i) m[i] += (double)hp[((size_t)b * 4 + w) * 8 + i];
+                    printf("[4] %s phase ticks per step, waves %d-%d:", dir ? "bwd" : "fwd", 2 * wc, 2 * wc + 1);
                     double tot = 0;
-                    const double div = 256.0 * (w1 - w0) * T / (wc ? 2 : 1);      // a cell wave serves ONE row group: x2 for per-step totals of the pair
-                    for (int i = 0; i < 5; ++i) { if (m[i] == 0) continue; printf("  %s %.0f", dir ? names_b[i] : names_f[i], m[i] / div / (wc ? 2 : 1)); tot += m[i] / div / (wc ? 2 : 1); }
+                    for (int i = 0; i < 5; ++i) { printf("  %s %.0f", dir ? names_b[i] : names_f[i], m[i] / 512 / T); tot += m[i] / 512 / T; }
                     printf("  | total %.0f\n", tot);
-                }
-            }
-            for (int tf : {5 + 384}) {   // forward timeline of block (xcd 0, cu 0), steps 64..71 (filled by the dir == 0 pass? no: the last pass was bwd) -- rerun fwd
-                CK(hipMemset(prof, 0, 8ull * (256 * 8 * 8 + 8 * 8 * 2 * 4)));
-                fwd_xcd(T, 0);
-                LstmFwdXcdArgs a{};
-                a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.flags = tf;
-                CK(launch_lstm_fwd_xcd(s, a)); CK(hipStreamSynchronize(s));
-                CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
-                const unsigned long long* ev = hp.data() + 256 * 8 * 8;
-                const unsigned long long base = ev[((0 * 8 + 0) * 2 + 0) * 4 + 0];
-                printf("[6] fwd timeline (flags %d), block (xcd 0, cu 0), ticks relative to step 64 / wave 0 / rg 0 operand-ready\n", tf);
-                for (int st = 0; st < 4; ++st) {
-                    for (int rg = 0; rg < 2; ++rg) {
-                        printf("[6] t=%d rg%d: operand ready", 64 + st, rg);
-                        for (int w = 0; w < 4; ++w) printf(" %6lld", (long long)(ev[((st * 8 + w) * 2 + rg) * 4 + 0] - base));
-                        printf(" | partials handed over");
-                        for (int w = 0; w < 4; ++w) printf(" %6lld", (long long)(ev[((st * 8 + w) * 2 + rg) * 4 + 1] - base));
-                        printf(" | cell wave: partials seen %6lld, store issued %6lld\n", (long long)(ev[((st * 8 + 4 + rg) * 2 + 0) * 4 + 0] - base),
-                               (long long)(ev[((st * 8 + 4 + rg) * 2 + 0) * 4 + 1] - base));
-                    }
                 }
             }
             hipFree(prof);
