@@ -330,6 +330,37 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
     }
 }
 
+// Inner-loop update of the MAML-style step (cfg-E; oracle/lstm_oracle.py maml_adapt): p <- p - lr * clip_by_global_norm(g).
+// Same norm bookkeeping as k_adam_update (every block re-derives the scale from the same partials in the same order);
+// Adam state and global_step are not touched.
+__global__ __launch_bounds__(256) void k_sgd_update(const UpdateArgs a) {
+    __shared__ double sh[4];
+    __shared__ float s_scale;
+    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;
+    for (int i = tid; i < a.n_partials; i += 256) s += a.partials[i];
+    s = wave_sum_d(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double sq = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        if (a.use_slices) sq += (double)a.tail[0];
+        const double gnorm = sqrt(sq), clip = (double)a.clip;
+        s_scale = (float)(clip / fmax(gnorm, clip)) * a.lr;
+        if (a.gnorm_out != nullptr && blockIdx.x == 0) *a.gnorm_out = (float)gnorm;
+    }
+    __syncthreads();
+    const float step = s_scale;
+    const long long n4 = a.n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+        p.x -= step * g.x; p.y -= step * g.y; p.z -= step * g.z; p.w -= step * g.w;
+        reinterpret_cast<float4*>(a.p)[i] = p;
+    }
+}
+
 // Last kernel of a train step.  A step that must not count -- a persistent recurrent kernel timed out on this rank
 // (*err_flag == 2) or on another one (tail[2], all-reduced), or a token id was out of range (*err_flag == 1) -- is
 // tallied in `counters` (host-mapped: [0] time-outs, [1] token-range rejections; the host compares them with what it has
@@ -508,6 +539,15 @@ hipError_t launch_adam_update(hipStream_t s, const UpdateArgs& a) {
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_adam_update, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sgd_update(hipStream_t s, const UpdateArgs& a) {
+    long long n4 = a.n >> 2;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_sgd_update, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

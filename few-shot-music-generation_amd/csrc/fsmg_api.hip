@@ -95,6 +95,7 @@ struct fsmg_model {
     bool persist_fwd = true, persist_bwd = true;   // FSMG_PERSIST_FWD / FSMG_PERSIST_BWD = 0: that direction launches per step
     bool persist = true;                // FSMG_PERSISTENT=0: one launch per time step instead of one persistent launch per chain chunk
     float* khf = nullptr;               // fragment-ordered recurrent weights: per layer fwd copy, bwd copy
+    float* P_saved = nullptr;           // cfg-E: theta while the handle computes at the adapted theta'
     // XCD-local recurrence (lstm_xcd.hip; hidden size 512): per layer the forward and backward register images of K_h,
     // the h hand-off buffer, the dh-partial inboxes and the per-launch ticket counters
     bool xcd = true;                    // FSMG_XCD=0: keep the column-split persistent kernels
@@ -891,6 +892,39 @@ int apply_update(fsmg_model* h, float grad_scale) {
     return FSMG_OK;
 }
 
+// cfg-E inner loop: theta' <- theta' - lr * clip_by_global_norm(grads of the last backward); Adam state and step untouched
+int sgd_update(fsmg_model* h, float lr) {
+    hipStream_t s = h->stream;
+    ScopedTimer tm(h, "update");
+    const bool slices = h->cfg.clip_norm_mode == FSMG_CLIP_TF1_SLICES;
+    const int64_t skip = slices ? round_up((int64_t)h->V1 * h->Ep, FLAT_ALIGN) : 0;
+    const int64_t n = h->n_flat - skip;
+    HIPCK(h, launch_sqnorm_partials(s, h->G + skip, n, h->partials));
+    UpdateArgs a{};
+    a.p = h->P; a.g = h->G; a.n = h->n_flat;
+    a.partials = h->partials; a.n_partials = sqnorm_blocks(n); a.tail = h->G + h->n_flat; a.use_slices = slices ? 1 : 0;
+    a.lr = lr; a.clip = h->cfg.max_grad_norm; a.gnorm_out = h->d_gnorm; a.err_flag = h->d_err;
+    HIPCK(h, launch_sgd_update(s, a));
+    h->khf_dirty = true;
+    h->have_grads = false;
+    return ensure_khf(h);
+}
+
+int save_theta(fsmg_model* h) {
+    if (!h->P_saved) {
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        if (hipMalloc((void**)&h->P_saved, sizeof(float) * (size_t)h->n_flat) != hipSuccess)
+            return fail(h, FSMG_ERR_NOMEM, "hipMalloc(saved parameters) failed");
+    }
+    HIPCK(h, hipMemcpyAsync(h->P_saved, h->P, sizeof(float) * (size_t)h->n_flat, hipMemcpyDeviceToDevice, h->stream));
+    return FSMG_OK;
+}
+int restore_theta(fsmg_model* h) {
+    HIPCK(h, hipMemcpyAsync(h->P, h->P_saved, sizeof(float) * (size_t)h->n_flat, hipMemcpyDeviceToDevice, h->stream));
+    h->khf_dirty = true;
+    return ensure_khf(h);
+}
+
 // a persistent recurrent kernel gave up waiting for its peers (its blocks were not co-resident): one launch per time step
 // for the next `fallback_steps` train steps, then the persistent path is tried again
 void on_timeout(fsmg_model* h) {
@@ -1093,6 +1127,7 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->dec) hipFree(h->dec);
     if (h->khf) hipFree(h->khf);
     if (h->khx) hipFree(h->khx);
+    if (h->P_saved) hipFree(h->P_saved);
     if (h->d_eval) hipFree(h->d_eval);
     if (h->host_counters) hipHostFree(h->host_counters);
     if (h->own_state && h->state) hipFree(h->state);
@@ -1282,6 +1317,59 @@ int fsmg_train_step(fsmg_handle h, const int32_t* support, const int32_t* query,
         h->persist_timed_out = false;
         rc = fsmg_forward_backward(h, support, query, N, K, Q, tokens_on_device);
         if (rc == FSMG_OK) rc = fsmg_apply_update(h, 1.0f, loss);
+    }
+    return rc;
+}
+
+// ---- cfg-E (BASELINE.json configs[4]): MAML-style inner / outer loop, first order.  DESIGN.md "cfg-E".
+static int maml_adapt(fsmg_handle h, const int32_t* support, int32_t N, int32_t K, int32_t inner_steps, float inner_lr, int32_t on_device) {
+    int rc = save_theta(h);
+    for (int i = 0; rc == FSMG_OK && i < inner_steps; ++i) {
+        rc = fsmg_forward_backward(h, support, support, N, K, 0, on_device);       // support rows only
+        if (rc == FSMG_OK) rc = sgd_update(h, inner_lr);
+    }
+    return rc;
+}
+
+int fsmg_maml_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K, int32_t Q,
+                               int32_t inner_steps, float inner_lr, int32_t tokens_on_device) {
+    if (!h || !support || !query) return FSMG_ERR_INVALID;
+    if (inner_steps < 0 || inner_steps > 64 || !(inner_lr >= 0.f) || K <= 0 || Q <= 0) return fail(h, FSMG_ERR_INVALID, "bad inner_steps / inner_lr / K / Q");
+    hipSetDevice(h->device);
+    int rc = maml_adapt(h, support, N, K, inner_steps, inner_lr, tokens_on_device);
+    if (rc == FSMG_OK) rc = fsmg_forward_backward(h, query, query, N, Q, 0, tokens_on_device);     // query rows at theta'
+    const int rc2 = h->P_saved ? restore_theta(h) : FSMG_OK;                                         // theta comes back whatever happened
+    return rc != FSMG_OK ? rc : rc2;
+}
+
+int fsmg_maml_step(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K, int32_t Q,
+                   int32_t inner_steps, float inner_lr, int32_t tokens_on_device, float* loss) {
+    int rc = fsmg_maml_forward_backward(h, support, query, N, K, Q, inner_steps, inner_lr, tokens_on_device);
+    if (rc != FSMG_OK) return rc;
+    rc = fsmg_apply_update(h, 1.0f, loss);
+    if (rc == FSMG_ERR_HIP && h->persist_timed_out) {        // same recovery as fsmg_train_step: nothing was updated, repeat per step
+        h->persist_timed_out = false;
+        rc = fsmg_maml_forward_backward(h, support, query, N, K, Q, inner_steps, inner_lr, tokens_on_device);
+        if (rc == FSMG_OK) rc = fsmg_apply_update(h, 1.0f, loss);
+    }
+    return rc;
+}
+
+int fsmg_maml_eval(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K, int32_t Q,
+                   int32_t inner_steps, float inner_lr, int32_t tokens_on_device, float* nll) {
+    if (!h || !support || !query || !nll) return FSMG_ERR_INVALID;
+    if (inner_steps < 0 || inner_steps > 64 || !(inner_lr >= 0.f) || K <= 0 || Q <= 0) return fail(h, FSMG_ERR_INVALID, "bad inner_steps / inner_lr / K / Q");
+    hipSetDevice(h->device);
+    int rc = FSMG_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        rc = maml_adapt(h, support, N, K, inner_steps, inner_lr, tokens_on_device);
+        // the flag of a time-out / token error inside the adaptation is still set: fsmg_eval_step reads and reports it
+        if (rc == FSMG_OK) rc = fsmg_eval_step(h, query, N, Q, tokens_on_device, nll);
+        const int rc2 = h->P_saved ? restore_theta(h) : FSMG_OK;
+        h->have_grads = false;
+        if (rc == FSMG_OK) rc = rc2;
+        if (!(rc == FSMG_ERR_HIP && h->persist_timed_out)) break;
+        h->persist_timed_out = false;                        // adapted with garbage (skipped) steps: repeat on per-step launches
     }
     return rc;
 }

@@ -203,6 +203,8 @@ struct UpdateArgs {
     const int* err_flag;                          // optional: *err_flag != 0 (a persistent step kernel gave up / a token id was out of range) -> no update
 };
 hipError_t launch_adam_update(hipStream_t s, const UpdateArgs& a);
+// p <- p - a.lr * clip_by_global_norm(g): the inner-loop step of cfg-E (m, v, step, n_decay, grad_scale unused)
+hipError_t launch_sgd_update(hipStream_t s, const UpdateArgs& a);
 // last kernel of a train step: counts the step (ring[step % cap] = loss, ++step) or, when *err_flag != 0 or the
 // all-reduced time-out indicator tail[2] is set, tallies it in counters ([0] time-outs, [1] token-range rejections;
 // host-mapped memory) and clears the flag

@@ -64,6 +64,9 @@ SIGNATURES = {
     'fsmg_grad_bucket': (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
     'fsmg_stream_wait_bucket': (C.c_int, [_P, _P, C.c_int32]),
     'fsmg_apply_update': (C.c_int, [_P, C.c_float, _F32P]),
+    'fsmg_maml_forward_backward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32]),
+    'fsmg_maml_step': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _F32P]),
+    'fsmg_maml_eval': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _F32P]),
     'fsmg_eval_step': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _F32P]),
     'fsmg_eval_batch': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F32P]),
     'fsmg_sample': (C.c_int, [_P, C.c_int32, _I32P]),
@@ -263,6 +266,30 @@ class FsmgModel(object):
         loss = C.c_float()
         self._ck(self._lib.fsmg_apply_update(self._h, float(grad_scale), C.byref(loss) if want_loss else None))
         return loss.value if want_loss else None
+
+    # -- cfg-E: MAML-style inner / outer loop ------------------------------------------------------
+    def maml_forward_backward(self, support, query, inner_steps, inner_lr, shape=None):
+        n, k, q = self._episode_shape(support, query, shape)
+        sp, dev, _k1 = _tok_ptr(support)
+        qp, _, _k2 = _tok_ptr(query)
+        self._ck(self._lib.fsmg_maml_forward_backward(self._h, sp, qp, n, k, q, int(inner_steps), float(inner_lr), dev))
+
+    def maml_step(self, support, query, inner_steps, inner_lr, shape=None, want_loss=True):
+        n, k, q = self._episode_shape(support, query, shape)
+        sp, dev, _k1 = _tok_ptr(support)
+        qp, _, _k2 = _tok_ptr(query)
+        loss = C.c_float()
+        self._ck(self._lib.fsmg_maml_step(self._h, sp, qp, n, k, q, int(inner_steps), float(inner_lr), dev,
+                                          C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
+
+    def maml_eval(self, support, query, inner_steps, inner_lr, shape=None):
+        n, k, q = self._episode_shape(support, query, shape)
+        sp, dev, _k1 = _tok_ptr(support)
+        qp, _, _k2 = _tok_ptr(query)
+        nll = C.c_float()
+        self._ck(self._lib.fsmg_maml_eval(self._h, sp, qp, n, k, q, int(inner_steps), float(inner_lr), dev, C.byref(nll)))
+        return nll.value
 
     def eval_step(self, query, shape=None):
         if shape is None:

@@ -50,6 +50,8 @@ class EpisodeParallel(object):
                 dist.broadcast(tensor, src=0, group=self.group)
 
     def train_step(self, support, query, want_loss=True, **kw):
+        """kw: shape=(N, K, Q) for raw device token addresses; maml=(inner_steps, inner_lr) selects the cfg-E step (per-rank
+        inner SGD on the support rows, no communication; the query-set gradients are exchanged exactly like a plain step's)"""
         try:
             return self._train_step_once(support, query, want_loss, **kw)
         except Exception as e:
@@ -59,8 +61,11 @@ class EpisodeParallel(object):
                 raise
             return self._train_step_once(support, query, want_loss, **kw)
 
-    def _train_step_once(self, support, query, want_loss=True, **kw):
-        self.engine.forward_backward(support, query, **kw)
+    def _train_step_once(self, support, query, want_loss=True, maml=None, **kw):
+        if maml is not None:
+            self.engine.maml_forward_backward(support, query, maml[0], maml[1], **kw)
+        else:
+            self.engine.forward_backward(support, query, **kw)
         buckets = getattr(self.engine, 'grad_buckets', None)
         if self.world > 1 and buckets is not None and self.bucketed:
             # overlapped exchange: each bucket is reduced on the communication stream as soon as it is final

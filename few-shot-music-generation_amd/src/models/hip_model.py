@@ -67,6 +67,9 @@ class HIPModel(BaseModel):
     def forward_backward(self, support, query, **kw):
         self._model.forward_backward(support, query, **kw)
 
+    def maml_forward_backward(self, support, query, inner_steps, inner_lr, **kw):
+        self._model.maml_forward_backward(support, query, inner_steps, inner_lr, **kw)
+
     def apply_update(self, grad_scale=1.0, want_loss=True):
         return self._model.apply_update(grad_scale, want_loss=want_loss)
 

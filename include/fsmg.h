@@ -146,6 +146,23 @@ int fsmg_eval_step(fsmg_handle h, const int32_t* query, int32_t N, int32_t Q,
 int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, int32_t N, int32_t Q,
                     int32_t tokens_on_device, float* nll);
 
+/* ---- cfg-E (BASELINE.json configs[4]): MAML-style inner / outer loop, first order.
+ * The reference has no code for it (READING_LIST.md:5-7 names the direction); semantics: DESIGN.md "cfg-E", oracle:
+ * oracle/lstm_oracle.py maml_step / maml_eval.  theta' starts at theta and takes `inner_steps` steps
+ *   theta' <- theta' - inner_lr * clip_by_global_norm(grad of the SUPPORT rows' mean NLL at theta', max_grad_norm);
+ * the outer gradient is the gradient of the QUERY rows' mean NLL with respect to theta' (no derivative through the inner
+ * steps); theta is restored before anything is updated.
+ *   fsmg_maml_forward_backward  leaves that gradient (+ the query loss in the tail) in the flat gradient buffer, theta and
+ *                               Adam state untouched: all-reduce it across ranks, then fsmg_apply_update(1/world);
+ *   fsmg_maml_step              = the two on one GPU (clip + Adam on theta, global_step++); *loss = query NLL at theta';
+ *   fsmg_maml_eval              few-shot evaluation: adapt on the support set, query NLL at theta', no state change. */
+int fsmg_maml_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K,
+                               int32_t Q, int32_t inner_steps, float inner_lr, int32_t tokens_on_device);
+int fsmg_maml_step(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K, int32_t Q,
+                   int32_t inner_steps, float inner_lr, int32_t tokens_on_device, float* loss);
+int fsmg_maml_eval(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K, int32_t Q,
+                   int32_t inner_steps, float inner_lr, int32_t tokens_on_device, float* nll);
+
 /* replaces LSTMBaseline.sample (src/models/lstm_baseline.py:135-156): greedy argmax decode of
  * `num` tokens from the start word and a zero state (the support set is ignored there). */
 int fsmg_sample(fsmg_handle h, int32_t num, int32_t* out_tokens);

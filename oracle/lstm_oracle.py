@@ -290,6 +290,55 @@ def sample(params, num, config):
     return out
 
 
+# ----------------------------------------------------------------------------- cfg-E: MAML-style inner / outer loop
+# BASELINE.json configs[4].  The reference has no code for it (READING_LIST.md:5-7 names MAML as the direction); the
+# semantics are specified in DESIGN.md section "cfg-E" and restated here.  First-order MAML on the LSTM baseline:
+#   theta'  <- theta;  repeat inner_steps times on the SUPPORT rows:
+#                theta' <- theta' - inner_lr * clip_by_global_norm(grad L_support(theta'), max_grad_norm)
+#   loss_q  =  L_query(theta')                      (the value train() returns; pre-outer-update)
+#   g       =  grad_{theta'} L_query(theta')        (first-order: no derivative through the inner steps)
+#   theta   <- clip + TF-Adam(theta, mean over ranks of g);  global_step += 1      (the same update as LSTMBaseline.train)
+def maml_adapt(params, support, config, inner_steps=1, inner_lr=0.1, clip_norm_mode='tf1_slices'):
+    """-> (theta', [support loss before each inner step]); params is not modified."""
+    d = model_dims(config)
+    fast = {k: v.copy() for k, v in params.items()}
+    X, Y = tokens_to_input_and_target(support, d['start'])
+    losses = []
+    clip = float(config['max_grad_norm'])
+    for _ in range(int(inner_steps)):
+        loss, cache = forward(fast, X, Y, config)
+        grads, aux = backward(fast, cache, config)
+        scale = clip / max(global_norm(grads, aux, clip_norm_mode), clip)
+        for k in fast:
+            dt = fast[k].dtype.type
+            fast[k] = fast[k] - dt(inner_lr) * (grads[k] * dt(scale))
+        losses.append(float(loss))
+    return fast, losses
+
+
+def maml_query_grads(params, support, query, config, inner_steps=1, inner_lr=0.1, clip_norm_mode='tf1_slices'):
+    """-> (query loss at theta', first-order outer gradients, aux)"""
+    d = model_dims(config)
+    fast, _ = maml_adapt(params, support, config, inner_steps, inner_lr, clip_norm_mode)
+    X, Y = tokens_to_input_and_target(query, d['start'])
+    loss, cache = forward(fast, X, Y, config)
+    grads, aux = backward(fast, cache, config)
+    return float(loss), grads, aux
+
+
+def maml_step(params, opt, support, query, config, inner_steps=1, inner_lr=0.1, clip_norm_mode='tf1_slices'):
+    """One outer step; mutates params / opt; returns the query loss at the adapted parameters."""
+    loss, grads, aux = maml_query_grads(params, support, query, config, inner_steps, inner_lr, clip_norm_mode)
+    apply_update(params, grads, aux, opt, config, clip_norm_mode)
+    return loss
+
+
+def maml_eval(params, support, query, config, inner_steps=1, inner_lr=0.1, clip_norm_mode='tf1_slices'):
+    """Few-shot evaluation: adapt on the support set, mean NLL of the query set at theta'; no state change."""
+    fast, _ = maml_adapt(params, support, config, inner_steps, inner_lr, clip_norm_mode)
+    return eval_step(fast, query, config)
+
+
 # ----------------------------------------------------------------------------- synthetic workloads (SURVEY.md 8d)
 def synthetic_episodes(n_episodes, N, K, Q, T, vocab, seed=1234, realistic=False):
     """cfg-B style inputs: ids i.i.d. uniform on [0, vocab) from RandomState(seed).

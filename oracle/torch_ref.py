@@ -98,6 +98,33 @@ class TorchRef(object):
         self.step = t
         return loss
 
+    # -- cfg-E: first-order MAML (oracle/lstm_oracle.py maml_step) ------------------
+    def _clip_scale(self, g, slices_sq):
+        sq = 0.0
+        for k in self.names:
+            sq += slices_sq if (k == 'embedding' and self.clip_norm_mode == 'tf1_slices') \
+                else float((g[k].double() ** 2).sum())
+        clip = float(self.config['max_grad_norm'])
+        return clip / max(np.sqrt(sq), clip)
+
+    def maml_query_grads(self, support, query, inner_steps, inner_lr):
+        """autograd with the inner steps DETACHED: the query gradient is taken w.r.t. the adapted parameters"""
+        theta = {k: v.detach().clone() for k, v in self.p.items()}
+        Xs, Ys = O.tokens_to_input_and_target(support, self.d['start'])
+        for _ in range(int(inner_steps)):
+            _, g, sq = self.grads_xy(Xs, Ys)
+            scale = self._clip_scale(g, sq)
+            with torch.no_grad():
+                for k in self.names:
+                    self.p[k].sub_(inner_lr * scale * g[k])
+        Xq, Yq = O.tokens_to_input_and_target(query, self.d['start'])
+        loss, g, sq = self.grads_xy(Xq, Yq)
+        g = {k: v.clone() for k, v in g.items()}
+        with torch.no_grad():
+            for k in self.names:
+                self.p[k].copy_(theta[k])
+        return loss, g, sq
+
     # -- plugin-level ---------------------------------------------------------
     def train(self, support, query):
         X, Y = O.train_xy(support, query, self.d['start'])

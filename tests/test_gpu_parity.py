@@ -416,6 +416,58 @@ def test_sample_matches_oracle_greedy_decode():
     assert model.sample(15) == O.sample(params, 15, cfg)
 
 
+@pytest.mark.parametrize('layers,inner_steps,hidden', [(1, 1, 40), (2, 2, 40), (1, 1, 512)])
+def test_maml_step_and_eval_match_oracle(layers, inner_steps, hidden):
+    """cfg-E (BASELINE.json configs[4]): three outer steps of the first-order MAML-style loop -- per episode `inner_steps`
+    clipped SGD steps on the support rows, query loss and gradient at the adapted parameters, clip + Adam on theta -- and
+    the few-shot evaluation, against oracle/lstm_oracle.py maml_step / maml_eval (itself checked against torch autograd).
+    hidden 512 takes the XCD-local recurrent kernels (support 15 rows, query 10 rows)."""
+    cfg = small_config(hidden_size=hidden, embedding_size=20, input_size=211, max_len=12, n_layers=layers, max_grad_norm=0.5)
+    inner_lr = 0.3
+    model = new_model(cfg)
+    params = f64_params(model)
+    opt = O.new_opt_state(params)
+    eps = O.synthetic_episodes(4, 5, 3, 2, cfg['max_len'], cfg['input_size'], seed=41, realistic=True)
+    want_eval = O.maml_eval(params, eps[3][0], eps[3][1], cfg, inner_steps, inner_lr)
+    got_eval = model.maml_eval(eps[3][0], eps[3][1], inner_steps, inner_lr)
+    assert abs(got_eval - want_eval) <= NLL_RTOL * abs(want_eval)
+    plain = O.eval_step(params, eps[3][1], cfg)
+    assert abs(want_eval - plain) > 10 * NLL_RTOL * abs(plain)          # the adaptation moves the NLL: the check has teeth
+    for name, ref in params.items():                                    # evaluation left theta alone
+        assert rel_max(model.get_param(name), ref) == 0.0, name
+    for s, (sup, qry) in enumerate(eps[:3]):
+        want = O.maml_step(params, opt, sup, qry, cfg, inner_steps, inner_lr)
+        got = model.maml_step(sup, qry, inner_steps, inner_lr)
+        assert abs(got - want) <= NLL_RTOL * abs(want), (s, got, want)
+    assert model.step == 3
+    for name, ref in params.items():
+        assert rel_max(model.get_param(name), ref) < 5e-4, name
+    # split form (what an episode-parallel rank runs): gradients in the buffer, theta untouched until apply_update
+    before = model.get_params()
+    model.maml_forward_backward(eps[3][0], eps[3][1], inner_steps, inner_lr)
+    _, grads, aux = O.maml_query_grads(params, eps[3][0], eps[3][1], cfg, inner_steps, inner_lr)
+    for name in grads:
+        assert rel_max(model.get_grad(name), grads[name]) < 5e-4, name
+        np.testing.assert_array_equal(model.get_param(name), before[name])
+
+
+def test_maml_plugin_runs_through_the_models_api(tmp_path):
+    from data.episode import Episode
+    from models.maml_lstm import MAMLLSTM
+    cfg = small_config(name='maml_lstm', inner_steps=2, inner_lr=0.2, checkpt_dir=str(tmp_path))
+    sup, qry = _episode(cfg, 3, 3, 2)
+    ep = Episode(sup, qry)
+    m = MAMLLSTM(dict(cfg))
+    m.recover_or_init('')
+    params = {k: v.astype(np.float64) for k, v in m.engine.get_params().items()}
+    opt = O.new_opt_state(params)
+    assert abs(m.eval(ep) - O.maml_eval(params, sup, qry, cfg, 2, 0.2)) <= NLL_RTOL * 10
+    for _ in range(2):
+        want = O.maml_step(params, opt, sup, qry, cfg, 2, 0.2)
+        assert abs(m.train(ep) - want) <= NLL_RTOL * abs(want)
+    assert m.eval_many([ep, ep]) == [m.eval(ep)] * 2 and len(m.sample(sup[0], 4)) == 4
+
+
 def test_plugin_api_checkpoint_resume(tmp_path):
     from data.episode import Episode
     from models.lstm_baseline import LSTMBaseline

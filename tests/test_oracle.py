@@ -173,3 +173,34 @@ def test_adam_and_lr_decay_match_torch_optim_adam():
         np.testing.assert_allclose(params['w'], tw.detach().numpy(), rtol=0, atol=1e-14)
     assert opt['step'] == 6
     assert np.abs(params['w'] - w0).max() > 5e-3          # the parameters moved by far more than the tolerance
+
+
+@pytest.mark.parametrize('inner_steps', [1, 2])
+def test_maml_first_order_gradients_match_torch_autograd(inner_steps):
+    """cfg-E (BASELINE.json configs[4]; semantics in DESIGN.md): theta' by clipped SGD on the support rows, the outer
+    gradient is d L_query / d theta' -- checked against autograd with the inner steps detached, then one outer update."""
+    cfg = small_config(n_layers=2, max_grad_norm=0.05)         # small clip: the inner clip branch is active
+    params = O.glorot_init(cfg, 13, np.float64)
+    sup, qry = _episode(cfg, N=2, K=2, Q=2, seed=9)
+    loss, grads, aux = O.maml_query_grads(params, sup, qry, cfg, inner_steps=inner_steps, inner_lr=0.2)
+    ref = TorchRef(cfg, params, dtype=torch.float64)
+    rloss, rg, rsq = ref.maml_query_grads(sup, qry, inner_steps, 0.2)
+    assert abs(loss - rloss) <= 1e-12 * abs(rloss)
+    for k in grads:
+        np.testing.assert_allclose(grads[k], rg[k].numpy(), rtol=1e-9, atol=1e-13, err_msg=k)
+    assert abs(aux['embedding_slices_sq'] - rsq) <= 1e-10 * rsq
+    # the adaptation helps on the support set it was computed from, and theta itself is untouched
+    before = {k: v.copy() for k, v in params.items()}
+    fast, sup_losses = O.maml_adapt(params, sup, cfg, inner_steps=3, inner_lr=0.2)
+    assert sup_losses[0] > sup_losses[1] > sup_losses[2]
+    for k in params:
+        np.testing.assert_array_equal(params[k], before[k])
+    # one outer step == apply_update with those gradients
+    opt, opt2 = O.new_opt_state(params), O.new_opt_state(params)
+    p2 = {k: v.copy() for k, v in params.items()}
+    got = O.maml_step(params, opt, sup, qry, cfg, inner_steps=inner_steps, inner_lr=0.2)
+    O.apply_update(p2, grads, aux, opt2, cfg)
+    assert got == loss and opt['step'] == 1
+    for k in params:
+        np.testing.assert_array_equal(params[k], p2[k])
+    assert O.maml_eval(before, sup, qry, cfg, inner_steps=inner_steps, inner_lr=0.2) == pytest.approx(loss, rel=1e-12)
