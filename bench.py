@@ -13,11 +13,15 @@ skipped; the per-step loss stays in a device ring and is read back after the tim
 With N > 1 every rank trains on its own episode per step and one RCCL all-reduce sums the flat gradient
 buffer (weak scaling: per-GPU work fixed); value = N * K / max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (the dW = out^T * dlogits GEMM,
-k_gemm<XC,XC>, one launch per step) timed with HIP events on the library's stream over a
-repeat of the timed steps; `kernels` (extra) is a per-class breakdown from a second, fully instrumented pass;
-`cpu_baseline` is the oracle's torch-CPU restatement of the same step ("port": TensorFlow cannot run here)
-on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0, the LAST line of stdout).  `roofline` is the kernel BASELINE.json's north star sets a
+target for -- the fused LSTM cell (recurrent 4x GEMV on MFMA + gate nonlinearities + state update: k_lstm_fwd_xcd and
+k_lstm_bwd_xcd at hidden size 512), 2 launches per step, each running T = 128 dependent time steps -- timed with HIP
+events on the library's stream over a repeat of the timed steps in the schedule the timed region used (single stream
+at cfg-B; event timing only replaces the hipGraph replay by the same launches issued eagerly).  `kernels` is the
+per-class breakdown of a fully instrumented pass (every GEMM with its own fraction of the MFMA peak); `guard` proves
+that the timed region did the work it claims (global_step advanced by exactly warmup + steps, no step skipped, no
+persistent-kernel time-out); `cpu_baseline` is the oracle's CPU restatement of the same step ("port": TensorFlow cannot
+run here) on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -45,10 +49,14 @@ OTHER = {
     # same update rule as episode-parallel training over 4 / 8 ranks.  `value` then counts steps, not episodes.
     'cfg-Bx4': (dict(CFG_B), 20, 5, 4),
     'cfg-Bx8': (dict(CFG_B), 40, 5, 4),
+    # BASELINE.json configs[4]: MAML-style inner/outer loop (models.maml_lstm; 1 inner clipped-SGD step on the support rows,
+    # outer clip+Adam on the query gradient), freemidi-sized vocabulary, 2-layer LSTM h=1024, 5-way/5-shot
+    'cfg-E': (dict(name='maml_lstm', seed=1234, input_size=4708, max_len=50, embedding_size=250, hidden_size=1024,
+                   n_layers=2, lr=5e-3, max_grad_norm=5, n_decay=10000, inner_steps=1, inner_lr=0.1), 5, 5, 4),
 }
 POOL = 256
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-DOMINANT = 'gemm_dw'
+CELL_CLASSES = ('lstm_fwd', 'lstm_bwd')      # the fused LSTM cell: the north star's target kernel
 CLASSES = ['gemm_zx', 'lstm_fwd', 'gemm_logits', 'ce', 'gemm_dhout', 'gemm_dw', 'lstm_bwd', 'gemm_dk',
            'gemm_dx', 'embed_grad', 'update']
 
@@ -61,10 +69,11 @@ def synthetic_episodes(n_episodes, N, K, Q, T, vocab, seed):
 
 
 def hbm_traffic():
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
-    correction + WRITE_SIZE), recorded under profiles/ -- counters cannot be read from inside this process"""
+    """HBM bytes per launch of the fused-cell kernels from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
+    correction + WRITE_SIZE; profiles/r02_lstm_cell_pmc.json, written by tools/refresh_profiles.sh) -- PMC counters cannot
+    be read from inside this process, so this is the recorded figure of the same kernels on the same workload, or None"""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_dw_gemm_hbm_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r02_lstm_cell_pmc.json')) as f:
             return json.load(f)['traffic_bytes_per_launch']
     except Exception:
         return None
@@ -88,27 +97,71 @@ def log(msg):
     sys.stderr.flush()
 
 
-def cpu_baseline(cfg, pool, budget_s=20.0):
-    """oracle torch-CPU restatement timed on the host cores: bounded sample of the same workload"""
+def _affinity():
+    return len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+
+
+def cpu_baseline(cfg, pool, shape, budget_s=18.0):
+    """The reference's CPU path, timed as this repository's CPU restatements of the identical op graph ("port": TensorFlow
+    cannot run on either box) on a bounded sample of the SAME workload, same episodes as the GPU run.
+    Variants: torch-CPU (MKL GEMMs, the closest stand-in for TF-Eigen) and, when its recipe has been built
+    (oracle/Makefile -> oracle/_build/libcpuref.so), the plain C++/OpenMP restatement.  Reports host cores used/available,
+    train and eval episodes/s and the NLL agreement with the GPU on the first sample episode."""
     import torch
     from oracle import lstm_oracle as O
     from oracle.torch_ref import TorchRef
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    cores = min(avail, int(os.environ.get('FSMG_CPU_THREADS', 16)))   # measured on the 2x EPYC 9575F host: 8/16/32/64/128 threads -> 0.49/0.57/0.45/0.24/0.09 episodes/s
-    ref = TorchRef(cfg, O.glorot_init(cfg, cfg['seed'], np.float32), dtype=torch.float32, threads=cores)
-    log('cpu_baseline: %d threads (of %d available), warm-up step' % (cores, avail))
+    avail = _affinity()
+    # thread count: the T = 128 recurrence is a chain of small [45 x 762] x [762 x 2048] matmuls (94 MFLOP each); beyond
+    # ~16 threads the per-op fork/join and cross-CCD traffic outweigh the extra FLOPs (measured on the 2x EPYC 9575F host,
+    # 8/16/32/64/128 threads: 0.49/0.57/0.45/0.24/0.09 episodes/s), so more cores make THIS graph slower, not faster
+    cores = min(avail, int(os.environ.get('FSMG_CPU_THREADS', 16)))
+    try:
+        torch.set_num_interop_threads(1)          # one op at a time: the graph is a dependency chain anyway
+    except RuntimeError:
+        pass                                      # already fixed by earlier parallel work in this process
+    params = O.glorot_init(cfg, cfg['seed'], np.float32)
+    ref = TorchRef(cfg, params, dtype=torch.float32, threads=cores)
+    log('cpu_baseline[torch]: %d threads (of %d available), warm-up step' % (cores, avail))
+    first_eval = ref.eval(pool[0][1])
     ref.train(*pool[0])                                   # warm-up
-    log('cpu_baseline: timing')
+    log('cpu_baseline[torch]: timing')
     n, t0 = 0, time.perf_counter()
     while True:
         ref.train(*pool[(n + 1) % len(pool)])
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 64:
+        if dt >= budget_s * 0.75 or n >= 64:
             break
-    return {'value': n / dt, 'unit': 'episodes/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d train episodes of the same cfg-B workload (torch-CPU fp32 restatement, %d threads, %.1f s)'
-                      % (n, cores, dt)}
+    ne, t1 = 0, time.perf_counter()
+    while True:
+        ref.eval(pool[(ne + 1) % len(pool)][1])
+        ne += 1
+        de = time.perf_counter() - t1
+        if de >= budget_s * 0.25 or ne >= 64:
+            break
+    variants = [{'name': 'torch-cpu', 'train_episodes_per_s': n / dt, 'eval_episodes_per_s': ne / de, 'threads': cores,
+                 'train_eps': n, 'eval_eps': ne}]
+    try:
+        from oracle.cpu_ref import CpuRef
+        cx = CpuRef(cfg, params, threads=min(avail, int(os.environ.get('FSMG_CXX_THREADS', 32))))
+        log('cpu_baseline[cxx]: %d threads, timing' % cx.threads)
+        cx.train(*pool[0])
+        nc, t2 = 0, time.perf_counter()
+        while True:
+            cx.train(*pool[(nc + 1) % len(pool)])
+            nc += 1
+            dc = time.perf_counter() - t2
+            if dc >= budget_s * 0.5 or nc >= 64:
+                break
+        variants.append({'name': 'c++/openmp', 'train_episodes_per_s': nc / dc, 'threads': cx.threads, 'train_eps': nc})
+    except Exception as e:                                 # not built on this box: the torch variant stands alone
+        log('cpu_baseline[cxx]: unavailable (%s)' % str(e)[:80])
+    best = max(variants, key=lambda v: v['train_episodes_per_s'])
+    return {'value': best['train_episodes_per_s'], 'unit': 'episodes/s', 'cores': best['threads'], 'kind': 'port',
+            'cores_used': best['threads'], 'cores_available': avail, 'variants': variants,
+            'train_eps': n, 'eval_eps': ne, 'first_eval_nll': float(first_eval),
+            'sample': '%d train + %d eval episodes of the same %d-way %d-shot workload (fp32 CPU restatement of the reference '
+                      'graph, best of %s; %.1f s)' % (n, ne, shape[0], shape[1], '/'.join(v['name'] for v in variants), dt + de)}
 
 
 def main():
@@ -118,13 +171,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
-    ap.add_argument('--config', default='cfg-B', choices=['cfg-B', 'cfg-C', 'cfg-D', 'cfg-Bx4', 'cfg-Bx8'])
+    ap.add_argument('--config', default='cfg-B', choices=['cfg-B', 'cfg-C', 'cfg-D', 'cfg-Bx4', 'cfg-Bx8', 'cfg-E'])
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from fsmg.dist import EpisodeParallel, init_from_env
-    from models.lstm_baseline import LSTMBaseline
 
     rank, world = init_from_env('nccl')
     if world != args.gpus:
@@ -137,6 +189,7 @@ def main():
         base, N_WAY, K_SHOT, Q_QUERY = OTHER[args.config]
     cfg = dict(base, device=local)
     B = N_WAY * (K_SHOT + Q_QUERY)
+    maml = (cfg['inner_steps'], cfg['inner_lr']) if args.config == 'cfg-E' else None
 
     pool_host = synthetic_episodes(POOL, N_WAY, K_SHOT, Q_QUERY, cfg['max_len'], cfg['input_size'], seed=1234 + rank)
     d_sup = torch.from_numpy(np.stack([s for s, _ in pool_host])).cuda()
@@ -144,17 +197,22 @@ def main():
     sup_stride, qry_stride = d_sup[0].numel() * 4, d_qry[0].numel() * 4
 
     log('rank %d/%d: pool on device, creating model' % (rank, world))
-    model = LSTMBaseline(cfg)
+    if maml:
+        from models.maml_lstm import MAMLLSTM as Model
+    else:
+        from models.lstm_baseline import LSTMBaseline as Model
+    model = Model(cfg)
     model.recover_or_init('')
     log('model ready')
     par = EpisodeParallel(model)
     eng = model.engine
     shape = (N_WAY, K_SHOT, Q_QUERY)
+    kw = dict(maml=maml) if maml else {}
 
     def step(i):
         e = i % POOL
         par.train_step(d_sup.data_ptr() + e * sup_stride, d_qry.data_ptr() + e * qry_stride,
-                       want_loss=False, shape=shape)
+                       want_loss=False, shape=shape, **kw)
 
     def barrier():
         torch.cuda.synchronize()
@@ -162,32 +220,66 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step0 = eng.step
     for i in range(args.warmup):
         step(i)
         if i == 0:
             torch.cuda.synchronize()
             log('first step done')
     barrier()
+    step_before = eng.step
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
     log('timed region done: %.3f s for %d steps' % (elapsed, args.steps))
-    # roofline leg: the same K steps again with HIP events bracketing every launch of the dominant kernel on
-    # the library's stream (event timing needs eager launches, so the step's hipGraph replay is off here;
-    # the kernel, its arguments and its data are identical to the timed region's)
-    eng.timing_select(DOMINANT)
-    eng.timing_enable(True)
-    eng.timing_reset()
-    for i in range(args.steps):
-        step(args.warmup + args.steps + i)
-    dom_ms, dom_n = eng.timing_read(DOMINANT)
-    eng.timing_enable(False)
+    # ---- guard: the timed region did the work it claims.  A step whose persistent kernel times out (or whose batch is
+    # rejected) is SKIPPED on the device -- no Adam, no global_step -- so a poisoned region would time no-ops.
+    step_after = eng.step
+    stats = eng.stats()
+    guard = {'global_step_before': step_before, 'global_step_after': step_after,
+             'advanced_by': step_after - step_before, 'expected': args.steps,
+             'warmup_advanced_by': step_before - step0, 'timeouts': stats['timeouts'],
+             'steps_skipped_timeout': stats['steps_skipped_timeout'], 'steps_skipped_token_range': stats['steps_skipped_token_range'],
+             'persistent_path': bool(stats['persistent_path']), 'xcd_local_kernels': stats['xcd_launches'] > 0,
+             'ok': (step_after - step_before == args.steps and step_before - step0 == args.warmup and stats['timeouts'] == 0
+                    and stats['steps_skipped_timeout'] == 0 and stats['steps_skipped_token_range'] == 0)}
+    local_elapsed = elapsed
+    per_rank = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, float(guard['ok'])], dtype=torch.float64, device='cuda')
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(g[0].item()) for g in gathered]
+        guard['ok'] = all(bool(g[1].item()) for g in gathered)
+        elapsed = max(per_rank)
+    if not guard['ok']:
+        log('GUARD FAILED: %r' % guard)
+    # ---- roofline leg: the same K steps again with HIP events around every launch of the fused-cell kernels on the library's
+    # stream, in the schedule of the timed region (event timing replaces the hipGraph replay by the same launches, eagerly)
+    cell = {}
+    if not maml:
+        for cls in CELL_CLASSES:
+            eng.timing_select(cls)
+            eng.timing_enable(True)
+            eng.timing_reset()
+            for i in range(args.steps):
+                step(args.warmup + args.steps + i)
+            cell[cls] = eng.timing_read(cls)
+            eng.timing_enable(False)
+    # exposed communication (N > 1): time of the all-reduce leg = step time with the exchange minus without is not measurable
+    # in-process; the collectives are bracketed with events on the communication stream instead
+    comm = None
+    if world > 1:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with model.stream_context():
+            ev0.record()
+            for _ in range(5):
+                dist.all_reduce(model.grad_tensor, op=dist.ReduceOp.SUM)
+            ev1.record()
+        torch.cuda.synchronize()
+        comm = {'allreduce_ms_standalone': ev0.elapsed_time(ev1) / 5, 'bytes': int(model.grad_tensor.numel() * 4)}
     losses = eng.read_losses(min(args.steps, 1024)) if args.steps > 0 else np.zeros(1)
 
     out = None
@@ -195,24 +287,44 @@ def main():
         gf = algorithmic_gflop(cfg, B)
         value = world * args.steps / elapsed
         total_gflop = 3 * (gf['gemm_zx'] + gf['lstm_fwd'] + gf['gemm_logits'])
-        dom_avg_ms = dom_ms / max(dom_n, 1)
-        achieved = gf[DOMINANT] / dom_avg_ms if dom_n else 0.0        # GFLOP/ms == TFLOP/s
+        names = {'cfg-B': 'cfg-B: synthetic V=10000 (V1=10001) T=128 5-way 5-shot 4-query (B=45 sequences/episode), LSTM E=250 H=512 L=1'}
+        wl = names.get(args.config, '%s (diagnostic run, not the headline workload): V=%d T=%d %d-way %d-shot %d-query, LSTM E=%d H=%d L=%d'
+                       % (args.config, cfg['input_size'], cfg['max_len'], N_WAY, K_SHOT, Q_QUERY, cfg['embedding_size'],
+                          cfg['hidden_size'], cfg['n_layers']))
         out = {
             'metric': 'episodes/s (LSTM-baseline train step, synthetic vocab=10k seq_len=128 5-way/5-shot h=512)',
             'value': value, 'unit': 'episodes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': (args.config + ' (diagnostic run, not the headline workload) -- ' if args.config != 'cfg-B' else '') + 'cfg-B: synthetic V=10000 (V1=10001) T=128 5-way 5-shot 4-query (B=45 sequences/episode), '
-                                   'LSTM E=250 H=512 L=1, full train step (fwd+BPTT+clip+Adam), one episode per GPU per step',
+            'config': {'workload': wl + (', MAML-style step (1 inner clipped-SGD step on the support rows + outer clip+Adam on the query gradient)'
+                                         if maml else ', full train step (fwd+BPTT+clip+Adam)') + ', one episode per GPU per step',
                        'episodes_per_step': world, 'parallelism': 'episode-parallel x%d, 1 RCCL all-reduce/step' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_gemm<XC,XC> = k_gemm<1, 1> (dW = out^T * dlogits, M=512 N=10004 K=5760)',
-                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': hbm_traffic(),
-                         'avg_launch_ms': dom_avg_ms, 'launches': dom_n, 'algorithmic_gflop_per_launch': gf[DOMINANT]},
-            'step_mfma_frac': (total_gflop / (1e3 * elapsed / max(args.steps, 1))) / PEAK_F32_MFMA_TFLOPS,
+            'guard': guard,
+            'step_mfma_frac': None if maml else (total_gflop / (1e3 * elapsed / max(args.steps, 1))) / PEAK_F32_MFMA_TFLOPS,
             'final_loss': float(losses[-1]), 'first_loss': float(losses[0]),
+            'per_rank_ms_per_step': [1e3 * t / max(args.steps, 1) for t in per_rank], 'comm': comm,
         }
-    if rank == 0:
+        if cell:
+            T = cfg['max_len']
+            tot_ms = sum(ms for ms, _ in cell.values())
+            tot_n = sum(n for _, n in cell.values())
+            gflop = sum(gf[c] for c in cell) * args.steps                 # both directions, every launch of the repeat
+            ach = gflop / tot_ms if tot_ms > 0 else 0.0
+            steps_per_launch = {c: (T * cfg['n_layers'] * args.steps) / max(n, 1) for c, (ms, n) in cell.items()}
+            out['roofline'] = {
+                'bound': 'mfma',
+                'kernel': 'fused LSTM cell: k_lstm_fwd_xcd + k_lstm_bwd_xcd (recurrent [B x H] x [H x 4H] contraction on v_mfma_f32_4x4x1_16B_f32 '
+                          '+ gate nonlinearities / gate gradients + state update, %d dependent time steps per launch)' % int(steps_per_launch['lstm_fwd']),
+                'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+                'traffic': hbm_traffic(), 'launches': tot_n, 'avg_launch_ms': tot_ms / max(tot_n, 1),
+                'algorithmic_gflop_per_launch': gf['lstm_fwd'] / max(cell['lstm_fwd'][1] / max(args.steps, 1), 1),
+                'forward': {'avg_launch_ms': cell['lstm_fwd'][0] / max(cell['lstm_fwd'][1], 1), 'us_per_time_step': 1e3 * cell['lstm_fwd'][0] / (T * cfg['n_layers'] * args.steps),
+                            'frac': gf['lstm_fwd'] * args.steps / cell['lstm_fwd'][0] / PEAK_F32_MFMA_TFLOPS},
+                'backward': {'avg_launch_ms': cell['lstm_bwd'][0] / max(cell['lstm_bwd'][1], 1), 'us_per_time_step': 1e3 * cell['lstm_bwd'][0] / (T * cfg['n_layers'] * args.steps),
+                             'frac': gf['lstm_bwd'] * args.steps / cell['lstm_bwd'][0] / PEAK_F32_MFMA_TFLOPS},
+                'note': 'algorithmic 2*B*H*4H FLOP per time step (SURVEY.md 8d, recurrent-only) over the HIP-event time of the launches in the timed '
+                        'schedule; latency-bound chain: us_per_time_step is the figure to watch (0.60 us at the MFMA peak)'}
+    if rank == 0 and not maml:
         # the other half of BASELINE.json's metric: the validation path (query-only forward, batched 16 episodes
         # per call like train.evaluate does); inputs resident in HBM, NLLs read back per call
         n_ev, reps = 16, 5
@@ -224,8 +336,8 @@ def main():
             nll = eng.eval_batch(qptr + r * n_ev * qry_stride, shape=(n_ev, N_WAY, Q_QUERY))
         torch.cuda.synchronize()
         out['eval'] = {'episodes_per_s': n_ev * reps / (time.perf_counter() - t0), 'batch_episodes': n_ev,
-                       'mean_val_nll': float(np.mean(nll)), 'unit': 'eval episodes/s (query-only forward, 20 sequences/episode)'}
-    if rank == 0 and world == 1:
+                       'mean_val_nll': float(np.mean(nll)), 'unit': 'eval episodes/s (query-only forward, %d sequences/episode)' % (N_WAY * Q_QUERY)}
+    if rank == 0 and world == 1 and not maml:
         # the reference's calling convention: host numpy episodes in, the loss read back every step (one 23 KB H2D
         # token copy + one synchronising 4-byte D2H per step) -- PCIe-inclusive, never the headline value
         n_h = min(args.steps, 30)
@@ -234,7 +346,7 @@ def main():
             eng.train_step(*pool_host[i % POOL], want_loss=True)
         out['host_synchronous'] = {'episodes_per_s': n_h / (time.perf_counter() - t0),
                                    'note': 'host token buffers + per-step loss readback (reference train() semantics)'}
-    if rank == 0 and world == 1 and not args.no_breakdown:
+    if rank == 0 and world == 1 and not args.no_breakdown and not maml:
         # second, fully instrumented pass: every kernel class bracketed by HIP events (extra information)
         eng.timing_select(None)
         eng.timing_enable(True)
@@ -256,11 +368,24 @@ def main():
         eng.timing_enable(False)
         out['kernels'] = kernels
         log('breakdown done')
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(base, pool_host)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not maml:
+        out['cpu_baseline'] = cpu_baseline(base, pool_host, shape)
+        if out['cpu_baseline'] and 'eval' in out:
+            gpu_first = float(eng.eval_step(pool_host[0][1]))          # after training: not comparable; compare a fresh handle instead
+            from fsmg.binding import FsmgModel
+            fresh = FsmgModel(base, device=local)
+            from oracle import lstm_oracle as O
+            fresh.init_params(0)
+            fresh.set_params(O.glorot_init(base, base['seed'], np.float32))
+            g = float(fresh.eval_step(pool_host[0][1]))
+            fresh.close()
+            c = out['cpu_baseline']['first_eval_nll']
+            out['cpu_baseline']['nll_agreement'] = {'gpu': g, 'cpu': c, 'rel_diff': abs(g - c) / abs(c)}
+            del gpu_first
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:
+        sys.stdout.flush()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
