@@ -1,22 +1,41 @@
 #!/bin/bash
 # Regenerates the round artefacts on the GPU box into gpurun_out/ (copy the ones to keep into profiles/).
-#   gpurun -- tools/refresh_profiles.sh
+#   gpurun -- tools/refresh_profiles.sh [tag]
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > $O/r_bench.json 2> $O/r_bench.err
-FSMG_OVERLAP=0 python $R/bench.py --no-cpu-baseline > $O/r_bench_single.json 2>/dev/null
-rm -rf /tmp/prof_st; rocprofv3 --kernel-trace --stats -d /tmp/prof_st -o st -- python $R/bench.py --no-cpu-baseline > $O/r_bench_under_rocprof.json 2>/dev/null
-python $R/tools/rocpd_stats.py $(find /tmp/prof_st -name "*.db" | head -1) > $O/r_kernel_stats.txt 2>&1
-python $R/tools/step_timeline.py $(find /tmp/prof_st -name "*.db" | head -1) 30 > $O/r_timeline.txt 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_$c; rocprofv3 --pmc $c --kernel-trace -f csv -d /tmp/prof_$c -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-breakdown > /dev/null 2>&1
-  python - $(find /tmp/prof_$c -name "*counter_collection.csv" | head -1) $c >> $O/r_pmc_traffic.txt <<'PY'
-import csv, sys, collections
-agg = collections.defaultdict(list)
-for r in csv.DictReader(open(sys.argv[1])):
-    if 'k_gemm' in r['Kernel_Name'] and r['Counter_Name'] == sys.argv[2]:
-        agg[(r['Kernel_Name'].split('(')[0][-40:], r['Grid_Size'])].append(float(r['Counter_Value']))
-for (k, g), v in sorted(agg.items()):
-    print('%s %-40s grid %-9s launches %3d mean %.3f' % (sys.argv[2], k, g, len(v), sum(v) / len(v)))
-PY
+python $R/bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
+rm -rf /tmp/prof_st; rocprofv3 --kernel-trace --stats -d /tmp/prof_st -o st -- python $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprofv3.json
+python $R/tools/rocpd_stats.py $(find /tmp/prof_st -name "*.db" | head -1) > $O/${TAG}_bench_rocprofv3_kernel_stats.txt 2>&1
+python $R/tools/step_timeline.py $(find /tmp/prof_st -name "*.db" | head -1) 30 > $O/${TAG}_step_timeline.txt 2>&1
+# counters: separate passes (SQ block 8 slots; FETCH_SIZE and WRITE_SIZE do not fit one TCC pass), kernel-trace only
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+  n=$(echo $set | cut -d' ' -f1)
+  rm -rf /tmp/prof_$n; rocprofv3 --pmc $set --kernel-trace -f csv -d /tmp/prof_$n -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-breakdown > /dev/null 2>&1
+  f=$(find /tmp/prof_$n -name "*counter_collection.csv" | head -1)
+  python $R/tools/pmc_summary.py $f > $O/${TAG}_pmc_$n.txt 2>&1
+  cp $f $O/${TAG}_pmc_$n.csv 2>/dev/null
 done
+python - $O $TAG <<'PY'
+import csv, json, sys, collections
+O, TAG = sys.argv[1], sys.argv[2]
+def means(counter):
+    agg = collections.defaultdict(list)
+    try:
+        for r in csv.DictReader(open('%s/%s_pmc_%s.csv' % (O, TAG, counter))):
+            if r['Counter_Name'] == counter and ('k_lstm_fwd_xcd' in r['Kernel_Name'] or 'k_lstm_bwd_xcd' in r['Kernel_Name']):
+                agg['fwd' if 'fwd' in r['Kernel_Name'] else 'bwd'].append(float(r['Counter_Value']))
+    except Exception as e:
+        print('no', counter, e)
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+f, w = means('FETCH_SIZE'), means('WRITE_SIZE')
+# rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB; gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM)
+out = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --steps 4 --warmup 2`, means per launch',
+       'fetch_size_kb': f, 'write_size_kb': w}
+if f and w:
+    per = {k: 2.0 * f[k] * 1024 + w.get(k, 0.0) * 1024 for k in f}
+    out['traffic_bytes_per_launch_by_kernel'] = per
+    out['traffic_bytes_per_launch'] = sum(per.values()) / max(len(per), 1)
+json.dump(out, open('%s/%s_lstm_cell_pmc.json' % (O, TAG), 'w'), indent=1)
+print(json.dumps(out))
+PY
