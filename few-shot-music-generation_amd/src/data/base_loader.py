@@ -58,6 +58,8 @@ class Loader(object):
         row = np.zeros(self.max_len, dtype=self.dtype)
         n = min(self.max_len, len(ids))
         row[:n] = ids[:n]
-        if self.persist:
-            np.save(sidecar, row)
+        if self.persist:                        # atomically: another rank must never np.load a half-written sidecar
+            tmp = '%s.%d.tmp.npy' % (sidecar, os.getpid())
+            np.save(tmp, row)
+            os.replace(tmp, sidecar)
         return row

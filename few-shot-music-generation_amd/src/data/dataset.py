@@ -52,6 +52,13 @@ class Metadata(object):
             self.open_files[filename] = open(self.path(filename), 'a')
         self.open_files[filename].write(line)
 
+    def write_whole(self, filename, text):
+        """a complete file in one atomic step (tmp + rename): a concurrent reader sees the old file or the new one, never half"""
+        tmp = '%s.%d.tmp' % (self.path(filename), os.getpid())
+        with open(tmp, 'w') as f:
+            f.write(text)
+        os.replace(tmp, self.path(filename))
+
     def close(self):
         for f in self.open_files.values():
             f.close()
@@ -166,7 +173,9 @@ class Dataset(object):
         parts = {'train': kept[:n_train], 'val': kept[n_train:n_train + n_val], 'test': kept[n_train + n_val:]}
         if persist:
             for name in ('train', 'val', 'test'):
-                self.metadata.write('%s.csv' % name, '\n'.join(parts[name]))
+                # the reference appends '\n'.join(artists) with no trailing newline (dataset.py:171-174): two writers would glue
+                # two artists into one bogus name.  One atomic write per split file; readers strip and skip blank lines
+                self.metadata.write_whole('%s.csv' % name, '\n'.join(parts[name]) + ('\n' if parts[name] else ''))
         return parts.get(split, parts['test'])
 
     # -- access ------------------------------------------------------------------

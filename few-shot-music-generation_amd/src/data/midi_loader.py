@@ -272,8 +272,10 @@ class MIDILoader(Loader):
         try:
             import pretty_midi
         except ImportError:
-            raise OSError('parsing raw MIDI needs pretty_midi; only pre-tokenised %s sidecars can be loaded without it'
-                          % self.sidecar_path(filepath))
+            # NOT an OSError: Loader.validate swallows those as "invalid song", every raw .mid would be rejected silently and
+            # an empty train/val/test split persisted; the reference fails at import time, so this must abort as well
+            raise RuntimeError('parsing raw MIDI needs pretty_midi; only pre-tokenised %s sidecars can be loaded without it'
+                               % self.sidecar_path(filepath))
         return pretty_midi.PrettyMIDI(filepath)
 
     def tokenize(self, midi):

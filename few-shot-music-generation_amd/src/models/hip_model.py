@@ -135,8 +135,9 @@ class HIPModel(BaseModel):
                 if key in blob and blob[key].shape == want:
                     self._model.set_param(name, blob[key])
                     restored.add(name)
-                    if 'adam_m/' + name in blob and blob['adam_m/' + name].shape == want:
-                        self._model.set_opt_state(name, blob['adam_m/' + name], blob['adam_v/' + name])
+                    km, kv = 'adam_m/' + name, 'adam_v/' + name
+                    if km in blob and kv in blob and blob[km].shape == want and blob[kv].shape == want:
+                        self._model.set_opt_state(name, blob[km], blob[kv])
             if 'global_step' in blob:
                 self._model.step = int(blob['global_step'])
         return restored

@@ -87,11 +87,20 @@ def main(argv=None):
     say('Config:')
     say(PP.pformat(config))
 
+    # Building a sampler validates songs, tokenises them and PERSISTS sidecars / split files next to the dataset.  Under
+    # torchrun the chief does that alone; the other ranks wait and then load what it wrote (identical datasets on every
+    # rank, no two writers on one file).
+    if world > 1 and not chief:
+        import torch.distributed as dist
+        dist.barrier()
     episode_sampler = {}
     for split in config['splits']:
         config['split'] = split
         sampler = load_sampler_from_config(config)
         episode_sampler[split] = ShardedEpisodeSampler(sampler, rank, world) if world > 1 else sampler
+    if world > 1 and chief:
+        import torch.distributed as dist
+        dist.barrier()
 
     config['input_size'] = episode_sampler['train'].get_num_unique_words()
     if not config['input_size'] > 0:

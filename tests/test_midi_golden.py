@@ -58,6 +58,8 @@ def test_midi_file_writer_and_loader_padding(tmp_path, gold):
     mid.write_bytes(b'')
     np.save(str(mid) + '.16.npy', np.arange(16, dtype=np.int32))
     assert MIDILoader(16).load(str(mid)).tolist() == list(range(16))
-    with pytest.raises(OSError):
+    with pytest.raises(RuntimeError):
         MIDILoader(8).load(str(mid))            # no sidecar for max_len=8 and no pretty_midi to parse with
-    assert MIDILoader(8).validate(str(mid)) is False and MIDILoader(8).is_song('x.mid')
+    with pytest.raises(RuntimeError):           # ... and validate() must NOT swallow the missing dependency as "invalid song"
+        MIDILoader(8).validate(str(mid))        # (that would persist an empty split; the reference fails at import time)
+    assert MIDILoader(8).is_song('x.mid')
