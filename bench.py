@@ -346,6 +346,22 @@ def main():
             eng.train_step(*pool_host[i % POOL], want_loss=True)
         out['host_synchronous'] = {'episodes_per_s': n_h / (time.perf_counter() - t0),
                                    'note': 'host token buffers + per-step loss readback (reference train() semantics)'}
+        # what train.train does here: the split's token table resident in HBM, an episode = 45 row indices from the host
+        # sampler (180 B H2D), losses read from the device ring once per log line
+        table = np.concatenate([np.concatenate([s.reshape(-1, cfg['max_len']), q.reshape(-1, cfg['max_len'])]) for s, q in pool_host[:32]])
+        eng.upload_table(0, table)
+        rng = np.random.RandomState(7)
+        idx = [(rng.randint(0, table.shape[0], size=(N_WAY, K_SHOT)), rng.randint(0, table.shape[0], size=(N_WAY, Q_QUERY))) for _ in range(64)]
+        n_i = max(args.steps, 30)
+        for i in range(3):
+            eng.train_step_indexed(0, *idx[i], want_loss=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_i):
+            eng.train_step_indexed(0, *idx[i % 64], want_loss=False)
+        _ = eng.read_losses(min(n_i, 1024))
+        out['host_indexed_deferred'] = {'episodes_per_s': n_i / (time.perf_counter() - t0),
+                                        'note': 'host sampler indices into the device-resident table, losses read once per window (train.train fast path)'}
     if rank == 0 and world == 1 and not args.no_breakdown and not maml:
         # second, fully instrumented pass: every kernel class bracketed by HIP events (extra information)
         eng.timing_select(None)

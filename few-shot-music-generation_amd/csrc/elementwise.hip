@@ -2,6 +2,7 @@
 // deterministic reductions, embedding-gradient segmented sum, global-norm + TF-style Adam,
 // parameter init and the greedy-decode GEMVs.  wave64 everywhere; reductions use
 // __shfl_xor over 64 lanes.
+#include <algorithm>
 #include "fsmg_kernels.h"
 
 namespace fsmg {
@@ -56,6 +57,19 @@ __global__ void k_token_prep(const int* __restrict__ support, int n_support, con
         Y[(long long)t * B + b] = tok;
         if (t + 1 < T) X[(long long)(t + 1) * B + b] = tok;
         if (t == 0) X[b] = start_word;
+    }
+}
+
+// Episode gather from the device-resident split table (reference src/data/episode.py:62-74 fills the same rows from its
+// per-song cache): out[r][t] = table[idx[r]][t]; an index outside [0, n_songs) raises the token-range flag.
+__global__ void k_gather_rows(const int* __restrict__ table, const int* __restrict__ idx, int n_rows, int T, int n_songs,
+                              int* __restrict__ out, int* __restrict__ err_flag) {
+    const long long total = (long long)n_rows * T;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / T), t = (int)(i % T);
+        int song = idx[r];
+        if (song < 0 || song >= n_songs) { atomicOr(err_flag, 1); song = 0; }
+        out[i] = table[(long long)song * T + t];
     }
 }
 
@@ -512,6 +526,13 @@ hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX
     if (n <= 0) return hipSuccess;
     if (Ep > 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_embed_grad, dim3(n), dim3(256), 0, s, X, n, dX, Ep, dEmb);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(hipStream_t s, const int* table, const int* idx, int n_rows, int T, int n_songs, int* out, int* err_flag) {
+    if (n_rows <= 0) return hipSuccess;
+    const long long total = (long long)n_rows * T;
+    hipLaunchKernelGGL(k_gather_rows, dim3((int)std::min<long long>((total + 255) / 256, 1024)), dim3(256), 0, s, table, idx, n_rows, T, n_songs, out, err_flag);
     return hipGetLastError();
 }
 

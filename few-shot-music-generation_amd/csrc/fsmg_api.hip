@@ -96,6 +96,10 @@ struct fsmg_model {
     bool persist = true;                // FSMG_PERSISTENT=0: one launch per time step instead of one persistent launch per chain chunk
     float* khf = nullptr;               // fragment-ordered recurrent weights: per layer fwd copy, bwd copy
     float* P_saved = nullptr;           // cfg-E: theta while the handle computes at the adapted theta'
+    static constexpr int MAX_TABLES = 4;
+    int* table[MAX_TABLES] = {};        // device-resident packed splits [n_songs][T] (fsmg_upload_table)
+    int64_t table_rows[MAX_TABLES] = {};
+    int* d_idx = nullptr; int idx_cap = 0;
     // XCD-local recurrence (lstm_xcd.hip; hidden size 512): per layer the forward and backward register images of K_h,
     // the h hand-off buffer, the dh-partial inboxes and the per-launch ticket counters
     bool xcd = true;                    // FSMG_XCD=0: keep the column-split persistent kernels
@@ -987,6 +991,38 @@ inline uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
+// forward + backward of one episode whose tokens `stage` puts into the handle's staging buffer ([n_sup + n_qry][T], support rows first)
+template <class Stage>
+int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&& stage) {
+    hipSetDevice(h->device);
+    int rc = validate_shape(h, N, K, Q);
+    if (rc != FSMG_OK) return rc;
+    const int B = N * (K + Q);
+    if (h->fallback_left > 0 && --h->fallback_left == 0 && h->persist != h->persist_cfg) {   // try the persistent path again
+        h->persist = h->persist_cfg;
+        drop_graphs(h);
+    }
+    if ((rc = ensure_scratch(h, B)) != FSMG_OK) return rc;
+    choose_schedule(h, B);
+    if ((rc = ensure_khf(h)) != FSMG_OK) return rc;
+    if ((rc = stage()) != FSMG_OK) return rc;
+    const int n_sup = N * K, n_qry = N * Q;
+    rc = run_graphed(h, "fb:" + std::to_string(n_sup) + ":" + std::to_string(n_qry), [&]() -> int {
+        int r = token_prep(h, n_sup, n_qry);
+        if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1, true);
+        if (r == FSMG_OK) r = backward(h, B);
+        return r;
+    });
+    if (rc != FSMG_OK) return rc;
+    // bucket readiness for an overlapped gradient exchange: with the two-stream (eager) schedule bucket 0 was
+    // recorded right behind the dW GEMM on the aux stream; a replayed graph finishes as a whole
+    if (!use_overlap(h)) HIPCK(h, hipEventRecord(h->ev_bucket[0], h->stream));
+    HIPCK(h, hipEventRecord(h->ev_bucket[1], h->stream));
+    h->lastB = B;
+    h->have_grads = true;
+    return FSMG_OK;
+}
+
 }  // namespace
 
 // =========================================================================== C ABI
@@ -1128,6 +1164,8 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->khf) hipFree(h->khf);
     if (h->khx) hipFree(h->khx);
     if (h->P_saved) hipFree(h->P_saved);
+    for (int* t : h->table) if (t) hipFree(t);
+    if (h->d_idx) hipFree(h->d_idx);
     if (h->d_eval) hipFree(h->d_eval);
     if (h->host_counters) hipHostFree(h->host_counters);
     if (h->own_state && h->state) hipFree(h->state);
@@ -1236,33 +1274,57 @@ int fsmg_get_grad(fsmg_handle h, const char* name, float* host, int64_t count) {
 int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K,
                           int32_t Q, int32_t tokens_on_device) {
     if (!h || !support || !query) return FSMG_ERR_INVALID;
+    return forward_backward_core(h, N, K, Q, [&]() { return stage_tokens(h, support, N * K, query, N * Q, tokens_on_device); });
+}
+
+// ---- device-resident episode table: a split's packed [n_songs][T] token table lives in HBM and an
+// episode is an index gather on the GPU (reference src/data/episode.py:62-74, src/data/dataset.py:187-199 fill the same
+// rows from the host cache): a step uploads N*(K+Q) indices (180 B at cfg-B) instead of 23 KB of tokens.
+int fsmg_upload_table(fsmg_handle h, int32_t table_id, const int32_t* host_table, int64_t n_songs) {
+    if (!h || !host_table || table_id < 0 || table_id >= fsmg_model::MAX_TABLES || n_songs <= 0 || n_songs > (1LL << 30) / std::max(1, h->T))
+        return h ? fail(h, FSMG_ERR_INVALID, "bad table id / size") : FSMG_ERR_INVALID;
     hipSetDevice(h->device);
-    int rc = validate_shape(h, N, K, Q);
-    if (rc != FSMG_OK) return rc;
-    const int B = N * (K + Q);
-    if (h->fallback_left > 0 && --h->fallback_left == 0 && h->persist != h->persist_cfg) {   // try the persistent path again
-        h->persist = h->persist_cfg;
-        drop_graphs(h);
-    }
-    if ((rc = ensure_scratch(h, B)) != FSMG_OK) return rc;
-    choose_schedule(h, B);
-    if ((rc = ensure_khf(h)) != FSMG_OK) return rc;
-    if ((rc = stage_tokens(h, support, N * K, query, N * Q, tokens_on_device)) != FSMG_OK) return rc;
-    const int n_sup = N * K, n_qry = N * Q;
-    rc = run_graphed(h, "fb:" + std::to_string(n_sup) + ":" + std::to_string(n_qry), [&]() -> int {
-        int r = token_prep(h, n_sup, n_qry);
-        if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1, true);
-        if (r == FSMG_OK) r = backward(h, B);
-        return r;
-    });
-    if (rc != FSMG_OK) return rc;
-    // bucket readiness for an overlapped gradient exchange: with the two-stream (eager) schedule bucket 0 was
-    // recorded right behind the dW GEMM on the aux stream; a replayed graph finishes as a whole
-    if (!use_overlap(h)) HIPCK(h, hipEventRecord(h->ev_bucket[0], h->stream));
-    HIPCK(h, hipEventRecord(h->ev_bucket[1], h->stream));
-    h->lastB = B;
-    h->have_grads = true;
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->table[table_id]) { hipFree(h->table[table_id]); h->table[table_id] = nullptr; h->table_rows[table_id] = 0; }
+    const size_t bytes = sizeof(int) * (size_t)n_songs * h->T;
+    if (hipMalloc((void**)&h->table[table_id], bytes) != hipSuccess) return fail(h, FSMG_ERR_NOMEM, "hipMalloc(token table) failed");
+    HIPCK(h, hipMemcpy(h->table[table_id], host_table, bytes, hipMemcpyHostToDevice));
+    h->table_rows[table_id] = n_songs;
     return FSMG_OK;
+}
+
+static int stage_indexed(fsmg_handle h, int32_t table_id, const int32_t* sup_idx, int n_sup, const int32_t* qry_idx, int n_qry) {
+    if (table_id < 0 || table_id >= fsmg_model::MAX_TABLES || !h->table[table_id]) return fail(h, FSMG_ERR_STATE, "no token table uploaded under this id");
+    const int n = n_sup + n_qry;
+    if (h->idx_cap < n) {
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        if (h->d_idx) hipFree(h->d_idx);
+        h->idx_cap = std::max(n, 4096);
+        if (hipMalloc((void**)&h->d_idx, sizeof(int) * h->idx_cap) != hipSuccess) { h->idx_cap = 0; h->d_idx = nullptr; return fail(h, FSMG_ERR_NOMEM, "hipMalloc(indices) failed"); }
+    }
+    if (n_sup > 0) HIPCK(h, hipMemcpyAsync(h->d_idx, sup_idx, sizeof(int) * n_sup, hipMemcpyHostToDevice, h->stream));
+    if (n_qry > 0) HIPCK(h, hipMemcpyAsync(h->d_idx + n_sup, qry_idx, sizeof(int) * n_qry, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, launch_gather_rows(h->stream, h->table[table_id], h->d_idx, n, h->T, (int)h->table_rows[table_id], h->d_tok, h->d_err));
+    return FSMG_OK;
+}
+
+int fsmg_forward_backward_indexed(fsmg_handle h, int32_t table_id, const int32_t* support_idx, const int32_t* query_idx,
+                                  int32_t N, int32_t K, int32_t Q) {
+    if (!h || !support_idx || !query_idx) return FSMG_ERR_INVALID;
+    return forward_backward_core(h, N, K, Q, [&]() { return stage_indexed(h, table_id, support_idx, N * K, query_idx, N * Q); });
+}
+
+int fsmg_train_step_indexed(fsmg_handle h, int32_t table_id, const int32_t* support_idx, const int32_t* query_idx,
+                            int32_t N, int32_t K, int32_t Q, float* loss) {
+    int rc = fsmg_forward_backward_indexed(h, table_id, support_idx, query_idx, N, K, Q);
+    if (rc != FSMG_OK) return rc;
+    rc = fsmg_apply_update(h, 1.0f, loss);
+    if (rc == FSMG_ERR_HIP && h->persist_timed_out) {
+        h->persist_timed_out = false;
+        rc = fsmg_forward_backward_indexed(h, table_id, support_idx, query_idx, N, K, Q);
+        if (rc == FSMG_OK) rc = fsmg_apply_update(h, 1.0f, loss);
+    }
+    return rc;
 }
 
 int fsmg_grad_buffer(fsmg_handle h, void** device_ptr, int64_t* count) {

@@ -170,6 +170,8 @@ hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a);
 hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);
 
 // ---------------------------------------------------------------- everything else (elementwise.hip)
+// out[r][0..T) = table[idx[r]][0..T) for r < n_rows (device-resident split table -> the token staging buffer)
+hipError_t launch_gather_rows(hipStream_t s, const int* table, const int* idx, int n_rows, int T, int n_songs, int* out, int* err_flag);
 // p[0 .. n_words) = word (p 16-byte aligned); the step uses this instead of hipMemsetAsync so that its hipGraph holds kernel nodes only
 hipError_t launch_fill32(hipStream_t s, void* p, uint32_t word, long long n_words);
 // tokens [nseq][T] (support rows then query rows) -> time-major input ids X[t][b] (start word at t=0)

@@ -95,6 +95,14 @@ class EpisodeSampler(object):
     def get_episode(self):
         return self.gather(*self.episode_indices())
 
+    def next_indices(self):
+        """the next episode of the stream as (support [N,K], query [N,Q]) row indices into token_table() -- same RNG
+        consumption as get_episode()"""
+        return self.episode_indices()
+
+    def token_table(self):
+        return self.dataset.token_table()[0]
+
     def get_episodes(self, n):
         """The next n episodes of the stream (same as n get_episode() calls)."""
         return [self.get_episode() for _ in range(n)]
@@ -115,13 +123,16 @@ class ShardedEpisodeSampler(object):
         assert 0 <= rank < world_size
         self.sampler, self.rank, self.world_size = sampler, rank, world_size
 
-    def get_episode(self):
+    def next_indices(self):
         mine = None
         for r in range(self.world_size):
             idx = self.sampler.episode_indices()
             if r == self.rank:
                 mine = idx
-        return self.sampler.gather(*mine)
+        return mine
+
+    def get_episode(self):
+        return self.sampler.gather(*self.next_indices())
 
     def __getattr__(self, name):
         return getattr(self.sampler, name)

@@ -64,6 +64,9 @@ SIGNATURES = {
     'fsmg_grad_bucket': (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
     'fsmg_stream_wait_bucket': (C.c_int, [_P, _P, C.c_int32]),
     'fsmg_apply_update': (C.c_int, [_P, C.c_float, _F32P]),
+    'fsmg_upload_table': (C.c_int, [_P, C.c_int32, _P, C.c_int64]),
+    'fsmg_forward_backward_indexed': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32]),
+    'fsmg_train_step_indexed': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _F32P]),
     'fsmg_maml_forward_backward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32]),
     'fsmg_maml_step': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _F32P]),
     'fsmg_maml_eval': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _F32P]),
@@ -265,6 +268,33 @@ class FsmgModel(object):
     def apply_update(self, grad_scale=1.0, want_loss=True):
         loss = C.c_float()
         self._ck(self._lib.fsmg_apply_update(self._h, float(grad_scale), C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
+
+    # -- device-resident episode table ----------------------------------------------------------------
+    def upload_table(self, table_id, table):
+        a = np.ascontiguousarray(table, dtype=np.int32)
+        if a.ndim != 2 or a.shape[1] != self.max_len:
+            raise ValueError('token table %r does not match max_len=%d' % (a.shape, self.max_len))
+        self._ck(self._lib.fsmg_upload_table(self._h, int(table_id), C.c_void_p(a.ctypes.data), a.shape[0]))
+
+    @staticmethod
+    def _idx(support_idx, query_idx):
+        s = np.ascontiguousarray(support_idx, dtype=np.int32)
+        q = np.ascontiguousarray(query_idx, dtype=np.int32)
+        if s.ndim != 2 or q.ndim != 2 or s.shape[0] != q.shape[0]:
+            raise ValueError('index arrays must be [N, K] and [N, Q]')
+        return s, q
+
+    def forward_backward_indexed(self, table_id, support_idx, query_idx):
+        s, q = self._idx(support_idx, query_idx)
+        self._ck(self._lib.fsmg_forward_backward_indexed(self._h, int(table_id), C.c_void_p(s.ctypes.data), C.c_void_p(q.ctypes.data),
+                                                         s.shape[0], s.shape[1], q.shape[1]))
+
+    def train_step_indexed(self, table_id, support_idx, query_idx, want_loss=True):
+        s, q = self._idx(support_idx, query_idx)
+        loss = C.c_float()
+        self._ck(self._lib.fsmg_train_step_indexed(self._h, int(table_id), C.c_void_p(s.ctypes.data), C.c_void_p(q.ctypes.data),
+                                                   s.shape[0], s.shape[1], q.shape[1], C.byref(loss) if want_loss else None))
         return loss.value if want_loss else None
 
     # -- cfg-E: MAML-style inner / outer loop ------------------------------------------------------

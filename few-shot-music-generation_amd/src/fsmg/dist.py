@@ -50,7 +50,8 @@ class EpisodeParallel(object):
                 dist.broadcast(tensor, src=0, group=self.group)
 
     def train_step(self, support, query, want_loss=True, **kw):
-        """kw: shape=(N, K, Q) for raw device token addresses; maml=(inner_steps, inner_lr) selects the cfg-E step (per-rank
+        """kw: shape=(N, K, Q) for raw device token addresses; table=id: support / query are row indices into the uploaded split
+        table; maml=(inner_steps, inner_lr) selects the cfg-E step (per-rank
         inner SGD on the support rows, no communication; the query-set gradients are exchanged exactly like a plain step's)"""
         try:
             return self._train_step_once(support, query, want_loss, **kw)
@@ -61,8 +62,10 @@ class EpisodeParallel(object):
                 raise
             return self._train_step_once(support, query, want_loss, **kw)
 
-    def _train_step_once(self, support, query, want_loss=True, maml=None, **kw):
-        if maml is not None:
+    def _train_step_once(self, support, query, want_loss=True, maml=None, table=None, **kw):
+        if table is not None:                 # support / query are [N,K] / [N,Q] row indices into a device-resident split table
+            self.engine.forward_backward_indexed(table, support, query)
+        elif maml is not None:
             self.engine.maml_forward_backward(support, query, maml[0], maml[1], **kw)
         else:
             self.engine.forward_backward(support, query, **kw)

@@ -67,6 +67,9 @@ class HIPModel(BaseModel):
     def forward_backward(self, support, query, **kw):
         self._model.forward_backward(support, query, **kw)
 
+    def forward_backward_indexed(self, table_id, support_idx, query_idx):
+        self._model.forward_backward_indexed(table_id, support_idx, query_idx)
+
     def maml_forward_backward(self, support, query, inner_steps, inner_lr, **kw):
         self._model.maml_forward_backward(support, query, inner_steps, inner_lr, **kw)
 

@@ -51,6 +51,30 @@ class LSTMBaseline(HIPModel):
         self._train_calls += 1
         return loss
 
+    # -- fast path of train.train: episodes as row indices into a device-resident split table, losses left on the device --
+    TABLE_IDS = {'train': 0, 'val': 1, 'test': 2}
+
+    def attach_table(self, split, table):
+        """Upload the packed [n_songs, max_len] int32 token table of a split (data.dataset.Dataset.token_table) once; episodes
+        of that split can then be given as row indices (train_indexed)."""
+        self._model.upload_table(self.TABLE_IDS[split], table)
+
+    def train_indexed(self, split, support_idx, query_idx, want_loss=False):
+        """Same step as train(episode) for the episode table[support_idx], table[query_idx]; with want_loss=False nothing is
+        read back (the loss goes to the device ring: recent_losses) and the host does not wait for the GPU."""
+        self._require_init()
+        loss = self._parallel.train_step(np.ascontiguousarray(support_idx, dtype=np.int32),
+                                         np.ascontiguousarray(query_idx, dtype=np.int32), want_loss=want_loss,
+                                         table=self.TABLE_IDS[split])
+        if want_loss:
+            self._log_scalar('Train/loss', loss, self._train_calls)
+        self._train_calls += 1
+        return loss
+
+    def recent_losses(self, n):
+        """the last n (<= 1024) train losses, oldest first; synchronises"""
+        return self._model.read_losses(int(n))
+
     def eval(self, episode):
         self._require_init()
         nll = self._model.eval_step(self._tokens(episode.query, 3))

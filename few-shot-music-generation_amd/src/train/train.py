@@ -121,17 +121,40 @@ def main(argv=None):
 
     say('Iter: %d, val-nll: %.3e' % (0, validate('val', n_val)))
 
-    avg_loss = 0.
+    # Fast path (same numbers, same log lines): the train split's packed token table lives in HBM, an episode travels as
+    # N*(K+Q) row indices, and the per-step loss stays in the device's ring until the next log line needs the window's
+    # mean -- the reference's loop (train.py:83-98) pays a blocking device->host read per step for `avg_loss +=`.
+    train_sampler = episode_sampler['train']
+    fast = (hasattr(model, 'attach_table') and hasattr(model, 'train_indexed') and hasattr(train_sampler, 'next_indices')
+            and os.environ.get('FSMG_TRAIN_SYNC', '0') == '0')
+    if fast:
+        model.attach_table('train', train_sampler.token_table())
+    RING = 1024
+    avg_loss, pending = 0., 0
+
+    def drain():                                   # fold the losses still on the device into avg_loss
+        nonlocal avg_loss, pending
+        if pending:
+            avg_loss += float(sum(model.recent_losses(pending)))
+            pending = 0
+
     for i in range(1, n_train + 1):
-        episode = episode_sampler['train'].get_episode()
-        avg_loss += model.train(episode)
+        if fast:
+            model.train_indexed('train', *train_sampler.next_indices())
+            pending += 1
+            if pending == RING:
+                drain()
+        else:
+            avg_loss += model.train(train_sampler.get_episode())
 
         if i % val_every_n == 0:            # val_every_n may be a float (Q11)
+            drain()
             say('Iter: %d, val-nll: %.3e' % (i, validate('val', n_val)))
             if args.checkpt_dir != '' and chief:
                 model.save(args.checkpt_dir)
 
         if i % print_every_n == 0:
+            drain()
             say('Iter: %d, loss: %.3e' % (i, avg_loss / print_every_n))
             avg_loss = 0.
 

@@ -137,6 +137,16 @@ int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss);
 int fsmg_grad_bucket(fsmg_handle h, int32_t bucket, void** device_ptr, int64_t* count);
 int fsmg_stream_wait_bucket(fsmg_handle h, void* stream, int32_t bucket);
 
+/* Device-resident episode table.  The reference fills an episode from a host cache of per-song rows
+ * (src/data/episode.py:62-74, src/data/dataset.py:187-199); here the packed split -- int32 [n_songs][max_len], the
+ * `.npy` sidecars of the split in artist/song order -- is uploaded once and an episode is N*K + N*Q ROW INDICES gathered on
+ * the GPU.  table_id in [0, 4) (e.g. 0 train, 1 val, 2 test).  An index outside [0, n_songs) -> FSMG_ERR_TOKEN_RANGE. */
+int fsmg_upload_table(fsmg_handle h, int32_t table_id, const int32_t* host_table, int64_t n_songs);
+int fsmg_forward_backward_indexed(fsmg_handle h, int32_t table_id, const int32_t* support_idx, const int32_t* query_idx,
+                                  int32_t N, int32_t K, int32_t Q);
+int fsmg_train_step_indexed(fsmg_handle h, int32_t table_id, const int32_t* support_idx, const int32_t* query_idx,
+                            int32_t N, int32_t K, int32_t Q, float* loss);
+
 /* replaces LSTMBaseline.eval (src/models/lstm_baseline.py:115-133): query-only mean NLL,
  * no state change. */
 int fsmg_eval_step(fsmg_handle h, const int32_t* query, int32_t N, int32_t Q,

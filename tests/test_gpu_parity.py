@@ -201,6 +201,32 @@ def test_device_resident_tokens_match_host_tokens():
     assert a.eval_step(qry) == b.eval_step(dq.data_ptr(), shape=(2, 1))
 
 
+def test_indexed_step_on_a_device_resident_table_equals_the_token_step():
+    """fsmg_upload_table + fsmg_train_step_indexed (the split's packed token table in HBM, an episode = row
+    indices gathered on the GPU) gives the bits of fsmg_train_step on the gathered tokens; losses left in the device ring
+    (want_loss=False) are the same numbers; a bad index is a token-range error and the update is skipped."""
+    from fsmg.binding import FsmgError
+    cfg = small_config(hidden_size=32, embedding_size=16, input_size=99, max_len=8)
+    rng = np.random.RandomState(3)
+    table = rng.randint(0, cfg['input_size'], size=(40, cfg['max_len'])).astype(np.int32)
+    a, b = new_model(cfg), new_model(cfg)
+    b.upload_table(0, table)
+    want, got = [], []
+    for s in range(4):
+        si, qi = rng.randint(0, 40, size=(3, 2)), rng.randint(0, 40, size=(3, 2))
+        want.append(a.train_step(table[si], table[qi]))
+        got.append(b.train_step_indexed(0, si, qi, want_loss=(s % 2 == 0)))
+    assert [g for g in got if g is not None] == want[0::2]
+    np.testing.assert_array_equal(b.read_losses(4), np.array(want, np.float32))
+    for k, v in a.get_params().items():
+        np.testing.assert_array_equal(b.get_param(k), v)
+    with pytest.raises(FsmgError, match='TOKEN_RANGE'):
+        b.train_step_indexed(0, np.array([[40, 0]]), np.array([[1, 2]]))
+    assert b.step == 4 and b.stats()['steps_skipped_token_range'] == 1
+    with pytest.raises(FsmgError, match='STATE'):
+        b.train_step_indexed(1, np.array([[0, 0]]), np.array([[1, 2]]))
+
+
 def test_all_schedules_are_bit_identical(monkeypatch):
     """two-stream overlap (default, eager) == single stream replayed from hipGraphs == single stream eager"""
     cfg = small_config(hidden_size=32, embedding_size=16, input_size=99, max_len=8, n_layers=2)

@@ -97,6 +97,15 @@ def test_main_with_lstm_baseline_on_gpu(tmp_path, golden_dir, capsys):
     T.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--checkpt_dir', str(tmp_path / 'ck2'),
             '--init_dir', ck])
     assert 'recovering lstm_baseline from' in capsys.readouterr().out
+    # the run above took the fast path (episodes as indices into the device-resident table, losses read per log line);
+    # the reference's calling convention (tokens + a loss read back per step) prints exactly the same lines
+    os.environ['FSMG_TRAIN_SYNC'] = '1'
+    try:
+        T.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--checkpt_dir', str(tmp_path / 'ck3')])
+    finally:
+        del os.environ['FSMG_TRAIN_SYNC']
+    sync_lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith('Iter: ') or 'Avg NLL' in l]
+    assert sync_lines == lines
 
 
 @pytest.mark.gpu
