@@ -1,0 +1,64 @@
+"""-m gpu: the episode-parallel path on the HIP engine.
+
+  * with >= 2 GPUs visible: 2 ranks over RCCL, one episode each, equal one rank on the concatenated batch (and, for the
+    MAML-style step, the oracle's mean of per-rank query gradients); replicas stay bit-identical.  Skipped on a 1-GPU box
+    (the driver's 8-GPU node runs it);
+  * on 1 GPU: the train step beside ANOTHER workload that holds CUs (large matmuls on a second stream -- what RCCL kernels or
+    a neighbour job do to the persistent recurrent kernels' co-residency): same numbers, and a time-out, if one happens, is
+    recovered and counted instead of poisoning later steps.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import free_port, small_config
+from gpu_utils import new_model
+from oracle import lstm_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('hidden,maml', [(48, 0), (512, 0), (48, 1)])
+def test_two_ranks_on_the_hip_engine_equal_one_rank_on_the_concatenated_batch(hidden, maml):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs (the 1-GPU box cannot place two ranks: "Duplicate GPU detected")')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dist_hip_worker.py'), str(hidden), str(maml)]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600, env=env)
+    assert proc.returncode == 0 and 'DIST_HIP_OK' in proc.stdout, proc.stdout[-4000:]
+
+
+def test_train_steps_beside_a_cu_hogging_workload_keep_their_numbers():
+    import torch
+    cfg = small_config(hidden_size=512, embedding_size=64, input_size=2000, max_len=32)
+    eps = O.synthetic_episodes(12, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=51)
+    quiet = new_model(cfg)
+    want = [quiet.train_step(s, q) for s, q in eps]
+    busy = new_model(cfg)
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device='cuda')
+    b = torch.randn(8192, 8192, device='cuda')
+    torch.cuda.synchronize()
+    got = []
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            c = a @ b                                    # ~7 ms each on every CU: the train steps below run beside them
+    for s, q in eps:
+        got.append(busy.train_step(s, q))
+        with torch.cuda.stream(side):
+            c = a @ b
+    torch.cuda.synchronize()
+    stats = busy.stats()
+    assert busy.step == len(eps) and stats['steps_skipped_token_range'] == 0
+    if stats['timeouts'] == 0:
+        assert got == want                               # same kernels, same order: same bits
+    else:                                                # a recovered time-out repeats the step on per-step launches
+        for g, w in zip(got, want):
+            assert abs(g - w) <= 1e-5 * abs(w)
+    del c
