@@ -1,8 +1,8 @@
 """-m gpu: the episode-parallel path on the HIP engine.
 
-  * with >= 2 GPUs visible: 2 ranks over RCCL, one episode each, equal one rank on the concatenated batch (and, for the
-    MAML-style step, the oracle's mean of per-rank query gradients); replicas stay bit-identical.  Skipped on a 1-GPU box
-    (the driver's 8-GPU node runs it);
+  * 2 ranks, one episode each, equal one rank on the concatenated batch (and, for the MAML-style step, the oracle's mean of
+    per-rank query gradients); replicas stay bit-identical.  Over RCCL when >= 2 GPUs are visible; on a 1-GPU box both
+    ranks share the GPU and exchange over gloo;
   * on 1 GPU: the train step beside ANOTHER workload that holds CUs (large matmuls on a second stream -- what RCCL kernels or
     a neighbour job do to the persistent recurrent kernels' co-residency): same numbers, and a time-out, if one happens, is
     recovered and counted instead of poisoning later steps.
@@ -25,9 +25,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize('hidden,maml', [(48, 0), (512, 0), (48, 1)])
 def test_two_ranks_on_the_hip_engine_equal_one_rank_on_the_concatenated_batch(hidden, maml):
     import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip('needs 2 GPUs (the 1-GPU box cannot place two ranks: "Duplicate GPU detected")')
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if torch.cuda.device_count() < 2:
+        # RCCL cannot place two ranks on one device ("Duplicate GPU detected"): both ranks share GPU 0 and exchange over gloo --
+        # the same host code (sharding, bucketed exchange on the communication stream, lock-step recovery when the two
+        # processes' persistent kernels get in each other's way); the RCCL leg runs wherever 2 GPUs are visible
+        env['FSMG_TEST_SAME_GPU'] = '1'
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dist_hip_worker.py'), str(hidden), str(maml)]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600, env=env)
