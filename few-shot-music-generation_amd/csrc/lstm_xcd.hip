@@ -363,6 +363,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd(const LstmBwdXcdArgs a)
         }
         __syncthreads();
         XCD_STAMP(2)
+        // the resets of phase A (and the dz stores of phase B) must have landed before this block publishes anything: wait for
+        // them HERE, before the prefetch below puts ~3200-cycle loads into the queue that a drain behind the MFMAs would also wait for
+        drain_vmem();
         if (act && t > a.t0) {             // prefetch for iteration t-1 (hidden by the MFMAs below)
             const float* gn = a.Z + ((size_t)(t - 1) * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
             n_si = gn[0]; n_tj = gn[4]; n_sf = gn[8]; n_so = gn[12];
@@ -395,7 +398,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd(const LstmBwdXcdArgs a)
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
             XCD_STAMP(3)
-            drain_vmem();                                             // the resets of phase A have landed
             f32x4* out = inbox + (size_t)(t & 1) * slot_w;
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) {
