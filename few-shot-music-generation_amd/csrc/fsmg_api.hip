@@ -1,6 +1,7 @@
 // C-ABI of libfsmg (include/fsmg.h): model handle, HBM layout, step orchestration.
 // Host-side C++ only; every kernel lives in gemm.hip / lstm_step.hip / elementwise.hip.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -157,6 +158,28 @@ int fail(fsmg_model* h, int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                                  \
             return fail(h, FSMG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));  \
     } while (0)
+
+// roctx ranges for rocprofv3 --marker-trace timelines (FSMG_ROCTX=1): libroctx64 is looked up at run time, so the library has no
+// link-time dependency on it and the ranges cost nothing when off
+struct Roctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = std::getenv("FSMG_ROCTX");
+        if (!e || e[0] == '0') return;
+        void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+        pop = (int (*)())dlsym(lib, "roctxRangePop");
+        if (!push || !pop) push = nullptr;
+    }
+};
+inline Roctx& roctx() { static Roctx r; return r; }
+struct ScopedRange {
+    bool on;
+    explicit ScopedRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~ScopedRange() { if (on) roctx().pop(); }
+};
 
 struct ScopedTimer {
     fsmg_model* h; TimerClass* tc = nullptr; hipEvent_t a = nullptr, b = nullptr;
@@ -631,6 +654,7 @@ int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t 
 }
 
 int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_out, bool want_dlogits) {
+    ScopedRange rng_(want_dlogits ? "fsmg.forward(train)" : "fsmg.forward(eval)");
     const int T = h->T, Hp = h->Hp, G4 = h->G4;
     const int64_t rows = (int64_t)T * B;
     const Lane mainl = main_lane(h);
@@ -741,6 +765,7 @@ int dw_gemm(fsmg_model* h, const Lane& ln, int B) {
 }
 
 int backward(fsmg_model* h, int B) {
+    ScopedRange rng_("fsmg.backward");
     const int T = h->T, Hp = h->Hp, G4 = h->G4;
     const int64_t rows = (int64_t)T * B;
     const Lane mainl = main_lane(h);
@@ -868,6 +893,7 @@ int backward(fsmg_model* h, int B) {
 }
 
 int apply_update(fsmg_model* h, float grad_scale) {
+    ScopedRange rng_("fsmg.clip+adam");
     hipStream_t s = h->stream;
     ScopedTimer tm(h, "update");
     const bool slices = h->cfg.clip_norm_mode == FSMG_CLIP_TF1_SLICES;

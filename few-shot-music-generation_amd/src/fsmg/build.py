@@ -4,7 +4,8 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(PKG_DIR, 'csrc')
-LIB = os.path.join(PKG_DIR, 'lib', 'libfsmg.so')
+# FSMG_LIB: load another build of the same ABI (the host-sanitizer builds of `make san`, tools/sanitize_run.sh)
+LIB = os.environ.get('FSMG_LIB') or os.path.join(PKG_DIR, 'lib', 'libfsmg.so')
 
 
 def build(verbose=False, jobs=None):
@@ -14,7 +15,7 @@ def build(verbose=False, jobs=None):
                           stderr=subprocess.STDOUT, universal_newlines=True)
     if verbose or proc.returncode != 0:
         print(proc.stdout)
-    if proc.returncode != 0 or not os.path.isfile(LIB):
+    if proc.returncode != 0 or not os.path.isfile(os.path.join(PKG_DIR, 'lib', 'libfsmg.so')):
         raise RuntimeError('building libfsmg.so failed (hipcc --offload-arch=gfx950):\n' + proc.stdout[-4000:])
     return LIB
 
