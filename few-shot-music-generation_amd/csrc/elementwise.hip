@@ -36,6 +36,18 @@ __global__ __launch_bounds__(256) void k_fill32(uint32_t* __restrict__ p, uint32
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = word;
 }
 
+// several fills in one launch (blockIdx.y = range): a step needs ~10 small fills, each a ~5 us dispatch on its own
+__global__ __launch_bounds__(256) void k_fill_multi(const FillRanges r) {
+    const int k = blockIdx.y;
+    uint32_t* p = r.p[k];
+    const uint32_t word = r.word[k];
+    const long long n = r.n[k], n4 = n >> 2;
+    const uint4 w4 = make_uint4(word, word, word, word);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        reinterpret_cast<uint4*>(p)[i] = w4;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = word;
+}
+
 // ---------------------------------------------------------------- token prep (K0)
 // Reference: convert_tokens_to_input_and_target + concat (src/models/base_model.py:63-86,
 // src/models/lstm_baseline.py:91-96).  One thread per (sequence b, step t): coalesced reads
@@ -526,6 +538,16 @@ hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX
     if (n <= 0) return hipSuccess;
     if (Ep > 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_embed_grad, dim3(n), dim3(256), 0, s, X, n, dX, Ep, dEmb);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_multi(hipStream_t s, const FillRanges& r) {
+    if (r.count <= 0) return hipSuccess;
+    long long most = 0;
+    for (int k = 0; k < r.count; ++k) most = std::max(most, r.n[k]);
+    long long bx = (most / 4 + 255) / 256;
+    bx = std::max<long long>(1, std::min<long long>(bx, 512));
+    hipLaunchKernelGGL(k_fill_multi, dim3((int)bx, r.count), dim3(256), 0, s, r);
     return hipGetLastError();
 }
 

@@ -603,6 +603,25 @@ static void phase_report(fsmg_model* h) {
 #define PHASE(i) ((void)0)
 #endif
 
+// collects the fills a phase needs and issues them as one launch (flush) right before the first kernel that depends on them
+struct FillBatch {
+    FillRanges r{};
+    fsmg_model* h;
+    explicit FillBatch(fsmg_model* h_) : h(h_) { r.count = 0; }
+    int add(void* p, uint32_t word, long long n_words) {
+        if (n_words <= 0) return FSMG_OK;
+        if (r.count == FILL_MAX_RANGES) { const int rc = flush(); if (rc != FSMG_OK) return rc; }
+        r.p[r.count] = (uint32_t*)p; r.word[r.count] = word; r.n[r.count] = n_words; ++r.count;
+        return FSMG_OK;
+    }
+    int flush() {
+        if (r.count == 0) return FSMG_OK;
+        HIPCK(h, launch_fill_multi(h->stream, r));
+        r.count = 0;
+        return FSMG_OK;
+    }
+};
+
 // the XCD-local kernels take this row count at this hidden size (and their buffers exist)
 inline bool use_xcd(const fsmg_model* h, int B) {
     return h->persist && h->xcd && h->khx != nullptr && h->HX != nullptr && B <= h->xcd_max_rows && lstm_xcd_supported(B, h->Hp) &&
@@ -669,9 +688,10 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     for (int l = 0; l < h->L; ++l) {
         const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
         const bool top = l == h->L - 1;
-        HIPCK(h, launch_fill32(s, h->Hs[l], 0u, (long long)((sizeof(float) * (size_t)B * Hp) / 4)));
-        HIPCK(h, launch_fill32(s, h->HF[l], 0u, (long long)((sizeof(float) * Bp16 * Hp) / 4)));
-        HIPCK(h, launch_fill32(s, h->Cs[l], 0u, (long long)((sizeof(float) * (size_t)B * Hp) / 4)));
+        FillBatch fills(h);                 // zero states + hand-off patterns of this layer: ONE launch, issued ahead of the chain
+        GEMMCK(fills.add(h->Hs[l], 0u, (long long)B * Hp));
+        GEMMCK(fills.add(h->Cs[l], 0u, (long long)B * Hp));
+        if (!xcd) GEMMCK(fills.add(h->HF[l], 0u, (long long)Bp16 * Hp));
         {
             ScopedTimer tm(h, "gemm_zx");
             GemmArgs g{};
@@ -684,14 +704,15 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
         }
         PHASE(1);
         if (chain)       // "not written yet" fill pattern of the h fragments of time indices 1..T (index 0 is the zero state)
-            HIPCK(h, launch_fill32(s, h->HF[l] + Bp16 * Hp, 0xFFFFFFFFu, (long long)((sizeof(float) * (size_t)T * Bp16 * Hp) / 4)));
+            GEMMCK(fills.add(h->HF[l] + Bp16 * Hp, 0xFFFFFFFFu, (long long)T * Bp16 * Hp));
         if (xcd) {       // the same for the XCD-local hand-off buffer, and fresh ticket counters for this layer's launches
-            HIPCK(h, launch_fill32(s, h->tickets, 0u, (long long)((sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES) / 4)));
+            GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
             h->ticket_next = 0;
-            const size_t step_f = (size_t)lstm_xcd_hx_floats(B, 0);
-            HIPCK(h, launch_fill32(s, h->HX, 0u, (long long)((sizeof(float) * step_f) / 4)));
-            HIPCK(h, launch_fill32(s, h->HX + step_f, 0xFFFFFFFFu, (long long)((sizeof(float) * step_f * T) / 4)));
+            const long long step_f = lstm_xcd_hx_floats(B, 0);
+            GEMMCK(fills.add(h->HX, 0u, step_f));
+            GEMMCK(fills.add(h->HX + step_f, 0xFFFFFFFFu, step_f * T));
         }
+        GEMMCK(fills.flush());
         for (int c = 0; c < nch; ++c) {
             const int t0 = chunk_begin(h, c, nch), t1 = chunk_begin(h, c + 1, nch);
             if (xcd) {
@@ -778,7 +799,9 @@ int backward(fsmg_model* h, int B) {
     const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
     const Lane auxl = aux_lane(h, false, chain);
     PHASE(3);
-    HIPCK(h, launch_fill32(s, h->G + h->off_emb, 0u, (long long)((sizeof(float) * (size_t)h->V1 * h->Ep) / 4)));
+    FillBatch fills(h);                     // embedding-gradient zero + the top layer's BPTT buffers: one launch
+    GEMMCK(fills.add(h->G + h->off_emb, 0u, (long long)h->V1 * h->Ep));
+    if (ov) GEMMCK(fills.flush());          // (two-stream order: the auxiliary stream forks right below)
     if (ov) {
         // aux: dH chunks in the order BPTT consumes them (last chunk first), then dW
         HIPCK(h, hipEventRecord(h->ev_fork, s));
@@ -797,19 +820,20 @@ int backward(fsmg_model* h, int B) {
     }
     for (int l = h->L - 1; l >= 0; --l) {
         const bool top = l == h->L - 1;
-        HIPCK(h, launch_fill32(s, h->dC, 0u, (long long)((sizeof(float) * (size_t)B * Hp) / 4)));
+        GEMMCK(fills.add(h->dC, 0u, (long long)B * Hp));
         if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[nch - 1], 0));
         PHASE(4);
         if (xcd) {
-            HIPCK(h, launch_fill32(s, h->inboxX, 0xFFFFFFFFu, (long long)((sizeof(float) * (size_t)lstm_xcd_inbox_floats(B)) / 4)));
-            HIPCK(h, launch_fill32(s, h->tickets, 0u, (long long)((sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES) / 4)));
+            GEMMCK(fills.add(h->inboxX, 0xFFFFFFFFu, lstm_xcd_inbox_floats(B)));
+            GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
             h->ticket_next = 0;
         } else if (rs) {        // "not written yet" fill pattern of the dh partial inboxes
-            HIPCK(h, launch_fill32(s, h->inbox, 0xFFFFFFFFu, (long long)((sizeof(float) * (size_t)lstm_bwd_rs_inbox_floats(B, Hp)) / 4)));
+            GEMMCK(fills.add(h->inbox, 0xFFFFFFFFu, lstm_bwd_rs_inbox_floats(B, Hp)));
         } else if (chain) {     // ... or of the dz fragments of every time step
-            const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
-            HIPCK(h, launch_fill32(s, h->dzF_all, 0xFFFFFFFFu, (long long)((sizeof(float) * (size_t)T * Bp16 * G4) / 4)));
+            const long long Bp16 = (B + 15) / 16 * 16;
+            GEMMCK(fills.add(h->dzF_all, 0xFFFFFFFFu, (long long)T * Bp16 * G4));
         }
+        GEMMCK(fills.flush());
         for (int c = nch - 1; c >= 0; --c) {
             const int t0 = chunk_begin(h, c, nch), t1 = chunk_begin(h, c + 1, nch);
             if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[c], 0));

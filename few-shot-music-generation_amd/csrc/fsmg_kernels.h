@@ -170,6 +170,10 @@ hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a);
 hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);
 
 // ---------------------------------------------------------------- everything else (elementwise.hip)
+// up to FILL_MAX_RANGES 32-bit pattern fills in ONE launch (each p 16-byte aligned)
+constexpr int FILL_MAX_RANGES = 16;
+struct FillRanges { uint32_t* p[FILL_MAX_RANGES]; uint32_t word[FILL_MAX_RANGES]; long long n[FILL_MAX_RANGES]; int count; };
+hipError_t launch_fill_multi(hipStream_t s, const FillRanges& r);
 // out[r][0..T) = table[idx[r]][0..T) for r < n_rows (device-resident split table -> the token staging buffer)
 hipError_t launch_gather_rows(hipStream_t s, const int* table, const int* idx, int n_rows, int T, int n_songs, int* out, int* err_flag);
 // p[0 .. n_words) = word (p 16-byte aligned); the step uses this instead of hipMemsetAsync so that its hipGraph holds kernel nodes only
