@@ -127,7 +127,7 @@ class HIPModel(BaseModel):
             return set()
         found = self._checkpoints(os.path.join(checkpt_path, self.name))
         if not found:
-            return set()
+            return self._recover_tf(checkpt_path)
         path = found[-1][1]
         print('recovering %s from %s' % (self.name, path))
         restored = set()
@@ -143,6 +143,27 @@ class HIPModel(BaseModel):
                         self._model.set_opt_state(name, blob[km], blob[kv])
             if 'global_step' in blob:
                 self._model.step = int(blob['global_step'])
+        return restored
+
+    def _recover_tf(self, checkpt_path):
+        """A checkpoint the REFERENCE wrote (tf.train.Saver's tensor bundle, tf_model.py:96-97,106-125): weights, Adam slots and
+        global_step are taken over -- every tensor whose name and shape match (optimistic_restore, tf_model.py:28-75)."""
+        from models import tf_checkpoint as TC
+        prefix = TC.latest_checkpoint(os.path.join(checkpt_path, self.name))
+        if prefix is None:
+            return set()
+        print('recovering %s from %s (TensorFlow checkpoint)' % (self.name, prefix))
+        params, adam_m, adam_v, step = TC.map_variables(TC.read_bundle(prefix), int(self._config['n_layers']))
+        restored = set()
+        for name, shape in self._model.param_shapes.items():
+            want = (shape[0],) if shape[1] == 1 else tuple(shape)
+            if name in params and tuple(params[name].shape) == want:
+                self._model.set_param(name, params[name].astype(np.float32))
+                restored.add(name)
+                if name in adam_m and name in adam_v and tuple(adam_m[name].shape) == want and tuple(adam_v[name].shape) == want:
+                    self._model.set_opt_state(name, adam_m[name].astype(np.float32), adam_v[name].astype(np.float32))
+        if step is not None:
+            self._model.step = step
         return restored
 
     def recover_or_init(self, init_path):
