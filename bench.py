@@ -178,10 +178,15 @@ def main():
     import torch.distributed as dist
     from fsmg.dist import EpisodeParallel, init_from_env
 
-    rank, world = init_from_env('nccl')
+    # FSMG_BENCH_SAME_GPU=1 (diagnostic): all ranks on GPU 0 over gloo -- exercises the N > 1 code path on a 1-GPU box (RCCL
+    # refuses two ranks on one device); the numbers of such a run mean nothing
+    same_gpu = os.environ.get('FSMG_BENCH_SAME_GPU', '0') == '1'
+    rank, world = init_from_env('gloo' if same_gpu else 'nccl')
     if world != args.gpus:
         raise SystemExit('launched with WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = 0 if same_gpu else int(os.environ.get('LOCAL_RANK', 0))
+    if same_gpu:
+        os.environ['LOCAL_RANK'] = '0'
     torch.cuda.set_device(local)
     global N_WAY, K_SHOT, Q_QUERY
     base = CFG_B
