@@ -180,7 +180,8 @@ class FsmgModel(object):
         if name not in self.param_shapes:
             raise FsmgError(-5, "unknown parameter '%s'" % name)
         rows, cols = self.param_shapes[name]
-        return (rows,) if cols == 1 else (rows, cols)
+        vector = name.startswith('bias_') or name == 'softmax_b'        # cols == 1 alone cannot tell a vector from an [n, 1] matrix (E = 1)
+        return (rows,) if vector else (rows, cols)
 
     def init_params(self, seed):
         self._ck(self._lib.fsmg_init_params(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))

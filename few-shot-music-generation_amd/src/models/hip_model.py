@@ -133,7 +133,7 @@ class HIPModel(BaseModel):
         restored = set()
         with np.load(path) as blob:
             for name, shape in self._model.param_shapes.items():
-                want = (shape[0],) if shape[1] == 1 else tuple(shape)
+                want = self._model._shape(name)
                 key = 'param/' + name
                 if key in blob and blob[key].shape == want:
                     self._model.set_param(name, blob[key])
@@ -156,7 +156,7 @@ class HIPModel(BaseModel):
         params, adam_m, adam_v, step = TC.map_variables(TC.read_bundle(prefix), int(self._config['n_layers']))
         restored = set()
         for name, shape in self._model.param_shapes.items():
-            want = (shape[0],) if shape[1] == 1 else tuple(shape)
+            want = self._model._shape(name)
             if name in params and tuple(params[name].shape) == want:
                 self._model.set_param(name, params[name].astype(np.float32))
                 restored.add(name)

@@ -68,6 +68,37 @@ def test_forward_backward_every_tensor(over, N, K, Q):
     assert abs(tail[0] - aux['embedding_slices_sq']) <= 1e-4 * aux['embedding_slices_sq']
 
 
+@pytest.mark.parametrize('over,N,K,Q', [
+    (dict(max_len=1), 2, 1, 1),                                         # a single time step: no recurrence at all
+    (dict(max_len=2, input_size=1), 1, 1, 1),                           # a one-word vocabulary (V1 = 2 with the start word)
+    (dict(embedding_size=1, hidden_size=1, input_size=5), 1, 1, 1),     # one unit, one embedding column
+    (dict(hidden_size=512, embedding_size=8, input_size=30, max_len=3), 1, 0, 1),   # empty support set, one query song, XCD-local kernels with 1 row
+    (dict(hidden_size=512, embedding_size=8, input_size=30, max_len=3), 16, 4, 4),  # 128 rows: the most the XCD-local kernels take
+    (dict(hidden_size=512, embedding_size=8, input_size=30, max_len=3), 43, 2, 1),  # 129 rows: one more -> column-split / per-step kernels
+])
+def test_degenerate_and_boundary_shapes(over, N, K, Q):
+    """Edge cases of the episode shape and the model dims (the reference feeds whatever the sampler yields: None batch dims,
+    lstm_baseline.py:31-36): every gradient and one update against the oracle."""
+    cfg = small_config(**over)
+    rng = np.random.RandomState(5)
+    sup = rng.randint(0, cfg['input_size'], size=(N, K, cfg['max_len'])).astype(np.int32)
+    qry = rng.randint(0, cfg['input_size'], size=(N, Q, cfg['max_len'])).astype(np.int32)
+    model = new_model(cfg)
+    params = f64_params(model)
+    loss, cache, grads, aux = oracle_step(params, sup, qry, cfg)
+    model.forward_backward(sup, qry)
+    assert abs(model.debug_read('tail', 16)[1] - loss) <= NLL_RTOL * abs(loss)
+    for name in grads:
+        assert rel_max(model.get_grad(name), grads[name]) < 2e-4, name
+    opt = O.new_opt_state(params)
+    O.apply_update(params, grads, aux, opt, cfg)
+    assert abs(model.apply_update(1.0) - loss) <= NLL_RTOL * abs(loss)
+    for name, ref in params.items():
+        assert rel_max(model.get_param(name), ref) < 5e-4, name
+    assert abs(model.eval_step(qry) - O.eval_step(params, qry, cfg)) <= NLL_RTOL * abs(loss)
+    assert model.stats()['timeouts'] == 0
+
+
 def test_forward_gates_before_backward():
     cfg = small_config()
     sup, qry = _episode(cfg, 2, 2, 1)

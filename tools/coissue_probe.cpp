@@ -36,6 +36,39 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* cyc,
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+template <int ACTIVE>
+__global__ __launch_bounds__(256, 1) void k_half(float* out, unsigned long long* cyc, int iters) {
+    float q0 = threadIdx.x * 1e-3f, q1 = 0.5f, q2 = 0.25f, q3 = 0.125f;
+    const float w = 1.0f + threadIdx.x * 1e-4f;
+    unsigned long long t0 = 0, t1 = 0;
+    if ((threadIdx.x & 63) < ACTIVE) {
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(q0) : "v"(w), "v"(q1));
+                asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(q1) : "v"(w), "v"(q2));
+                asm volatile("v_exp_f32 %0, %0" : "+v"(q2));
+                asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(q3) : "v"(w), "v"(q0));
+            }
+        }
+        t1 = __builtin_amdgcn_s_memtime();
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = q0 + q1 + q2 + q3;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int ACTIVE>
+int run_half(float* out, unsigned long long* cyc) {
+    const int iters = 50;
+    hipLaunchKernelGGL((k_half<ACTIVE>), dim3(256), dim3(256), 0, 0, out, cyc, iters);
+    hipLaunchKernelGGL((k_half<ACTIVE>), dim3(256), dim3(256), 0, 0, out, cyc, iters);
+    CK(hipDeviceSynchronize());
+    unsigned long long h[256]; CK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
+    double m = 0; for (auto v : h) m += (double)v; m /= 256;
+    printf("192 v_fma + 64 v_exp (dependent mix), %2d of 64 lanes active: %7.1f ticks per 256 instructions\n", ACTIVE, m / iters);
+    return 0;
+}
+
 template <int MODE>
 int run(const char* name, float* out, unsigned long long* cyc) {
     const int iters = 50;
@@ -56,5 +89,7 @@ int main() {
     run<2>("256 v_fma_f32 (SGPR operand) alone", out, cyc);
     run<3>("128 MFMA + 128 v_pk_fma_f32 interleaved 1:1", out, cyc);
     run<4>("128 MFMA + 256 v_fma_f32 interleaved 1:2", out, cyc);
+    run_half<64>(out, cyc); run_half<32>(out, cyc); run_half<16>(out, cyc);
     return 0;
 }
+// ---- does a wave64 VALU instruction with only 32 (or 16) active lanes issue faster?  (k_half below)
