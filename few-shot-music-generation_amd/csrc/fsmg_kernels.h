@@ -146,7 +146,6 @@ struct LstmFwdXcdArgs {
     int B, T, t0, t1;
     int spin_limit;
     unsigned long long* prof;   // != nullptr: instrumented build, [256 blocks][4 waves][8] tick sums per phase (RG = 2 only)
-    int flags;                  // experiment switches (tools/xcd_chain_bench.cpp); 0 in production
 };
 struct LstmBwdXcdArgs {
     const float* KhXb;    // backward register image of K_h

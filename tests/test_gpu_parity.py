@@ -276,8 +276,8 @@ def test_all_schedules_are_bit_identical(monkeypatch):
 
 
 def test_persistent_forward_chain_is_bit_identical(monkeypatch):
-    """FSMG_PERSISTENT=1 (one launch per chain chunk, h handed between blocks inside the launch; measured slower
-    than one launch per step and off by default) computes exactly the same step, in both schedules."""
+    """The column-split persistent kernels (one launch per chain chunk, h handed between blocks inside the launch; the default
+    where they apply) compute exactly the bits of one launch per time step (FSMG_PERSISTENT=0), in both schedules."""
     cfg = small_config(hidden_size=128, embedding_size=32, input_size=150, max_len=24, n_layers=2)
     eps = O.synthetic_episodes(3, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=12)      # 45 rows: 3 row tiles
     out = []
