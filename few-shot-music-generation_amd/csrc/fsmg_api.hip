@@ -131,6 +131,18 @@ struct fsmg_model {
     bool overlap = true;                // FSMG_OVERLAP=0 disables the two-stream schedule
     bool overlap_forced = false;        // FSMG_OVERLAP was set: no per-call decision
     bool ov_call = false;               // the decision for the call in progress (choose_schedule)
+    // XCD-partitioned schedule (FSMG_XCD_OVERLAP=1; off by default: measured 385 against 388 episodes/s at cfg-B, DESIGN.md
+    // section 4): the recurrence packs its rows on the first XCDs and work-queue GEMMs on the auxiliary stream take the XCDs
+    // it leaves free
+    bool xov = false, xov_call = false;
+    bool bucket0_recorded = false;      // backward() recorded ev_bucket[0] itself (two-stream / XCD-partitioned order)
+    int xov_dw_split = 6;               // K split of dW under this schedule: short tiles, so little is in flight when the chain ends
+    int xov_dw_share = 15;              // percent of dW's tiles offered to the restricted launch
+    int xov_blocks = 2;                 // resident blocks per CU of the restricted launches
+    int xov_head = 18;                  // forward: time steps whose projection runs beside the rest of the recurrence
+    // forward projection / dW: [0..1] draw counters, [2] stop flag, [3] items, [4 ..] claim words (gemm_restricted)
+    static constexpr int XOV_CTL = 8192;
+    int* xov_ctl = nullptr;             // [2][XOV_CTL]
     int64_t slab_cap = 0;
     // whole-phase hipGraphs, keyed by the shape of the call; dropped when scratch moves
     std::map<std::string, hipGraphExec_t> graphs;
@@ -436,6 +448,7 @@ int ensure_scratch(fsmg_model* h, int B) {
             if (S2 > 1) slab_need = std::max(slab_need, (int64_t)S2 * m * h->V1p);
         }
     }
+    if (h->xov) slab_need = std::max(slab_need, (int64_t)std::min(h->xov_dw_split, MAX_SPLIT) * Hp * h->V1p);   // dW in short tiles
     const int64_t o_slab = place(4 * std::max<int64_t>(slab_need, 64));
     const int64_t o_cslab = place(4 * (int64_t)MAX_SPLIT * std::max<int64_t>(h->V1p, G4));
     const int64_t o_slab2 = place(4 * std::max<int64_t>(slab_need, 64));
@@ -517,7 +530,7 @@ template <class F>
 int run_graphed(fsmg_model* h, const std::string& key, F&& body) {
     // hipGraph (ROCm 7.2) runs captured cross-stream branches one after the other, so the two-stream
     // schedule only overlaps with eager launches
-    if (!h->cfg.use_graph || h->timing || h->ov_call) return body();
+    if (!h->cfg.use_graph || h->timing || h->ov_call || h->xov_call) return body();
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -631,7 +644,16 @@ inline bool use_xcd(const fsmg_model* h, int B) {
 // put a high-priority wave on every SIMD of the chip and spend half of their time in hand-offs; GEMM waves beside them
 // stretch both (measured at cfg-B: 374-379 episodes/s two-stream with 1-4 chunks against 383-385 single-stream), so a pass
 // that takes them runs single-stream; the per-step kernels of big validation batches keep the overlap.
-inline void choose_schedule(fsmg_model* h, int B) { h->ov_call = h->overlap && (h->overlap_forced || !use_xcd(h, B)); }
+inline void choose_schedule(fsmg_model* h, int B, bool train = false) {
+    h->ov_call = h->overlap && (h->overlap_forced || !use_xcd(h, B));
+    h->xov_call = false;
+    if (train && h->xov && !h->ov_call && !h->timing && h->aux != nullptr && use_xcd(h, B) && h->persist_fwd && h->persist_bwd) {
+        const int rpx = lstm_xcd_packed_rows(B);
+        h->xov_call = (B + rpx - 1) / rpx < 8;          // packing frees at least one XCD
+    }
+}
+// first XCD the packed recurrence leaves free
+inline int xov_first_free(int B) { const int rpx = lstm_xcd_packed_rows(B); return (B + rpx - 1) / rpx; }
 
 // every XCD-local launch of a pass gets its own 8 zeroed ticket counters
 inline int* next_tickets(fsmg_model* h) {
@@ -640,7 +662,24 @@ inline int* next_tickets(fsmg_model* h) {
     return t;
 }
 
-int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t rows_total, bool want_dlogits) {
+// Work-queue GEMM in two launches (GemmArgs::xcd_first): the restricted one lets the XCDs >= first draw items below
+// `limit` until *stop is raised; the clean-up one, ordered by the caller after the inputs of the remaining items, drains the
+// queue chip-wide.  work / stop are zeroed on the main stream before the fork.
+inline int gemm_items(const GemmArgs& g) { return ((g.M + gemm_tile_m() - 1) / gemm_tile_m()) * ((g.N + 127) / 128) * std::max(1, g.ksplit); }
+inline bool xov_fits(const GemmArgs& g) { return 4 + gemm_items(g) <= fsmg_model::XOV_CTL; }
+int gemm_restricted(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int first, int* ctl, int limit) {
+    g.xcd_first = first; g.work = ctl; g.stop = ctl + 2; g.claim = ctl + 4; g.work_limit = limit;
+    HIPCK(h, launch_gemm(s, amode, bmode, g, gemm_lds_pad_for(h->xov_blocks)));
+    return FSMG_OK;
+}
+int gemm_cleanup(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int* ctl) {
+    g.xcd_first = -1; g.work = ctl; g.claim = ctl + 4;
+    HIPCK(h, launch_gemm(s, amode, bmode, g, 0));
+    return FSMG_OK;
+}
+
+// logits of the rows of time steps [t0, t1) = top-layer outputs * W + d
+GemmArgs logits_args(fsmg_model* h, int B, int t0, int t1) {
     const int Hp = h->Hp;
     const int64_t r0 = (int64_t)t0 * B, m = (int64_t)(t1 - t0) * B;
     GemmArgs g{};
@@ -648,6 +687,19 @@ int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t 
     g.B = h->P + h->off_w; g.ldb = h->V1p;
     g.C = h->logits + (size_t)r0 * h->V1p; g.ldc = h->V1p; g.M = (int)m; g.N = h->V1p; g.K = Hp;
     g.bias = h->P + h->off_d; g.ksplit = 1; g.nt_store = 1;
+    return g;
+}
+int ce_rows(fsmg_model* h, hipStream_t s, int B, int t0, int t1, int64_t rows_total) {
+    ScopedTimer tm(h, "ce");
+    const int64_t r0 = (int64_t)t0 * B, m = (int64_t)(t1 - t0) * B;
+    HIPCK(h, launch_ce_rows(s, h->logits + (size_t)r0 * h->V1p, h->V1p, (int)m, h->V1, h->Y + r0, h->lse + r0,
+                            h->ce + r0, h->dlogits + (size_t)r0 * h->V1p, (float)(1.0 / ((double)rows_total + 1e-12))));
+    return FSMG_OK;
+}
+
+int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t rows_total, bool want_dlogits) {
+    const int64_t r0 = (int64_t)t0 * B, m = (int64_t)(t1 - t0) * B;
+    GemmArgs g = logits_args(h, B, t0, t1);
     if (!want_dlogits) {
         // validation: no backward pass will read the logits, so they are never written; the GEMM epilogue emits
         // per-row softmax partials and a small kernel finishes the cross entropy
@@ -663,13 +715,7 @@ int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t 
         ScopedTimer tm(h, "gemm_logits");
         GEMMCK(gemm(h, ln, OP_KC, OP_XC, g));
     }
-    {
-        ScopedTimer tm(h, "ce");
-        HIPCK(h, launch_ce_rows(ln.s, h->logits + (size_t)r0 * h->V1p, h->V1p, (int)m, h->V1, h->Y + r0, h->lse + r0,
-                                h->ce + r0, h->dlogits + (size_t)r0 * h->V1p,
-                                (float)(1.0 / ((double)rows_total + 1e-12))));
-    }
-    return FSMG_OK;
+    return ce_rows(h, ln.s, B, t0, t1, rows_total);
 }
 
 int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_out, bool want_dlogits) {
@@ -683,7 +729,12 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     const bool chain1 = !xcd && h->persist && h->persist_fwd && !h->force_fwd_rt && lstm_fwd_chain_supported(B, Hp);
     const bool chain_rt = !xcd && h->persist && h->persist_fwd && !chain1 && lstm_fwd_chain_rt_supported(B, Hp);   // all row tiles per block
     const bool chain = chain1 || chain_rt;
-    const int nch = ov ? ((chain || xcd) ? h->nchunk_persist : h->nchunk) : 1;
+    const int nch_ov = ov ? ((chain || xcd) ? h->nchunk_persist : h->nchunk) : 1;
+    // XCD-partitioned schedule: the projection of the first `head` steps runs on the free XCDs beside the rest of the chain
+    const GemmArgs ghead = logits_args(h, B, 0, T);
+    const bool xov = h->xov_call && xcd && want_dlogits && !ov && xov_fits(ghead);
+    const int head = std::min(h->xov_head, T - 1), xfree = xov_first_free(B);
+    const int rpx = xov ? lstm_xcd_packed_rows(B) : 0;
     PHASE(0);
     for (int l = 0; l < h->L; ++l) {
         const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
@@ -711,13 +762,18 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             const long long step_f = lstm_xcd_hx_floats(B, 0);
             GEMMCK(fills.add(h->HX, 0u, step_f));
             GEMMCK(fills.add(h->HX + step_f, 0xFFFFFFFFu, step_f * T));
+            if (xov && top) GEMMCK(fills.add(h->xov_ctl, 0u, 4 + gemm_items(ghead)));
         }
         GEMMCK(fills.flush());
+        const bool split_head = xov && top && head >= 1;
+        const int nch = split_head ? 2 : nch_ov;
         for (int c = 0; c < nch; ++c) {
-            const int t0 = chunk_begin(h, c, nch), t1 = chunk_begin(h, c + 1, nch);
+            const int t0 = split_head ? (c == 0 ? 0 : head) : chunk_begin(h, c, nch);
+            const int t1 = split_head ? (c == 0 ? head : T) : chunk_begin(h, c + 1, nch);
             if (xcd) {
                 ScopedTimer tm(h, "lstm_fwd");
                 LstmFwdXcdArgs a{};
+                a.rpx = rpx;
                 a.KhX = h->khx + (size_t)(2 * l) * Hp * G4; a.HX = h->HX; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
                 a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_fwd_xcd(s, a));
@@ -750,12 +806,28 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
                 HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_chunk[c], 0));
                 GEMMCK(logits_and_ce(h, aux_lane(h, !want_dlogits, chain || xcd), B, t0, t1, rows, want_dlogits));
             }
+            if (split_head && c == 0) {
+                HIPCK(h, hipEventRecord(h->ev_chunk[0], s));
+                HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_chunk[0], 0));
+                // whole row tiles inside the finished steps, all column tiles
+                const int limit = (int)((int64_t)head * B / gemm_tile_m()) * ((h->V1p + 127) / 128);
+                GEMMCK(gemm_restricted(h, h->aux, OP_KC, OP_XC, ghead, xfree, h->xov_ctl, limit));
+                HIPCK(h, hipEventRecord(h->ev_join, h->aux));
+            }
         }
     }
     PHASE(2);
     if (ov) {
         HIPCK(h, hipEventRecord(h->ev_join, h->aux));
         HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));
+    } else if (xov && head >= 1) {
+        HIPCK(h, launch_fill32(s, h->xov_ctl + 2, 1u, 1));     // chain done: the free XCDs stop drawing tiles
+        {
+            ScopedTimer tm(h, "gemm_logits");
+            GEMMCK(gemm_cleanup(h, s, OP_KC, OP_XC, ghead, h->xov_ctl));
+            HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));    // tiles that were in flight on the free XCDs
+        }
+        GEMMCK(ce_rows(h, s, B, 0, T, rows));
     } else {
         GEMMCK(logits_and_ce(h, mainl, B, 0, T, rows, want_dlogits));
     }
@@ -776,13 +848,16 @@ int dhout_chunk(fsmg_model* h, const Lane& ln, int B, int t0, int t1) {
     return gemm(h, ln, OP_KC, OP_KC, g);
 }
 
-int dw_gemm(fsmg_model* h, const Lane& ln, int B) {
-    ScopedTimer tm(h, "gemm_dw");        // dW = Hout^T * dlogits, dd = colsum(dlogits)
+GemmArgs dw_args(fsmg_model* h, int B) {      // dW = Hout^T * dlogits, dd = colsum(dlogits)
     GemmArgs g{};
     g.A = h->Hs[h->L - 1] + (size_t)B * h->Hp; g.lda = h->Hp; g.B = h->dlogits; g.ldb = h->V1p;
     g.C = h->G + h->off_w; g.ldc = h->V1p; g.M = h->Hp; g.N = h->V1p; g.K = (int)((int64_t)h->T * B);
     g.colsum = h->G + h->off_d; g.ksplit = 1;
-    return gemm(h, ln, OP_XC, OP_XC, g);
+    return g;
+}
+int dw_gemm(fsmg_model* h, const Lane& ln, int B) {
+    ScopedTimer tm(h, "gemm_dw");
+    return gemm(h, ln, OP_XC, OP_XC, dw_args(h, B));
 }
 
 int backward(fsmg_model* h, int B) {
@@ -798,6 +873,17 @@ int backward(fsmg_model* h, int B) {
                               (int64_t)T * ((B + 15) / 16 * 16) * G4 <= h->dzfa_floats);
     const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
     const Lane auxl = aux_lane(h, false, chain);
+    // XCD-partitioned schedule: dW's tiles are claimed by the free XCDs while the top layer's chain runs, the rest after it
+    GemmArgs gdw = dw_args(h, B);
+    int dw_split = pick_split(gdw.M, gdw.N, gdw.K, mainl.slots);
+    if (h->xov_call && xcd && !ov) dw_split = std::max(dw_split, std::min(std::min(h->xov_dw_split, MAX_SPLIT), gdw.K / 256));
+    while (dw_split > 1 && (int64_t)dw_split * gdw.M * gdw.N > h->slab_cap) --dw_split;
+    if (dw_split > 1) {
+        gdw.C = mainl.slabs; gdw.c_slab = (int64_t)gdw.M * gdw.N; gdw.ksplit = dw_split;
+        gdw.colsum = mainl.colsum_slabs; gdw.colsum_slab = gdw.N;
+    }
+    const bool xov = h->xov_call && xcd && !ov && xov_fits(gdw);
+    const int rpx = xov ? lstm_xcd_packed_rows(B) : 0;
     PHASE(3);
     FillBatch fills(h);                     // embedding-gradient zero + the top layer's BPTT buffers: one launch
     GEMMCK(fills.add(h->G + h->off_emb, 0u, (long long)h->V1 * h->Ep));
@@ -814,6 +900,18 @@ int backward(fsmg_model* h, int B) {
         GEMMCK(dw_gemm(h, auxl, B));
         HIPCK(h, hipEventRecord(h->ev_join, h->aux));
         HIPCK(h, hipEventRecord(h->ev_bucket[0], h->aux));
+        h->bucket0_recorded = true;
+    } else if (xov) {
+        GEMMCK(fills.add(h->xov_ctl + fsmg_model::XOV_CTL, 0u, 4 + gemm_items(gdw)));
+        GEMMCK(fills.flush());
+        GEMMCK(dhout_chunk(h, mainl, B, 0, T));
+        HIPCK(h, hipEventRecord(h->ev_fork, s));
+        HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+        // no more blocks than the free XCDs can use while the chain runs: the replicas dealt to the chain's XCDs only
+        // start (and leave) when it is over, in the way of the clean-up launch
+        const int dw_limit = (int)((int64_t)gemm_items(gdw) * h->xov_dw_share / 100);
+        GEMMCK(gemm_restricted(h, h->aux, OP_XC, OP_XC, gdw, xov_first_free(B), h->xov_ctl + fsmg_model::XOV_CTL, dw_limit));
+        HIPCK(h, hipEventRecord(h->ev_join, h->aux));
     } else {
         GEMMCK(dhout_chunk(h, mainl, B, 0, T));
         GEMMCK(dw_gemm(h, mainl, B));
@@ -840,6 +938,7 @@ int backward(fsmg_model* h, int B) {
             ScopedTimer tm(h, "lstm_bwd");
             if (xcd) {
                 LstmBwdXcdArgs a{};
+                a.rpx = rpx;
                 a.KhXb = h->khx + (size_t)(2 * l + 1) * Hp * G4; a.inbox = h->inboxX; a.Z = h->Z[l]; a.Cs = h->Cs[l];
                 a.dc = h->dC; a.dH = h->dH; a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_bwd_xcd(s, a));
@@ -877,6 +976,19 @@ int backward(fsmg_model* h, int B) {
                 HIPCK(h, launch_lstm_bwd_step(s, a));
             }
             h->n_step_launches += t1 - t0;
+        }
+        if (xov && top) {                     // the rest of dW chip-wide, then the fixed-order slab sum
+            ScopedTimer tm(h, "gemm_dw");
+            HIPCK(h, launch_fill32(s, h->xov_ctl + fsmg_model::XOV_CTL + 2, 1u, 1));
+            GEMMCK(gemm_cleanup(h, s, OP_XC, OP_XC, gdw, h->xov_ctl + fsmg_model::XOV_CTL));
+            HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));
+            if (dw_split > 1) {
+                const int64_t mn = (int64_t)gdw.M * gdw.N;
+                HIPCK(h, launch_reduce_slabs(s, mainl.slabs, mn, dw_split, h->G + h->off_w, mn));
+                HIPCK(h, launch_reduce_slabs(s, mainl.colsum_slabs, gdw.N, dw_split, h->G + h->off_d, gdw.N));
+            }
+            HIPCK(h, hipEventRecord(h->ev_bucket[0], s));
+            h->bucket0_recorded = true;
         }
         const int in_p = h->in_dim[l];
         PHASE(5);
@@ -1053,10 +1165,11 @@ int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&
         drop_graphs(h);
     }
     if ((rc = ensure_scratch(h, B)) != FSMG_OK) return rc;
-    choose_schedule(h, B);
+    choose_schedule(h, B, true);
     if ((rc = ensure_khf(h)) != FSMG_OK) return rc;
     if ((rc = stage()) != FSMG_OK) return rc;
     const int n_sup = N * K, n_qry = N * Q;
+    h->bucket0_recorded = false;
     rc = run_graphed(h, "fb:" + std::to_string(n_sup) + ":" + std::to_string(n_qry), [&]() -> int {
         int r = token_prep(h, n_sup, n_qry);
         if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1, true);
@@ -1066,7 +1179,7 @@ int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&
     if (rc != FSMG_OK) return rc;
     // bucket readiness for an overlapped gradient exchange: with the two-stream (eager) schedule bucket 0 was
     // recorded right behind the dW GEMM on the aux stream; a replayed graph finishes as a whole
-    if (!use_overlap(h)) HIPCK(h, hipEventRecord(h->ev_bucket[0], h->stream));
+    if (!h->bucket0_recorded) HIPCK(h, hipEventRecord(h->ev_bucket[0], h->stream));
     HIPCK(h, hipEventRecord(h->ev_bucket[1], h->stream));
     h->lastB = B;
     h->have_grads = true;
@@ -1127,6 +1240,11 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         const char* env = std::getenv("FSMG_OVERLAP");
         h->overlap = env ? (env[0] != '0') : ((int64_t)h->V1 >= 8LL * h->H * h->L);
         h->overlap_forced = env != nullptr;
+        if (const char* e = std::getenv("FSMG_XCD_OVERLAP")) h->xov = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FSMG_XOV_HEAD")) h->xov_head = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("FSMG_XOV_DW_SPLIT")) h->xov_dw_split = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("FSMG_XOV_DW_SHARE")) h->xov_dw_share = std::max(0, std::min(100, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_XOV_BLOCKS")) h->xov_blocks = std::max(1, std::min(4, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
         h->persist_cfg = h->persist;
         if (const char* e = std::getenv("FSMG_FALLBACK_STEPS")) h->fallback_steps = std::max(1, std::atoi(e));
@@ -1171,7 +1289,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     if (hipMemsetAsync(h->state, 0, sb, h->stream) != hipSuccess) return bail(FSMG_ERR_HIP, "memset(state) failed");
 
     char* small = nullptr;
-    const size_t small_bytes = 256 * 4 + sizeof(float) * RING_CAP + sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES;
+    const size_t small_bytes = 256 * 4 + sizeof(float) * RING_CAP + sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES + sizeof(int) * 2 * fsmg_model::XOV_CTL;
     if (hipMalloc((void**)&small, small_bytes) != hipSuccess) return bail(FSMG_ERR_NOMEM, "hipMalloc(scalars) failed");
     hipMemsetAsync(small, 0, small_bytes, h->stream);
     h->d_step = (long long*)small; h->d_err = (int*)(small + 256); h->d_gnorm = (float*)(small + 512);
@@ -1181,6 +1299,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         return bail(FSMG_ERR_NOMEM, "hipHostMalloc(mapped step counters) failed");
     std::memset(h->host_counters, 0, 64);
     h->tickets = (int*)(small + 1024 + sizeof(float) * RING_CAP);
+    h->xov_ctl = h->tickets + 8 * fsmg_model::TICKET_LAUNCHES;
 
     // decode scratch: per layer h ping/pong + c, plus x and argmax block scratch
     {

@@ -28,6 +28,15 @@ struct GemmArgs {
     // the logit of the row's target column into ce_tgt_logit[row]
     float2* ce_part; const int* ce_tgt; float* ce_tgt_logit; int ce_nvocab;
     int nt_store;           // 1: C is written with non-temporal stores (streaming, read back much later)
+    // Work-queue launches for the XCD-partitioned schedule (k_gemm_queue; not with `gather` on an XC operand).  Every block
+    // draws one (split, row tile, column tile) item, row tiles slowest, in the order blocks start.  work[0] / work[1]: draw
+    // counters of the restricted / clean-up launch, claim[items]: taken marks; all zeroed by the caller.
+    //   xcd_first > 0: restricted launch -- only blocks on XCDs >= xcd_first draw, only items < work_limit, and only while
+    //                  *stop == 0 (the caller raises it when the kernel that owned the other XCDs is done);
+    //   xcd_first < 0: clean-up launch -- one block per item, computes the items nobody took.  Order it after everything
+    //                  the remaining items read.
+    // Placement decides speed, never results: an item is computed once, by the same code either way.
+    int xcd_first; int* work; int* claim; int work_limit; const int* stop;
 };
 // amode/bmode in {OP_KC, OP_XC}. Supported combinations: (KC,XC) (XC,XC) (KC,KC)
 hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, int lds_pad = 0);
@@ -146,6 +155,7 @@ struct LstmFwdXcdArgs {
     int B, T, t0, t1;
     int spin_limit;
     unsigned long long* prof;   // != nullptr: instrumented build, [256 blocks][4 waves][8] tick sums per phase (RG = 2 only)
+    int rpx;                    // rows per XCD; 0 = ceil(B / 8).  lstm_xcd_packed_rows(B) packs the batch on the first XCDs
 };
 struct LstmBwdXcdArgs {
     const float* KhXb;    // backward register image of K_h
@@ -159,11 +169,13 @@ struct LstmBwdXcdArgs {
     int B, T, t0, t1;
     int spin_limit;
     unsigned long long* prof;
+    int rpx;              // as LstmFwdXcdArgs
 };
 bool lstm_xcd_supported(int B, int Hp);
 long long lstm_xcd_hx_floats(int B, int T);
 long long lstm_xcd_inbox_floats(int B);
 long long lstm_xcd_weight_floats();           // floats per register image
+int lstm_xcd_packed_rows(int B);               // rows per XCD that leave whole XCDs free without adding row groups
 hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd);
 hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a);
 hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);

@@ -371,25 +371,18 @@ __device__ __forceinline__ void read_frag(const float* tile, int x, int half, in
     }
 }
 
+// one 128 x 128 tile of split z: the body shared by the static-grid kernel and the work-queue kernel below
 template <int AMODE, int BMODE>
-__global__ __launch_bounds__(256, 4) void k_gemm(const GemmArgs g) {
-    static_assert(BK == 16 && BM == 128, "the direct-to-LDS kernel is written for 128x128x16 tiles");
-    constexpr int PIPE = 4 * TILE_F, EPI = 4 * 32 * 68;
-    __shared__ __attribute__((aligned(1024))) float smem[PIPE > EPI ? PIPE : EPI];
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, float* smem, int tm, int tn, int z, int tilesN) {
+    constexpr int TILE_F_ = TILE_F;
     float* As = smem;                   // [2][TILE_F]
-    float* Bs = smem + 2 * TILE_F;      // [2][TILE_F]
-
+    float* Bs = smem + 2 * TILE_F_;     // [2][TILE_F]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, khalf = lane >> 5;
-
-    const int tilesM = (g.M + 127) / 128, tilesN = (g.N + 127) / 128;
-    const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
-    const int tm = bid % tilesM, tn = bid / tilesM;
     const int m0 = tm * 128, n0 = tn * 128;
 
-    const int z = blockIdx.y;
     int kb = 0, ke = g.K;
     if (g.ksplit > 1) {
         const int per = ((g.K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK;
@@ -431,8 +424,8 @@ __global__ __launch_bounds__(256, 4) void k_gemm(const GemmArgs g) {
             if (kt + 1 < nfull) { sa.fetch(); sb.fetch(); }
             else { sa.fetch_partial(kb + (kt + 1) * BK, ke); sb.fetch_partial(kb + (kt + 1) * BK, ke); }
         }
-        const float* at = As + cur * TILE_F;
-        const float* bt = Bs + cur * TILE_F;
+        const float* at = As + cur * TILE_F_;
+        const float* bt = Bs + cur * TILE_F_;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             float a0[4], a1[4], b0[4], b1[4];
@@ -454,8 +447,8 @@ __global__ __launch_bounds__(256, 4) void k_gemm(const GemmArgs g) {
             for (int k = 0; k < BK; ++k) csum += bc[k * 128];
         }
         if (more) {
-            sa.commit(As + (cur ^ 1) * TILE_F, wave, lane);
-            sb.commit(Bs + (cur ^ 1) * TILE_F, wave, lane);
+            sa.commit(As + (cur ^ 1) * TILE_F_, wave, lane);
+            sb.commit(Bs + (cur ^ 1) * TILE_F_, wave, lane);
         }
         __syncthreads();
     }
@@ -465,8 +458,64 @@ __global__ __launch_bounds__(256, 4) void k_gemm(const GemmArgs g) {
 }
 
 template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 4) void k_gemm(const GemmArgs g) {
+    static_assert(BK == 16 && BM == 128, "the direct-to-LDS kernel is written for 128x128x16 tiles");
+    constexpr int PIPE = 4 * TILE_F, EPI = 4 * 32 * 68;
+    __shared__ __attribute__((aligned(1024))) float smem[PIPE > EPI ? PIPE : EPI];
+    const int tilesM = (g.M + 127) / 128, tilesN = (g.N + 127) / 128;
+    const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
+    gemm_tile<AMODE, BMODE>(g, smem, bid % tilesM, bid / tilesM, blockIdx.y, tilesN);
+}
+
+// Work-queue variant for the XCD-partitioned schedule (GemmArgs::xcd_first): every block draws ONE (split, row tile,
+// column tile) item, row tiles slowest, in the order blocks start -- so XCDs that are busy with something else simply
+// draw fewer.  A restricted launch
+// (xcd_first > 0) only lets blocks on XCDs >= xcd_first draw, and only while *stop == 0 and below work_limit items; the
+// clean-up launch (xcd_first < 0) drains the queue chip-wide.  Which block computes a tile never changes the tile.
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 4) void k_gemm_queue(const GemmArgs g) {
+    constexpr int PIPE = 4 * TILE_F, EPI = 4 * 32 * 68;
+    __shared__ __attribute__((aligned(1024))) float smem[PIPE > EPI ? PIPE : EPI];
+    __shared__ int s_item;
+    const int tilesM = (g.M + 127) / 128, tilesN = (g.N + 127) / 128;
+    const int total = tilesM * tilesN * (g.ksplit > 1 ? g.ksplit : 1);
+    const int limit = g.xcd_first > 0 ? min(g.work_limit, total) : total;
+    if (g.xcd_first > 0) {
+        int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if ((xcc & 7) < g.xcd_first) return;
+    }
+    if (threadIdx.x == 0) {
+        // one atomicAdd per block (a CAS loop on the counter serialises the whole chip at ~2 us per item); the per-item
+        // claim word settles restricted launch against clean-up launch
+        int item = -1;
+        if (g.xcd_first < 0) {
+            const int j = atomicAdd(g.work + 1, 1);
+            if (j < total && atomicCAS(g.claim + j, 0, 1) == 0) item = j;
+        } else if (__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+            const int j = atomicAdd(g.work, 1);
+            if (j < limit && atomicCAS(g.claim + j, 0, 1) == 0) item = j;
+        }
+        s_item = item;
+    }
+    __syncthreads();
+    const int item = s_item;
+    if (item < 0) return;
+    gemm_tile<AMODE, BMODE>(g, smem, (item / tilesN) % tilesM, item % tilesN, item / (tilesM * tilesN), tilesN);
+}
+
+template <int AMODE, int BMODE>
 hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    if (g.xcd_first != 0) {             // work-queue launch: one resident set of blocks (4 per CU), see k_gemm_queue
+        if (g.work == nullptr || g.claim == nullptr || (g.xcd_first > 0 && g.stop == nullptr) || (AMODE == OP_XC && g.gather != nullptr)) return hipErrorInvalidValue;
+        const int total = tilesM * tilesN * (g.ksplit > 1 ? g.ksplit : 1);
+        // a restricted launch needs as many blocks on the XCDs that may draw as there are items below its limit
+        const int lim = g.work_limit < total ? g.work_limit : total;
+        const int blocks = g.xcd_first > 0 ? (int)(((long long)lim * 8 + 7 - g.xcd_first) / (8 - g.xcd_first)) + 64 : total;
+        hipLaunchKernelGGL((k_gemm_queue<AMODE, BMODE>), dim3(blocks), dim3(NTHREADS), lds_pad, s, g);
+        return hipGetLastError();
+    }
     dim3 grid(tilesM * tilesN, g.ksplit > 1 ? g.ksplit : 1);
     // lds_pad: unused dynamic LDS that only lowers the number of co-resident blocks per CU
     // rows of a gathered XC operand change with k: that one (dKx) keeps the register-staged kernel

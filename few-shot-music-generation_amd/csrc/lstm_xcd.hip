@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd(const LstmFwdXcdArgs a)
     const int xcd = role.xcd, cu = role.cu;
     const int B = a.B, T = a.T;
     (void)T;
-    const int rpx = (B + NXCD - 1) / NXCD, row0 = xcd * rpx;
+    const int rpx = a.rpx > 0 ? a.rpx : (B + NXCD - 1) / NXCD, row0 = xcd * rpx;
+    if (row0 >= B) return;                        // XCD without rows (packed split): leave its CUs to other streams
 
     f32x4 W[32];
     {
@@ -268,7 +269,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd(const LstmBwdXcdArgs a)
     if (!take_role(a.tickets, a.err_flag, s_role, role)) return;
     const int xcd = role.xcd, cu = role.cu;
     const int B = a.B;
-    const int rpx = (B + NXCD - 1) / NXCD, row0 = xcd * rpx;
+    const int rpx = a.rpx > 0 ? a.rpx : (B + NXCD - 1) / NXCD, row0 = xcd * rpx;
+    if (row0 >= B) return;
 
     f32x4 W[32];          // component e' of word i = weight register 4i + e' = (cg = /64, k = %64): Kh[128w + 64cg + lane][64cu + k]
     {
@@ -450,6 +452,9 @@ bool lstm_xcd_supported(int B, int Hp) { return Hp == XH && B >= 1 && xcd_row_gr
 long long lstm_xcd_hx_floats(int B, int T) { return (long long)(T + 1) * NXCD * 4 * xcd_row_groups(B) * 2 * 64 * 4; }
 long long lstm_xcd_inbox_floats(int B) { return 2LL * NXCD * NCU * NCU * xcd_row_groups(B) * 16 * 4; }
 long long lstm_xcd_weight_floats() { return (long long)XH * XG4; }
+// Rows per XCD that fill the row groups the 8-way split already pays for: the batch then sits on the first
+// ceil(B / rows) XCDs and the others are free for another stream's GEMMs (B = 45: 8 rows on 6 XCDs instead of 6 on 8).
+int lstm_xcd_packed_rows(int B) { return 4 * xcd_row_groups(B); }
 
 hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd) {
     hipLaunchKernelGGL(k_repack_kh_xcd, dim3(1024), dim3(256), 0, s, Kh, fwd, bwd);

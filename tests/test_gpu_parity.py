@@ -602,6 +602,30 @@ def test_graph_replay_equals_eager_launches_at_full_size(monkeypatch):
         np.testing.assert_array_equal(out[0][2][k], out[1][2][k])
 
 
+def test_xcd_partitioned_schedule_gives_the_same_bits(monkeypatch):
+    """FSMG_XCD_OVERLAP=1 (off by default): the recurrence packs its rows on six XCDs and work-queue
+    GEMMs on the auxiliary stream take tiles of the projection / of dW on the other two while it runs.  Which XCD computes a
+    tile, and when, must not change a bit: with dW's K split left as the default schedule picks it the losses and every
+    gradient are identical; with the schedule's own finer split only dW's summation order differs."""
+    over, N, K, Q = FULL['cfg-B']
+    cfg = small_config(**over)
+    eps = O.synthetic_episodes(3, N, K, Q, cfg['max_len'], cfg['input_size'], seed=29)
+    out = []
+    for xov, split in (('0', '1'), ('1', '1'), ('1', '6')):
+        monkeypatch.setenv('FSMG_XCD_OVERLAP', xov)
+        monkeypatch.setenv('FSMG_XOV_DW_SPLIT', split)
+        model = new_model(cfg)
+        losses = [model.train_step(s_, q_) for s_, q_ in eps]
+        model.forward_backward(*eps[0])
+        out.append((losses, {k: model.get_grad(k) for k in model.param_shapes}, model.stats()))
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        np.testing.assert_array_equal(out[0][1][k], out[1][1][k])
+        np.testing.assert_allclose(out[2][1][k], out[0][1][k], rtol=0, atol=1e-5 * np.abs(out[0][1][k]).max())
+    np.testing.assert_allclose(out[2][0], out[0][0], rtol=1e-6)
+    assert all(st['timeouts'] == 0 and st['xcd_launches'] > 0 for _, _, st in out)
+
+
 def test_fresh_handles_reproduce_each_other_bit_for_bit_at_cfg_b():
     """Race screen (tools/race_hunt2.py in small): 100 fresh handles, two train steps each on DIFFERENT episodes (so a
     stale buffer of the previous handle or step would carry different data), every gradient and parameter identical

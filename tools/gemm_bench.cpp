@@ -77,6 +77,10 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
     float* slabs; CK(hipMalloc(&slabs, (size_t)16 * 5760 * 512 * 4 + (size_t)16 * 512 * 10004 * 4));
     float* csl; CK(hipMalloc(&csl, 32 * 10004 * 4));
+    // XCD_FIRST=k: every GEMM as a work-queue launch restricted to the XCDs >= k (GemmArgs::xcd_first) + its clean-up launch;
+    // XCD_FIRST=-1: the clean-up (chip-wide work-queue) launch alone
+    const int xcd_first = getenv("XCD_FIRST") ? atoi(getenv("XCD_FIRST")) : 0;
+    int* ctl; CK(hipMalloc(&ctl, 4 * 65536));
     for (const Shape& sh : shapes) {
         const size_t an = (size_t)sh.M * sh.K, bn = (size_t)sh.K * sh.N, cn = (size_t)sh.M * sh.N;
         float* A = dev_random(an, 1); float* B = dev_random(bn, 2);
@@ -99,8 +103,16 @@ int main(int argc, char** argv) {
             if (sh.colsum) { g.colsum = (S > 1) ? csl : cs; g.colsum_slab = sh.N; }
             float ms_k = 0, ms_t = 0;
             for (int r = -2; r < reps; ++r) {
+                if (xcd_first != 0) CK(hipMemsetAsync(ctl, 0, 4 * 65536, s));
                 CK(hipEventRecord(e0, s));
-                CK(launch_gemm(s, sh.amode, sh.bmode, g, pad));
+                if (xcd_first != 0) {
+                    GemmArgs r1 = g; r1.xcd_first = xcd_first; r1.work = ctl; r1.work_limit = 1 << 30; r1.stop = ctl + 2; r1.claim = ctl + 4;
+                    if (xcd_first > 0) CK(launch_gemm(s, sh.amode, sh.bmode, r1, pad));
+                    r1.xcd_first = -1;
+                    CK(launch_gemm(s, sh.amode, sh.bmode, r1, pad));
+                } else {
+                    CK(launch_gemm(s, sh.amode, sh.bmode, g, pad));
+                }
                 CK(hipEventRecord(e1, s));
                 if (S > 1) {
                     CK(launch_reduce_slabs(s, slabs, (long long)cn, S, C, (long long)cn));
