@@ -134,6 +134,7 @@ struct fsmg_model {
     // XCD-partitioned schedule (FSMG_XCD_OVERLAP=1; off by default: measured 385 against 388 episodes/s at cfg-B, DESIGN.md
     // section 4): the recurrence packs its rows on the first XCDs and work-queue GEMMs on the auxiliary stream take the XCDs
     // it leaves free
+    int bx3 = 1;                        // FSMG_GEMM=f32 selects the fp32-MFMA GEMM, default: bf16-split (k_gemm_bx3)
     bool xov = false, xov_call = false;
     bool bucket0_recorded = false;      // backward() recorded ev_bucket[0] itself (two-stream / XCD-partitioned order)
     int xov_dw_split = 6;               // K split of dW under this schedule: short tiles, so little is in flight when the chain ends
@@ -358,13 +359,14 @@ int download_tensor(fsmg_model* h, const float* flat, const char* name, float* h
 // idle; splitting K multiplies the block count.  Cost model: MFMA time at ~100 TF/s divided by the
 // slot efficiency of tiles*S blocks over the resident-block slots, plus S slabs of C written and read back.
 constexpr int MAX_SPLIT = 16;
-int pick_split(int64_t M, int64_t N, int64_t K, int64_t slots = 0) {
+int pick_split(int64_t M, int64_t N, int64_t K, int64_t slots = 0, bool bx3 = false) {
     static const int max_split_env = std::getenv("FSMG_MAX_SPLIT") ? std::max(1, std::atoi(std::getenv("FSMG_MAX_SPLIT"))) : MAX_SPLIT;   // debugging knob
     if (max_split_env <= 1) return 1;
     if (slots <= 0) slots = gemm_block_slots();
+    if (bx3) slots = slots * 3 / 4;                     // k_gemm_bx3: three resident blocks per CU where k_gemm has four
     const int64_t tm = gemm_tile_m();
     const int64_t tiles = ((M + tm - 1) / tm) * ((N + 127) / 128);
-    const double t_mfma = 2.0 * M * N * K / 100e12;
+    const double t_mfma = 2.0 * M * N * K / (bx3 ? 170e12 : 100e12);
     const double t_slab = 2.0 * M * N * 4.0 / 4e12;
     int best = 1; double best_t = 1e30;
     for (int S = 1; S <= MAX_SPLIT; ++S) {
@@ -430,8 +432,10 @@ int ensure_scratch(fsmg_model* h, int B) {
     {
         auto need = [&](int64_t M, int64_t N, int64_t K) {
             for (int64_t slots : {(int64_t)256, (int64_t)512, (int64_t)768, (int64_t)gemm_block_slots()}) {
-                const int S = pick_split(M, N, K, slots);
-                if (S > 1) slab_need = std::max(slab_need, (int64_t)S * M * N);
+                for (bool bx : {false, true}) {
+                    const int S = pick_split(M, N, K, slots, bx);
+                    if (S > 1) slab_need = std::max(slab_need, (int64_t)S * M * N);
+                }
             }
         };
         need(rows, Hp, h->V1p); need(Hp, h->V1p, rows); need(Hp, G4, rows);
@@ -442,10 +446,12 @@ int ensure_scratch(fsmg_model* h, int B) {
     for (int c = 0; c < nc; ++c) {
         const int64_t m = ((int64_t)(c + 1) * T / nc - (int64_t)c * T / nc) * B;
         for (int64_t slots : {(int64_t)256, (int64_t)512, (int64_t)768, (int64_t)gemm_block_slots()}) {
-            const int S = pick_split(m, Hp, h->V1p, slots);
-            if (S > 1) slab_need = std::max(slab_need, (int64_t)S * m * Hp);
-            const int S2 = pick_split(m, h->V1p, Hp, slots);
-            if (S2 > 1) slab_need = std::max(slab_need, (int64_t)S2 * m * h->V1p);
+            for (bool bx : {false, true}) {
+                const int S = pick_split(m, Hp, h->V1p, slots, bx);
+                if (S > 1) slab_need = std::max(slab_need, (int64_t)S * m * Hp);
+                const int S2 = pick_split(m, h->V1p, Hp, slots, bx);
+                if (S2 > 1) slab_need = std::max(slab_need, (int64_t)S2 * m * h->V1p);
+            }
         }
     }
     if (h->xov) slab_need = std::max(slab_need, (int64_t)std::min(h->xov_dw_split, MAX_SPLIT) * Hp * h->V1p);   // dW in short tiles
@@ -505,7 +511,8 @@ inline Lane aux_lane(fsmg_model* h, bool forward_only = false, bool persistent_c
 // summed in a fixed order (deterministic); colsum likewise.
 int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g) {
     hipStream_t s = ln.s;
-    const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K, ln.slots) : 1;
+    g.bx3 = h->bx3 && !(amode == OP_XC && g.gather != nullptr);      // gathered K rows (dKx) stay on the staged fp32 kernel
+    const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K, ln.slots, g.bx3 != 0) : 1;
     if (S <= 1 || (int64_t)S * g.M * g.N > h->slab_cap) {
         g.ksplit = 1;
         HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
@@ -705,7 +712,7 @@ int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t 
         // per-row softmax partials and a small kernel finishes the cross entropy
         ScopedTimer tm(h, "gemm_logits");
         g.ce_part = h->ce_part + (size_t)r0 * h->ce_nparts; g.ce_tgt = h->Y + r0; g.ce_tgt_logit = h->tgt_logit + r0;
-        g.ce_nvocab = h->V1;
+        g.ce_nvocab = h->V1; g.bx3 = h->bx3;
         HIPCK(h, launch_gemm(ln.s, OP_KC, OP_XC, g, ln.lds_pad));          // K = Hp: never split
         HIPCK(h, launch_ce_combine(ln.s, h->ce_part + (size_t)r0 * h->ce_nparts, h->ce_nparts,
                                    h->tgt_logit + r0, (int)m, h->ce + r0));
@@ -1240,6 +1247,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         const char* env = std::getenv("FSMG_OVERLAP");
         h->overlap = env ? (env[0] != '0') : ((int64_t)h->V1 >= 8LL * h->H * h->L);
         h->overlap_forced = env != nullptr;
+        if (const char* e = std::getenv("FSMG_GEMM")) h->bx3 = std::strcmp(e, "f32") != 0;
         if (const char* e = std::getenv("FSMG_XCD_OVERLAP")) h->xov = std::atoi(e) != 0;
         if (const char* e = std::getenv("FSMG_XOV_HEAD")) h->xov_head = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("FSMG_XOV_DW_SPLIT")) h->xov_dw_split = std::max(1, std::atoi(e));

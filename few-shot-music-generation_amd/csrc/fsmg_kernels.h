@@ -37,6 +37,7 @@ struct GemmArgs {
     //                  the remaining items read.
     // Placement decides speed, never results: an item is computed once, by the same code either way.
     int xcd_first; int* work; int* claim; int work_limit; const int* stop;
+    int bx3;                // 1: k_gemm_bx3 -- fp32 product from three bf16 planes per operand on the bf16 matrix pipe (gemm.hip)
 };
 // amode/bmode in {OP_KC, OP_XC}. Supported combinations: (KC,XC) (XC,XC) (KC,KC)
 hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, int lds_pad = 0);

@@ -504,6 +504,207 @@ __global__ __launch_bounds__(256, 4) void k_gemm_queue(const GemmArgs g) {
     gemm_tile<AMODE, BMODE>(g, smem, (item / tilesN) % tilesM, item % tilesN, item / (tilesM * tilesN), tilesN);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix pipe ("bx3"): v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA, so an
+// fp32 product is assembled from bf16 pieces.  Every operand value is split EXACTLY into three bf16 numbers
+//     a = a1 + a2 + a3,   a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)
+// (round-to-nearest: |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a|, and the last residual fits 8 significant bits; the two
+// subtractions are exact in fp32), and the six partial products that matter are accumulated in fp32:
+//     a b ~= a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2),   dropped: a2 b3 + a3 b2 + a3 b3 <= 2^-23 |a b|
+// i.e. one half-ulp of the fp32 product, unbiased -- the accumulation (fp32, as in the fp32 MFMA) dominates the error
+// either way.  6 MFMAs of 32x32x16 (32 cycles each) replace 8 of 32x32x2 (64 cycles each) per 16 k: 2.67x the rate.
+// The split runs on the VALU between the global load and the LDS write (5.5 instructions per element), the LDS holds
+// the three planes as [plane][k half][128 x][8 bf16] so that a fragment is one conflict-free ds_read_b128 per lane.
+// Same tiling, epilogue, split-K and XCD-aware tile order as k_gemm; same A / B conventions.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// two fp32 values -> their three bf16 planes, packed (x in the low half)
+__device__ __forceinline__ void split2(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = cvt_pk_bf16(x, y);
+    const float rx = x - __uint_as_float(p0 << 16), ry = y - __uint_as_float(p0 & 0xffff0000u);
+    p1 = cvt_pk_bf16(rx, ry);
+    const float sx = rx - __uint_as_float(p1 << 16), sy = ry - __uint_as_float(p1 & 0xffff0000u);
+    p2 = cvt_pk_bf16(sx, sy);
+}
+
+constexpr int BX_PLANE = 2 * 128 * 16;          // bytes: [2 k halves][128 x][8 bf16]
+constexpr int BX_OPER = 3 * BX_PLANE;           // one operand tile, three planes
+constexpr int BX_STAGE = 2 * BX_OPER;           // A + B
+
+// Global -> registers -> LDS for one operand tile (128 x, 16 k).  Eight values per thread either way:
+//   XC (x contiguous): thread = (x = tid % 128, k half = tid / 128), eight 4-byte loads down k (a wave reads 256
+//       contiguous bytes per load); one 16-byte LDS write per plane;
+//   KC (k contiguous): thread = (rows tid / 4 and tid / 4 + 64, k quad = tid % 4), two 16-byte loads (four lanes cover
+//       the 64 bytes a row contributes to the tile); two 8-byte LDS writes per plane.
+template <int MODE>
+struct BxStager {
+    const float* p[2];
+    float v[8];
+    long long step, ld_;
+    int lds_ofs[2];
+    __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather, int kb, int tid) {
+        ld_ = ld;
+        if (MODE == OP_XC) {
+            const int x = min(x0 + (tid & 127), X - 1), kh = tid >> 7;
+            p[0] = src + (long long)(kb + 8 * kh) * ld + x; p[1] = nullptr;
+            step = (long long)16 * ld;
+            lds_ofs[0] = kh * 2048 + (tid & 127) * 16; lds_ofs[1] = 0;
+        } else {
+            const int kq = tid & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int xl = (tid >> 2) + 64 * i, x = min(x0 + xl, X - 1);
+                const long long row = gather ? (long long)gather[x] : (long long)x;
+                p[i] = src + row * ld + kb + 4 * kq;
+                lds_ofs[i] = (kq >> 1) * 2048 + xl * 16 + (kq & 1) * 8;
+            }
+            step = 16;
+        }
+    }
+    __device__ __forceinline__ void fetch() {
+        if (MODE == OP_XC) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = p[0][i * ld_];
+            p[0] += step;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 q = *reinterpret_cast<const float4*>(p[i]);
+                v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+                p[i] += step;
+            }
+        }
+    }
+    // last tile of a K range: k0 = first k of the tile, zeros from kend on
+    __device__ __forceinline__ void fetch_partial(int k0, int kend, int tid) {
+        if (MODE == OP_XC) {
+            const int kh = tid >> 7;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (k0 + 8 * kh + i < kend) ? p[0][i * ld_] : 0.0f;
+            p[0] += step;
+        } else {
+            const int kq = tid & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * i + e] = (k0 + 4 * kq + e < kend) ? p[i][e] : 0.0f;
+                p[i] += step;
+            }
+        }
+    }
+    __device__ __forceinline__ float sum8() const { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
+    __device__ __forceinline__ void commit(unsigned char* tile) const {
+        unsigned w[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], w[0][j], w[1][j], w[2][j]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            if (MODE == OP_XC) {
+                *reinterpret_cast<uint4*>(tile + pl * BX_PLANE + lds_ofs[0]) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+            } else {
+                *reinterpret_cast<uint2*>(tile + pl * BX_PLANE + lds_ofs[0]) = make_uint2(w[pl][0], w[pl][1]);
+                *reinterpret_cast<uint2*>(tile + pl * BX_PLANE + lds_ofs[1]) = make_uint2(w[pl][2], w[pl][3]);
+            }
+        }
+    }
+};
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 2) void k_gemm_bx3(const GemmArgs g) {
+    constexpr int EPI = 4 * 32 * 68 * 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[(2 * BX_STAGE > EPI) ? 2 * BX_STAGE : EPI];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int tilesM = (g.M + 127) / 128, tilesN = (g.N + 127) / 128;
+    const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
+    const int tm = bid % tilesM, tn = bid / tilesM, z = blockIdx.y;
+    const int m0 = tm * 128, n0 = tn * 128;
+
+    int kb = 0, ke = g.K;
+    if (g.ksplit > 1) {
+        const int per = ((g.K + g.ksplit - 1) / g.ksplit + 15) / 16 * 16;
+        kb = z * per;
+        ke = min(g.K, kb + per);
+    }
+    const int nk = (ke > kb) ? (ke - kb + 15) / 16 : 0;
+    const int nfull = (ke > kb) ? (ke - kb) / 16 : 0;
+
+    BxStager<AMODE> sa;
+    BxStager<BMODE> sb;
+    sa.init(g.A, g.lda, g.M, m0, g.gather, kb, tid);
+    sb.init(g.B, g.ldb, g.N, n0, nullptr, kb, tid);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0;
+    float csum = 0.0f;
+
+    if (nk > 0) {
+        if (nfull > 0) { sa.fetch(); sb.fetch(); }
+        else { sa.fetch_partial(kb, ke, tid); sb.fetch_partial(kb, ke, tid); }
+        if (do_colsum) csum += sb.sum8();
+        sa.commit(smem);
+        sb.commit(smem + BX_OPER);
+    }
+    __syncthreads();
+
+    const int fa = khalf * 2048 + (wm * 64 + l31) * 16, fb = khalf * 2048 + (wn * 64 + l31) * 16;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            if (kt + 1 < nfull) { sa.fetch(); sb.fetch(); }
+            else { sa.fetch_partial(kb + (kt + 1) * 16, ke, tid); sb.fetch_partial(kb + (kt + 1) * 16, ke, tid); }
+        }
+        const unsigned char* at = smem + cur * BX_STAGE;
+        const unsigned char* bt = at + BX_OPER;
+        bf16x8_t a[3][2], b[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[pl][i] = *reinterpret_cast<const bf16x8_t*>(at + pl * BX_PLANE + fa + i * 512);
+                b[pl][i] = *reinterpret_cast<const bf16x8_t*>(bt + pl * BX_PLANE + fb + i * 512);
+            }
+        // smallest terms first; four independent accumulators per term keep the pipe full
+#define BX_TERM(PA, PB)                                                                                        \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][0], acc[0][0], 0, 0, 0);            \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][1], acc[0][1], 0, 0, 0);            \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][0], acc[1][0], 0, 0, 0);            \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][1], acc[1][1], 0, 0, 0);
+        BX_TERM(2, 0) BX_TERM(0, 2) BX_TERM(1, 1) BX_TERM(1, 0) BX_TERM(0, 1) BX_TERM(0, 0)
+#undef BX_TERM
+        if (more) {
+            if (do_colsum) csum += sb.sum8();
+            sa.commit(smem + (cur ^ 1) * BX_STAGE);
+            sb.commit(smem + (cur ^ 1) * BX_STAGE + BX_OPER);
+        }
+        __syncthreads();
+    }
+
+    float* smem_f = reinterpret_cast<float*>(smem);
+    if (do_colsum) {                    // the two k halves of a column live in threads tid and tid + 128
+        __shared__ float s_cs[128];
+        if (tid >= 128) s_cs[tid - 128] = csum;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < g.N) g.colsum[(long long)z * g.colsum_slab + n0 + tid] = csum + s_cs[tid];
+    }
+    store_tile(g, acc, smem_f, z, m0, n0, tn, tilesN, wave, lane);
+}
+
 template <int AMODE, int BMODE>
 hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
@@ -517,6 +718,10 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
         return hipGetLastError();
     }
     dim3 grid(tilesM * tilesN, g.ksplit > 1 ? g.ksplit : 1);
+    if (g.bx3) {
+        hipLaunchKernelGGL((k_gemm_bx3<AMODE, BMODE>), grid, dim3(256), lds_pad, s, g);
+        return hipGetLastError();
+    }
     // lds_pad: unused dynamic LDS that only lowers the number of co-resident blocks per CU
     // rows of a gathered XC operand change with k: that one (dKx) keeps the register-staged kernel
     if (AMODE == OP_XC && g.gather != nullptr) hipLaunchKernelGGL((k_gemm_staged<OP_XC, OP_XC>), grid, dim3(NTHREADS), lds_pad, s, g);

@@ -611,6 +611,7 @@ def test_xcd_partitioned_schedule_gives_the_same_bits(monkeypatch):
     cfg = small_config(**over)
     eps = O.synthetic_episodes(3, N, K, Q, cfg['max_len'], cfg['input_size'], seed=29)
     out = []
+    monkeypatch.setenv('FSMG_GEMM', 'f32')       # the work-queue kernel exists for the fp32-MFMA GEMM only
     for xov, split in (('0', '1'), ('1', '1'), ('1', '6')):
         monkeypatch.setenv('FSMG_XCD_OVERLAP', xov)
         monkeypatch.setenv('FSMG_XOV_DW_SPLIT', split)

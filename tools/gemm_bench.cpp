@@ -5,6 +5,7 @@
 // Prints per shape: ksplit, kernel-only ms (GEMM without the slab reduce), total ms, TF on the total.
 #include "fsmg_kernels.h"
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <cmath>
 #include <algorithm>
@@ -14,25 +15,32 @@ using namespace fsmg;
 
 struct Shape { const char* name; int amode, bmode; int M, N, K; int ksplit; bool colsum; };
 
-// reference: one thread per element, plain fp32 fma chain in k order
+// reference: one thread per element, fp64 accumulation
 __global__ void k_ref(const float* A, int lda, int amode, const float* B, int ldb, int bmode, float* C, int M, int N, int K) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)M * N) return;
     const int m = (int)(i / N), n = (int)(i % N);
-    float s = 0.f;
+    double s = 0.0;                 // exact products, fp64 sum: what every kernel's error is measured against
     for (int k = 0; k < K; ++k) {
         const float a = (amode == OP_KC) ? A[(long long)m * lda + k] : A[(long long)k * lda + m];
         const float b = (bmode == OP_KC) ? B[(long long)n * ldb + k] : B[(long long)k * ldb + n];
-        s = fmaf(a, b, s);
+        s += (double)a * (double)b;
     }
-    C[i] = s;
+    C[i] = (float)s;
 }
 __global__ void k_ref_colsum(const float* B, int ldb, float* cs, int N, int K) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    float s = 0.f;
+    double s = 0.0;
     for (int k = 0; k < K; ++k) s += B[(long long)k * ldb + n];
-    cs[n] = s;
+    cs[n] = (float)s;
+}
+static double rms_rel(const float* d_a, const float* d_b, size_t n) {
+    std::vector<float> a(n), b(n);
+    CK(hipMemcpy(a.data(), d_a, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), d_b, n * 4, hipMemcpyDeviceToHost));
+    double e = 0, r = 0;
+    for (size_t i = 0; i < n; ++i) { double d = (double)a[i] - b[i]; e += d * d; r += (double)b[i] * b[i]; }
+    return std::sqrt(e / (r > 0 ? r : 1));
 }
 static double max_rel(const float* d_a, const float* d_b, size_t n) {
     std::vector<float> a(n), b(n);
@@ -80,8 +88,11 @@ int main(int argc, char** argv) {
     // XCD_FIRST=k: every GEMM as a work-queue launch restricted to the XCDs >= k (GemmArgs::xcd_first) + its clean-up launch;
     // XCD_FIRST=-1: the clean-up (chip-wide work-queue) launch alone
     const int xcd_first = getenv("XCD_FIRST") ? atoi(getenv("XCD_FIRST")) : 0;
+    const int bx3 = getenv("BX3") ? atoi(getenv("BX3")) : 0;      // BX3=1: the bf16-split kernel (k_gemm_bx3)
     int* ctl; CK(hipMalloc(&ctl, 4 * 65536));
+    const char* only = getenv("ONLY");                         // ONLY=substring of the shape name
     for (const Shape& sh : shapes) {
+        if (only && !strstr(sh.name, only)) continue;
         const size_t an = (size_t)sh.M * sh.K, bn = (size_t)sh.K * sh.N, cn = (size_t)sh.M * sh.N;
         float* A = dev_random(an, 1); float* B = dev_random(bn, 2);
         float* C; CK(hipMalloc(&C, cn * 4)); float* cs; CK(hipMalloc(&cs, sh.N * 4));
@@ -99,7 +110,7 @@ int main(int argc, char** argv) {
             g.A = A; g.lda = (sh.amode == OP_KC) ? sh.K : sh.M;
             g.B = B; g.ldb = (sh.bmode == OP_KC) ? sh.K : sh.N;
             g.C = (S > 1) ? slabs : C; g.ldc = sh.N; g.M = sh.M; g.N = sh.N; g.K = sh.K;
-            g.ksplit = S; g.c_slab = (long long)cn;
+            g.ksplit = S; g.c_slab = (long long)cn; g.bx3 = bx3;
             if (sh.colsum) { g.colsum = (S > 1) ? csl : cs; g.colsum_slab = sh.N; }
             float ms_k = 0, ms_t = 0;
             for (int r = -2; r < reps; ++r) {
@@ -128,7 +139,7 @@ int main(int argc, char** argv) {
             if (verify) {
                 CK(hipStreamSynchronize(s));
                 const double e = max_rel(C, Cref, cn), ec = sh.colsum ? max_rel(cs, csref, sh.N) : 0.0;
-                printf("  verify S %d: C err %.2e  colsum err %.2e  %s\n", S, e, ec, (e < 2e-5 && ec < 2e-5) ? "ok" : "MISMATCH");
+                printf("  verify S %d: C max err / max|C| %.2e  rms err / rms %.2e  colsum err %.2e  %s\n", S, e, rms_rel(C, Cref, cn), ec, (e < 2e-5 && ec < 2e-4) ? "ok" : "MISMATCH");
                 CK(hipMemset(C, 0xff, cn * 4));
             }
             printf("%s  M %5d N %5d K %5d  S %d  blocks %5d (%.2f rounds of %d)  gemm %.3f ms  total %.3f ms  %.1f TF\n", sh.name, sh.M, sh.N, sh.K, S,
