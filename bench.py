@@ -56,6 +56,14 @@ OTHER = {
 }
 POOL = 256
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# the GEMMs' bound: fp32 products assembled from 6 bf16 MFMAs (k_gemm_bx3, csrc/gemm.hip) -> dense bf16 peak / 6
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_BX3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+ARITHMETIC = ('fp32 storage, fp32 accumulation everywhere.  GEMMs (default, FSMG_GEMM=bx3): every operand value is split EXACTLY into three '
+              'bf16 numbers and the six partial products >= 2^-23 of the fp32 product are summed in fp32 by v_mfma_f32_32x32x16_bf16 -- '
+              'error against fp64 below the fp32-MFMA kernel\'s on every shape of the step (tools/gemm_bench.cpp, BX3=0/1 with verify; '
+              'tests/test_gpu_parity.py::test_bf16_split_gemm_is_no_less_accurate_than_the_fp32_mfma_gemm); FSMG_GEMM=f32 selects '
+              'v_mfma_f32_32x32x2_f32 (timed in the same run as alt_gemm_f32_mfma).  Fused LSTM cell: v_mfma_f32_4x4x1_16B_f32 (fp32 MFMA).')
 CELL_CLASSES = ('lstm_fwd', 'lstm_bwd')      # the fused LSTM cell: the north star's target kernel
 CLASSES = ['gemm_zx', 'lstm_fwd', 'gemm_logits', 'ce', 'gemm_dhout', 'gemm_dw', 'lstm_bwd', 'gemm_dk',
            'gemm_dx', 'embed_grad', 'update']
@@ -300,12 +308,15 @@ def main():
             'metric': 'episodes/s (LSTM-baseline train step, synthetic vocab=10k seq_len=128 5-way/5-shot h=512)',
             'value': value, 'unit': 'episodes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32', 'arithmetic': ARITHMETIC, 'gemm_kind': os.environ.get('FSMG_GEMM', 'bx3'), 'data': 'synthetic',
             'config': {'workload': wl + (', MAML-style step (1 inner clipped-SGD step on the support rows + outer clip+Adam on the query gradient)'
                                          if maml else ', full train step (fwd+BPTT+clip+Adam)') + ', one episode per GPU per step',
                        'episodes_per_step': world, 'parallelism': 'episode-parallel x%d, 1 RCCL all-reduce/step' % world},
             'guard': guard,
+            # whole-step algorithmic TFLOP/s over the fp32-MFMA peak (the bound of round 1's arithmetic; > 1 is possible now
+            # that the GEMMs run on the bf16 pipe) and over the blended bound (GEMM FLOPs at peak/6 of bf16, cell FLOPs at fp32 MFMA)
             'step_mfma_frac': None if maml else (total_gflop / (1e3 * elapsed / max(args.steps, 1))) / PEAK_F32_MFMA_TFLOPS,
+            'step_tflops': None if maml else total_gflop / (1e3 * elapsed / max(args.steps, 1)),
             'final_loss': float(losses[-1]), 'first_loss': float(losses[0]),
             'per_rank_ms_per_step': [1e3 * t / max(args.steps, 1) for t in per_rank], 'comm': comm,
         }
@@ -385,10 +396,40 @@ def main():
                 kernels[c] = {'ms_per_step': per_step}
                 if c in gf:
                     kernels[c]['tflops'] = gf[c] / per_step
-                    kernels[c]['frac_mfma_peak'] = gf[c] / per_step / PEAK_F32_MFMA_TFLOPS
+                    kernels[c]['frac_mfma_peak'] = gf[c] / per_step / PEAK_F32_MFMA_TFLOPS      # of the fp32-MFMA peak
+                    if c.startswith('gemm_') and os.environ.get('FSMG_GEMM', 'bx3') != 'f32':
+                        kernels[c]['frac_bx3_bound'] = gf[c] / per_step / PEAK_BX3_TFLOPS          # of bf16 peak / 6
         eng.timing_enable(False)
         out['kernels'] = kernels
         log('breakdown done')
+    if rank == 0 and world == 1 and not args.no_breakdown and not maml and os.environ.get('FSMG_GEMM', 'bx3') != 'f32':
+        # the same timed loop with every GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32): what the bf16-split GEMMs buy
+        os.environ['FSMG_GEMM'] = 'f32'
+        try:
+            alt = Model(cfg)
+            alt.recover_or_init('')
+            par_alt = EpisodeParallel(alt)
+            def step_alt(i):
+                e = i % POOL
+                par_alt.train_step(d_sup.data_ptr() + e * sup_stride, d_qry.data_ptr() + e * qry_stride, want_loss=False, shape=shape)
+            n_alt = min(args.steps, 60)
+            for i in range(min(args.warmup, 10)):
+                step_alt(i)
+            torch.cuda.synchronize()
+            a0 = alt.engine.step
+            t0 = time.perf_counter()
+            for i in range(n_alt):
+                step_alt(10 + i)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            l_alt = alt.engine.read_losses(min(n_alt, 1024))
+            out['alt_gemm_f32_mfma'] = {'value': n_alt / dt, 'unit': 'episodes/s', 'ms_per_step': 1e3 * dt / n_alt, 'steps': n_alt,
+                                        'advanced_by': alt.engine.step - a0, 'final_loss': float(l_alt[-1]),
+                                        'note': 'same workload and schedule, every GEMM on v_mfma_f32_32x32x2_f32 (FSMG_GEMM=f32)'}
+            del alt, par_alt
+        finally:
+            del os.environ['FSMG_GEMM']
+        log('fp32-MFMA GEMM leg done')
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not maml:
         out['cpu_baseline'] = cpu_baseline(base, pool_host, shape)
         if out['cpu_baseline'] and 'eval' in out:
