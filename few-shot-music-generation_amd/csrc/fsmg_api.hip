@@ -511,7 +511,7 @@ inline Lane aux_lane(fsmg_model* h, bool forward_only = false, bool persistent_c
 // summed in a fixed order (deterministic); colsum likewise.
 int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g) {
     hipStream_t s = ln.s;
-    g.bx3 = h->bx3 && !(amode == OP_XC && g.gather != nullptr);      // gathered K rows (dKx) stay on the staged fp32 kernel
+    g.bx3 = h->bx3;
     const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K, ln.slots, g.bx3 != 0) : 1;
     if (S <= 1 || (int64_t)S * g.M * g.N > h->slab_cap) {
         g.ksplit = 1;
@@ -1161,8 +1161,11 @@ inline uint64_t splitmix64(uint64_t x) {
 }
 
 // forward + backward of one episode whose tokens `stage` puts into the handle's staging buffer ([n_sup + n_qry][T], support rows first)
+int apply_update(fsmg_model* h, float grad_scale);
+// with_update: the clip + Adam update (grad_scale 1) rides in the same captured graph -- the single-GPU train step; a
+// gradient exchange between the two halves (episode-parallel training) needs them as separate calls
 template <class Stage>
-int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&& stage) {
+int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&& stage, bool with_update = false) {
     hipSetDevice(h->device);
     int rc = validate_shape(h, N, K, Q);
     if (rc != FSMG_OK) return rc;
@@ -1177,10 +1180,11 @@ int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&
     if ((rc = stage()) != FSMG_OK) return rc;
     const int n_sup = N * K, n_qry = N * Q;
     h->bucket0_recorded = false;
-    rc = run_graphed(h, "fb:" + std::to_string(n_sup) + ":" + std::to_string(n_qry), [&]() -> int {
+    rc = run_graphed(h, (with_update ? "fbu:" : "fb:") + std::to_string(n_sup) + ":" + std::to_string(n_qry), [&]() -> int {
         int r = token_prep(h, n_sup, n_qry);
         if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1, true);
         if (r == FSMG_OK) r = backward(h, B);
+        if (r == FSMG_OK && with_update) r = apply_update(h, 1.0f);
         return r;
     });
     if (rc != FSMG_OK) return rc;
@@ -1191,6 +1195,32 @@ int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&
     h->lastB = B;
     h->have_grads = true;
     return FSMG_OK;
+}
+
+int after_update(fsmg_model* h, float grad_scale, float* loss) {
+    h->have_grads = false;
+    if (loss) return check_tokens_and_read(h, h->G + h->n_flat + 1, grad_scale, loss, 1, true);
+    // no read-back: skipped steps of EARLIER calls that have retired by now are noticed here (a time-out switches the
+    // handle to per-step launches; the skipped episodes stay skipped -- fsmg_get_stats counts them)
+    const int what = poll_skipped(h);
+    if (what == 1) return report(h, 1);
+    return FSMG_OK;
+}
+
+// forward + backward + update as ONE captured graph (17 us between two graph launches at cfg-B otherwise)
+template <class Stage>
+int fused_train_step(fsmg_model* h, int32_t N, int32_t K, int32_t Q, float* loss, Stage&& stage) {
+    int rc = forward_backward_core(h, N, K, Q, stage, true);
+    if (rc == FSMG_OK) rc = after_update(h, 1.0f, loss);
+    if (rc == FSMG_ERR_HIP && h->persist_timed_out) {
+        // a persistent step kernel could not get all of its blocks resident (another workload holds the CUs): the
+        // update kernels saw the flag and left parameters, Adam state and step counter alone, and the handle has
+        // fallen back to one launch per time step -- repeat the step that way
+        h->persist_timed_out = false;
+        rc = forward_backward_core(h, N, K, Q, stage, true);
+        if (rc == FSMG_OK) rc = after_update(h, 1.0f, loss);
+    }
+    return rc;
 }
 
 }  // namespace
@@ -1493,15 +1523,8 @@ int fsmg_forward_backward_indexed(fsmg_handle h, int32_t table_id, const int32_t
 
 int fsmg_train_step_indexed(fsmg_handle h, int32_t table_id, const int32_t* support_idx, const int32_t* query_idx,
                             int32_t N, int32_t K, int32_t Q, float* loss) {
-    int rc = fsmg_forward_backward_indexed(h, table_id, support_idx, query_idx, N, K, Q);
-    if (rc != FSMG_OK) return rc;
-    rc = fsmg_apply_update(h, 1.0f, loss);
-    if (rc == FSMG_ERR_HIP && h->persist_timed_out) {
-        h->persist_timed_out = false;
-        rc = fsmg_forward_backward_indexed(h, table_id, support_idx, query_idx, N, K, Q);
-        if (rc == FSMG_OK) rc = fsmg_apply_update(h, 1.0f, loss);
-    }
-    return rc;
+    if (!h || !support_idx || !query_idx) return FSMG_ERR_INVALID;
+    return fused_train_step(h, N, K, Q, loss, [&]() { return stage_indexed(h, table_id, support_idx, N * K, query_idx, N * Q); });
 }
 
 int fsmg_grad_buffer(fsmg_handle h, void** device_ptr, int64_t* count) {
@@ -1535,29 +1558,13 @@ int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss) {
     uint32_t bits; std::memcpy(&bits, &grad_scale, 4);
     int rc = run_graphed(h, "up:" + std::to_string(bits), [&]() -> int { return apply_update(h, grad_scale); });
     if (rc != FSMG_OK) return rc;
-    h->have_grads = false;
-    if (loss) return check_tokens_and_read(h, h->G + h->n_flat + 1, grad_scale, loss, 1, true);
-    // no read-back: skipped steps of EARLIER calls that have retired by now are noticed here (a time-out switches the
-    // handle to per-step launches; the skipped episodes stay skipped -- fsmg_get_stats counts them)
-    const int what = poll_skipped(h);
-    if (what == 1) return report(h, 1);
-    return FSMG_OK;
+    return after_update(h, grad_scale, loss);
 }
 
 int fsmg_train_step(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K, int32_t Q,
                     int32_t tokens_on_device, float* loss) {
-    int rc = fsmg_forward_backward(h, support, query, N, K, Q, tokens_on_device);
-    if (rc != FSMG_OK) return rc;
-    rc = fsmg_apply_update(h, 1.0f, loss);
-    if (rc == FSMG_ERR_HIP && h->persist_timed_out) {
-        // a persistent step kernel could not get all of its blocks resident (another workload holds the CUs): the
-        // update kernels saw the flag and left parameters, Adam state and step counter alone, and the handle has
-        // fallen back to one launch per time step -- repeat the step that way
-        h->persist_timed_out = false;
-        rc = fsmg_forward_backward(h, support, query, N, K, Q, tokens_on_device);
-        if (rc == FSMG_OK) rc = fsmg_apply_update(h, 1.0f, loss);
-    }
-    return rc;
+    if (!h || !support || !query) return FSMG_ERR_INVALID;
+    return fused_train_step(h, N, K, Q, loss, [&]() { return stage_tokens(h, support, N * K, query, N * Q, tokens_on_device); });
 }
 
 // ---- cfg-E (BASELINE.json configs[4]): MAML-style inner / outer loop, first order.  DESIGN.md "cfg-E".

@@ -541,19 +541,33 @@ constexpr int BX_STAGE = 2 * BX_OPER;           // A + B
 //       contiguous bytes per load); one 16-byte LDS write per plane;
 //   KC (k contiguous): thread = (rows tid / 4 and tid / 4 + 64, k quad = tid % 4), two 16-byte loads (four lanes cover
 //       the 64 bytes a row contributes to the tile); two 8-byte LDS writes per plane.
+//   XC with gathered K rows (dKx: row k of the operand is row gather[k] of the embedding): the eight row ids of the NEXT
+//       tile are fetched one tile ahead, so a tile's loads do not wait for an index load first.
 template <int MODE>
 struct BxStager {
     const float* p[2];
     float v[8];
     long long step, ld_;
     int lds_ofs[2];
-    __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather, int kb, int tid) {
-        ld_ = ld;
+    const int* gp;          // XC + gather: &gather[k] of this thread's first row of the next tile
+    int gk, gK;             // ... that k, and the K bound of the gather array
+    int gi[8];
+    __device__ __forceinline__ void load_ids() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gi[i] = gp[min(i, gK - 1 - gk)];      // clamped: the id of a row past K is never used
+    }
+    __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather, int kb, int tid, int K = 0) {
+        ld_ = ld; gp = nullptr;
         if (MODE == OP_XC) {
             const int x = min(x0 + (tid & 127), X - 1), kh = tid >> 7;
             p[0] = src + (long long)(kb + 8 * kh) * ld + x; p[1] = nullptr;
             step = (long long)16 * ld;
             lds_ofs[0] = kh * 2048 + (tid & 127) * 16; lds_ofs[1] = 0;
+            if (gather != nullptr) {
+                p[0] = src + x;
+                gK = K; gk = min(kb + 8 * kh, K - 1); gp = gather + gk;
+                load_ids();
+            }
         } else {
             const int kq = tid & 3;
 #pragma unroll
@@ -566,8 +580,19 @@ struct BxStager {
             step = 16;
         }
     }
+    __device__ __forceinline__ void advance_ids() {          // ids of the tile after the one just requested
+        const int nk = min(gk + 16, gK - 1);
+        gp += nk - gk; gk = nk;
+        load_ids();
+    }
     __device__ __forceinline__ void fetch() {
         if (MODE == OP_XC) {
+            if (gp != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = p[0][(long long)gi[i] * ld_];
+                advance_ids();
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = p[0][i * ld_];
             p[0] += step;
@@ -584,6 +609,12 @@ struct BxStager {
     __device__ __forceinline__ void fetch_partial(int k0, int kend, int tid) {
         if (MODE == OP_XC) {
             const int kh = tid >> 7;
+            if (gp != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (k0 + 8 * kh + i < kend) ? p[0][(long long)gi[i] * ld_] : 0.0f;
+                advance_ids();
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = (k0 + 8 * kh + i < kend) ? p[0][i * ld_] : 0.0f;
             p[0] += step;
@@ -638,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(const GemmArgs g) {
 
     BxStager<AMODE> sa;
     BxStager<BMODE> sb;
-    sa.init(g.A, g.lda, g.M, m0, g.gather, kb, tid);
+    sa.init(g.A, g.lda, g.M, m0, g.gather, kb, tid, g.K);
     sb.init(g.B, g.ldb, g.N, n0, nullptr, kb, tid);
 
     f32x16 acc[2][2];
@@ -718,7 +749,7 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
         return hipGetLastError();
     }
     dim3 grid(tilesM * tilesN, g.ksplit > 1 ? g.ksplit : 1);
-    if (g.bx3) {
+    if (g.bx3) {             // (gathered K rows included: BxStager)
         hipLaunchKernelGGL((k_gemm_bx3<AMODE, BMODE>), grid, dim3(256), lds_pad, s, g);
         return hipGetLastError();
     }

@@ -63,6 +63,8 @@ class EpisodeParallel(object):
             return self._train_step_once(support, query, want_loss, **kw)
 
     def _train_step_once(self, support, query, want_loss=True, maml=None, table=None, **kw):
+        if self.world == 1 and maml is None and hasattr(self.engine, 'fused_train_step'):
+            return self.engine.fused_train_step(support, query, want_loss=want_loss, table=table, **kw)
         if table is not None:                 # support / query are [N,K] / [N,Q] row indices into a device-resident split table
             self.engine.forward_backward_indexed(table, support, query)
         elif maml is not None:

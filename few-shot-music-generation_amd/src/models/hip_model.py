@@ -73,6 +73,12 @@ class HIPModel(BaseModel):
     def maml_forward_backward(self, support, query, inner_steps, inner_lr, **kw):
         self._model.maml_forward_backward(support, query, inner_steps, inner_lr, **kw)
 
+    def fused_train_step(self, support, query, want_loss=True, table=None, **kw):
+        """forward + backward + clip + Adam as ONE captured graph (the single-process step: nothing to exchange in between)"""
+        if table is not None:
+            return self._model.train_step_indexed(table, support, query, want_loss=want_loss)
+        return self._model.train_step(support, query, want_loss=want_loss, **kw)
+
     def apply_update(self, grad_scale=1.0, want_loss=True):
         return self._model.apply_update(grad_scale, want_loss=want_loss)
 
