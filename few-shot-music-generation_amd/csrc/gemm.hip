@@ -1,4 +1,7 @@
-// fp32 GEMM for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak).
+// fp32 GEMMs for gfx950: k_gemm_bx3 (default) assembles every fp32 product from bf16 pieces on v_mfma_f32_32x32x16_bf16
+// (16x the fp32 MFMA's rate; exact three-way operand split, six products, fp32 accumulation -- see the block comment above
+// it), k_gemm / k_gemm_staged / k_gemm_queue run on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak).  The notes below
+// describe the fp32-MFMA kernels; tiling, epilogue, split-K and tile order are shared.
 //
 // One kernel template serves every dense contraction of the LSTM-baseline step
 // (DESIGN.md "Kernels"): the hoisted input projection with the embedding gather fused
