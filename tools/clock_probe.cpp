@@ -50,6 +50,7 @@ int main() {
     float* C; CK(hipMalloc(&C, (size_t)3 * 512 * 10004 * 4)); float* sink; CK(hipMalloc(&sink, 4096));
     GemmArgs g{};
     g.A = A; g.lda = 512; g.B = B; g.ldb = 10004; g.C = C; g.ldc = 10004; g.M = 512; g.N = 10004; g.K = 5760; g.ksplit = 3; g.c_slab = (long long)512 * 10004;
+    g.bx3 = getenv("BX3") ? atoi(getenv("BX3")) : 0;          // BX3=1: the bf16-split GEMM as the co-runner
     const char* names[] = {"idle chip", "beside the dW GEMM (random operands)", "beside a register-only MFMA loop", "after 50 ms of GEMMs, still running"};
     for (int mode = 0; mode < 4; ++mode) {
         if (mode == 1) for (int r = 0; r < 6; ++r) CK(launch_gemm(sg, OP_XC, OP_XC, g, 0));
