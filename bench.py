@@ -401,6 +401,15 @@ def main():
                         kernels[c]['frac_bx3_bound'] = gf[c] / per_step / PEAK_BX3_TFLOPS          # of bf16 peak / 6
         eng.timing_enable(False)
         out['kernels'] = kernels
+        # the GEMMs as one family (63 % of the step): fp32-equivalent TFLOP/s over the instrumented pass against their own bound
+        gemm = [c for c in kernels if c.startswith('gemm_')]
+        g_ms = sum(kernels[c]['ms_per_step'] for c in gemm)
+        g_gf = sum(gf[c] for c in gemm)
+        bx3 = os.environ.get('FSMG_GEMM', 'bx3') != 'f32'
+        out['roofline_gemm'] = {'bound': 'mfma', 'kernel': 'k_gemm_bx3 (all seven dense contractions of the step)' if bx3 else 'k_gemm (fp32 MFMA)',
+                                'achieved': g_gf / g_ms, 'peak': PEAK_BX3_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s (fp32-equivalent)',
+                                'frac': g_gf / g_ms / (PEAK_BX3_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS), 'ms_per_step': g_ms,
+                                'note': 'peak = dense bf16 MFMA peak / 6 products per fp32 product at the 2.4 GHz spec clock; the chip sustains 1.92 GHz beside this kernel'}
         log('breakdown done')
     if rank == 0 and world == 1 and not args.no_breakdown and not maml and os.environ.get('FSMG_GEMM', 'bx3') != 'f32':
         # the same timed loop with every GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32): what the bf16-split GEMMs buy
