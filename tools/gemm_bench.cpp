@@ -50,10 +50,20 @@ static double max_rel(const float* d_a, const float* d_b, size_t n) {
     return e / (r > 0 ? r : 1);
 }
 
+// DIST=0 (default): uniform on [-0.5, 0.5).  DIST=1: sign * mantissa * 2^e with e uniform on [-30, 30] (sixty binades in
+// one operand: the split must be exact at every magnitude).  DIST=2: 1e4 * uniform -- products of 1e8 that cancel to sums of
+// O(1e8 sqrt K): errors are reported relative to max|C|, so this checks that no piece is dropped at large magnitudes.
 static float* dev_random(size_t n, unsigned seed) {
+    static const int dist = getenv("DIST") ? atoi(getenv("DIST")) : 0;
     std::vector<float> h(n);
     unsigned s = seed * 2654435761u + 12345u;
-    for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+    for (size_t i = 0; i < n; ++i) {
+        s = s * 1664525u + 1013904223u;
+        float u = ((s >> 8) & 0xffff) / 65536.0f - 0.5f;
+        if (dist == 1) { s = s * 1664525u + 1013904223u; u = std::ldexp(u + (u < 0 ? -0.5f : 0.5f), (int)((s >> 10) % 61) - 30); }
+        else if (dist == 2) u *= 1e4f;
+        h[i] = u;
+    }
     float* d; CK(hipMalloc(&d, n * 4)); CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
     return d;
 }
