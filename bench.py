@@ -11,7 +11,14 @@ one full train call: token staging, forward, BPTT, clip_by_global_norm, Adam, gl
 skipped; the per-step loss stays in a device ring and is read back after the timed region).
 
 With N > 1 every rank trains on its own episode per step and one RCCL all-reduce sums the flat gradient
-buffer (weak scaling: per-GPU work fixed); value = N * K / max-over-ranks time.
+buffer (weak scaling: per-GPU work fixed); value = N * K / max-over-ranks time.  `python bench.py --gpus N` WITHOUT a
+torchrun environment starts its own N ranks (re-executes itself under torch.distributed.run on 127.0.0.1, rank r on GPU r)
+and prints rank 0's line; under torchrun (RANK / WORLD_SIZE set) it is one rank of the job.  For N > 1 the timed loop runs
+once per exchange schedule IN THE SAME RUN (`schedules`): "graph_end" (one graph per backward pass, the three gradient
+buckets reduced on the communication stream when it ends), "split_bucket0" (two graphs: bucket 0 = softmax gradients, 56 %
+of the bytes, is released behind the projection-gradient GEMMs and travels under BPTT) and "one_collective" (a single
+all-reduce on the compute stream); `value` is the fastest, `comm.exposed_ms` what each one adds to the same loop without
+any exchange.
 
 Prints ONE JSON line (rank 0, the LAST line of stdout).  `roofline` is the kernel BASELINE.json's north star sets a
 target for -- the fused LSTM cell (recurrent 4x GEMV on MFMA + gate nonlinearities + state update: k_lstm_fwd_xcd and
@@ -172,6 +179,44 @@ def cpu_baseline(cfg, pool, shape, budget_s=18.0):
                       'graph, best of %s; %.1f s)' % (n, ne, shape[0], shape[1], '/'.join(v['name'] for v in variants), dt + de)}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this script under torch.distributed.run (rank r -> GPU r,
+    rendezvous on 127.0.0.1), pass their output through and print rank 0's JSON line LAST."""
+    import socket
+    import subprocess
+    same_gpu = os.environ.get('FSMG_BENCH_SAME_GPU', '0') == '1'
+    if not same_gpu:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible (FSMG_BENCH_SAME_GPU=1 runs all ranks on GPU 0 over gloo: '
+                             'a dry run of the launcher, its numbers mean nothing)' % (args.gpus, have))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, _affinity() // max(args.gpus, 1))))
+    env['FSMG_BENCH_SELF_LAUNCHED'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('self-launch: %s' % ' '.join(cmd[1:]))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, universal_newlines=True, env=env)
+    lines = proc.stdout.splitlines()
+    result = None
+    for i in range(len(lines) - 1, -1, -1):
+        if lines[i].startswith('{"metric"'):
+            result = lines.pop(i)
+            break
+    for line in lines:
+        print(line)
+    if result is None:
+        raise SystemExit('bench.py --gpus %d: the ranks printed no result line (exit code %d)' % (args.gpus, proc.returncode))
+    sys.stdout.flush()
+    print(result)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -181,6 +226,8 @@ def main():
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--config', default='cfg-B', choices=['cfg-B', 'cfg-C', 'cfg-D', 'cfg-Bx4', 'cfg-Bx8', 'cfg-E'])
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -214,18 +261,24 @@ def main():
         from models.maml_lstm import MAMLLSTM as Model
     else:
         from models.lstm_baseline import LSTMBaseline as Model
-    model = Model(cfg)
-    model.recover_or_init('')
-    log('model ready')
-    par = EpisodeParallel(model)
-    eng = model.engine
     shape = (N_WAY, K_SHOT, Q_QUERY)
     kw = dict(maml=maml) if maml else {}
 
-    def step(i):
-        e = i % POOL
-        par.train_step(d_sup.data_ptr() + e * sup_stride, d_qry.data_ptr() + e * qry_stride,
-                       want_loss=False, shape=shape, **kw)
+    def make(env_over):
+        """a fresh model + its episode-parallel driver, created under the given environment overrides (the library and
+        fsmg.dist read their schedule knobs at creation)"""
+        saved = {k: os.environ.get(k) for k in env_over}
+        os.environ.update(env_over)
+        try:
+            m = Model(cfg)
+            m.recover_or_init('')
+            return m, EpisodeParallel(m)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
 
     def barrier():
         torch.cuda.synchronize()
@@ -233,42 +286,104 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step0 = eng.step
-    for i in range(args.warmup):
-        step(i)
-        if i == 0:
-            torch.cuda.synchronize()
-            log('first step done')
-    barrier()
-    step_before = eng.step
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    log('timed region done: %.3f s for %d steps' % (elapsed, args.steps))
-    # ---- guard: the timed region did the work it claims.  A step whose persistent kernel times out (or whose batch is
-    # rejected) is SKIPPED on the device -- no Adam, no global_step -- so a poisoned region would time no-ops.
-    step_after = eng.step
-    stats = eng.stats()
-    guard = {'global_step_before': step_before, 'global_step_after': step_after,
+    def timed(par_, eng_, tag):
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; returns this rank's
+        seconds and the guard that proves the region did the work it claims"""
+        def step_(i):
+            e = i % POOL
+            par_.train_step(d_sup.data_ptr() + e * sup_stride, d_qry.data_ptr() + e * qry_stride,
+                            want_loss=False, shape=shape, **kw)
+        step0 = eng_.step
+        for i in range(args.warmup):
+            step_(i)
+            if i == 0:
+                torch.cuda.synchronize()
+                log('%s: first step done' % tag)
+        barrier()
+        step_before = eng_.step
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step_(args.warmup + i)
+        barrier()
+        el = time.perf_counter() - t0
+        log('%s: timed region done: %.3f s for %d steps' % (tag, el, args.steps))
+        # ---- guard: a step whose persistent kernel times out (or whose batch is rejected) is SKIPPED on the device -- no Adam,
+        # no global_step -- so a poisoned region would time no-ops
+        step_after = eng_.step
+        stats = eng_.stats()
+        g = {'rank': rank, 'global_step_before': step_before, 'global_step_after': step_after,
              'advanced_by': step_after - step_before, 'expected': args.steps,
              'warmup_advanced_by': step_before - step0, 'timeouts': stats['timeouts'],
              'steps_skipped_timeout': stats['steps_skipped_timeout'], 'steps_skipped_token_range': stats['steps_skipped_token_range'],
-             'persistent_path': bool(stats['persistent_path']), 'xcd_local_kernels': stats['xcd_launches'] > 0,
+             'persistent_path': bool(stats['persistent_path']), 'fallback_steps_left': stats['fallback_steps_left'],
+             'xcd_local_kernels': stats['xcd_launches'] > 0,
              'ok': (step_after - step_before == args.steps and step_before - step0 == args.warmup and stats['timeouts'] == 0
                     and stats['steps_skipped_timeout'] == 0 and stats['steps_skipped_token_range'] == 0)}
-    local_elapsed = elapsed
-    per_rank = [elapsed]
-    if world > 1:
-        t = torch.tensor([elapsed, float(guard['ok'])], dtype=torch.float64, device='cuda')
-        gathered = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)
-        per_rank = [float(g[0].item()) for g in gathered]
-        guard['ok'] = all(bool(g[1].item()) for g in gathered)
-        elapsed = max(per_rank)
+        return el, g
+
+    # exchange schedules timed in this run (N > 1); a single GPU has nothing to exchange: one graph per step
+    if world == 1:
+        plans = [('single_gpu_one_graph', {})]
+    else:
+        plans = [('graph_end', {}), ('split_bucket0', {'FSMG_DP_SPLIT': '1'}), ('one_collective', {'FSMG_DP_BUCKETS': '0'})]
+        if os.environ.get('FSMG_BENCH_SCHEDULES'):
+            keep = os.environ['FSMG_BENCH_SCHEDULES'].split(',')
+            plans = [pl for pl in plans if pl[0] in keep] or plans[:1]
+    schedules, built = {}, {}
+    for name, env_over in plans:
+        m_, p_ = make(env_over)
+        el, g = timed(p_, m_.engine, name)
+        per = [el]
+        gs = [g]
+        if world > 1:
+            gs = [None] * world
+            dist.all_gather_object(gs, g)
+            per = [None] * world
+            dist.all_gather_object(per, el)
+        worst = max(per)
+        schedules[name] = {'value': world * args.steps / worst, 'ms_per_step': 1e3 * worst / max(args.steps, 1),
+                           'per_rank_ms_per_step': [1e3 * t / max(args.steps, 1) for t in per],
+                           'guard_ok': all(x['ok'] for x in gs), 'guard_per_rank': gs}
+        built[name] = (m_, p_, el)
+    ok_names = [n for n in schedules if schedules[n]['guard_ok']] or list(schedules)
+    used = min(ok_names, key=lambda n: schedules[n]['ms_per_step'])
+    model, par, local_elapsed = built[used]
+    for n in list(built):
+        if n != used:
+            del built[n]
+    eng = model.engine
+    elapsed = schedules[used]['ms_per_step'] * max(args.steps, 1) / 1e3
+    per_rank = [t * max(args.steps, 1) / 1e3 for t in schedules[used]['per_rank_ms_per_step']]
+    guard = dict(schedules[used]['guard_per_rank'][0])
+    guard['ok'] = schedules[used]['guard_ok']
     if not guard['ok']:
-        log('GUARD FAILED: %r' % guard)
+        log('GUARD FAILED: %r' % schedules[used]['guard_per_rank'])
+
+    def step(i):
+        e = i % POOL
+        par.train_step(d_sup.data_ptr() + e * sup_stride, d_qry.data_ptr() + e * qry_stride,
+                       want_loss=False, shape=shape, **kw)
+
+    world_info = None
+    without_exchange_ms = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(local)
+        mine = {'rank': rank, 'local_device': local, 'name': props.name, 'uuid': str(getattr(props, 'uuid', '')),
+                'pci_bus_id': getattr(props, 'pci_bus_id', None)}
+        devs = [None] * world
+        dist.all_gather_object(devs, mine)
+        world_info = {'size': dist.get_world_size(), 'backend': dist.get_backend(), 'devices': devs,
+                      'distinct_devices': len({(d['local_device'], d['uuid'], d['pci_bus_id']) for d in devs}),
+                      'launcher': 'bench.py self-launch' if os.environ.get('FSMG_BENCH_SELF_LAUNCHED') == '1' else 'torchrun',
+                      'same_gpu_dry_run': same_gpu}
+        # the same loop with NO exchange (replicas diverge: timing only, on its own model) -> what each schedule's exchange adds
+        m0, p0 = make({})
+        p0.exchange = False
+        el0, _ = timed(p0, m0.engine, 'no_exchange')
+        per0 = [None] * world
+        dist.all_gather_object(per0, el0)
+        without_exchange_ms = 1e3 * max(per0) / max(args.steps, 1)
+        del m0, p0
     # ---- roofline leg: the same K steps again with HIP events around every launch of the fused-cell kernels on the library's
     # stream, in the schedule of the timed region (event timing replaces the hipGraph replay by the same launches, eagerly)
     cell = {}
@@ -281,18 +396,25 @@ def main():
                 step(args.warmup + args.steps + i)
             cell[cls] = eng.timing_read(cls)
             eng.timing_enable(False)
-    # exposed communication (N > 1): time of the all-reduce leg = step time with the exchange minus without is not measurable
-    # in-process; the collectives are bracketed with events on the communication stream instead
+    # communication (N > 1): the all-reduce of the flat gradient buffer alone on the library's stream, and per schedule what the
+    # exchange adds to the same timed loop without any exchange (= the exposed, un-overlapped part)
     comm = None
     if world > 1:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with model.stream_context():
+            dist.all_reduce(model.grad_tensor, op=dist.ReduceOp.SUM)
             ev0.record()
             for _ in range(5):
                 dist.all_reduce(model.grad_tensor, op=dist.ReduceOp.SUM)
             ev1.record()
         torch.cuda.synchronize()
-        comm = {'allreduce_ms_standalone': ev0.elapsed_time(ev1) / 5, 'bytes': int(model.grad_tensor.numel() * 4)}
+        nbytes = int(model.grad_tensor.numel() * 4)
+        ar_ms = ev0.elapsed_time(ev1) / 5
+        comm = {'allreduce_ms_standalone': ar_ms, 'bytes': nbytes,
+                'allreduce_busbw_GBps': 2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9 if ar_ms > 0 else None,
+                'ms_per_step_without_exchange': without_exchange_ms,
+                'exposed_ms': {n: schedules[n]['ms_per_step'] - without_exchange_ms for n in schedules},
+                'note': 'exposed_ms = ms_per_step of the schedule minus the same K-step loop with the exchange switched off (timing only)'}
     losses = eng.read_losses(min(args.steps, 1024)) if args.steps > 0 else np.zeros(1)
 
     out = None
@@ -319,6 +441,9 @@ def main():
             'step_tflops': None if maml else total_gflop / (1e3 * elapsed / max(args.steps, 1)),
             'final_loss': float(losses[-1]), 'first_loss': float(losses[0]),
             'per_rank_ms_per_step': [1e3 * t / max(args.steps, 1) for t in per_rank], 'comm': comm,
+            'schedule_used': used,
+            'schedules': {n: {k: v for k, v in sc.items() if k != 'guard_per_rank'} for n, sc in schedules.items()},
+            'guard_per_rank': schedules[used]['guard_per_rank'], 'world': world_info,
         }
         if cell:
             T = cfg['max_len']

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
     __shared__ float s_scale, s_alpha;
     // the gradients of a step whose persistent recurrent kernel timed out are garbage, and a batch with an out-of-range
     // token is rejected as a whole (the reference would fail the feed): keep the parameters
-    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f) return;
+    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;
     for (int i = tid; i < a.n_partials; i += 256) s += a.partials[i];
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
 __global__ __launch_bounds__(256) void k_sgd_update(const UpdateArgs a) {
     __shared__ double sh[4];
     __shared__ float s_scale;
-    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f) return;
+    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;
     for (int i = tid; i < a.n_partials; i += 256) s += a.partials[i];
@@ -397,7 +397,8 @@ __global__ void k_step_increment(long long* step, const float* loss_src, float l
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int e = err_flag != nullptr ? *err_flag : 0;
     const bool peer_timeout = loss_src != nullptr && loss_src[1] != 0.0f;      // loss_src is tail[1]; tail[2] is the indicator
-    if (e != 0 || peer_timeout) {
+    const bool peer_token = loss_src != nullptr && loss_src[2] != 0.0f;        // tail[3]: some rank's batch held an out-of-range id
+    if (e != 0 || peer_timeout || peer_token) {
         if (counters != nullptr) {
             if (e == 2 || peer_timeout) counters[0] += 1; else counters[1] += 1;
             __threadfence_system();
@@ -412,7 +413,8 @@ __global__ void k_step_increment(long long* step, const float* loss_src, float l
     }
 }
 
-// flag_src != nullptr: also dst[2] = (*flag_src == 2) -- the "a persistent recurrent kernel timed out" indicator travels
+// flag_src != nullptr: also dst[2] = (*flag_src == 2), dst[3] = (*flag_src == 1) -- the "a persistent recurrent kernel timed out" /
+// "a token id was out of range" indicators travel
 // in the gradient tail, so after the all-reduce EVERY rank of an episode-parallel step knows that some rank's gradients
 // are garbage
 __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partials, int n, float* dst,
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
     __syncthreads();
     if (tid == 0) {
         dst[0] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
-        if (flag_src != nullptr) dst[2] = (*flag_src == 2) ? 1.0f : 0.0f;
+        if (flag_src != nullptr) { dst[2] = (*flag_src == 2) ? 1.0f : 0.0f; dst[3] = (*flag_src == 1) ? 1.0f : 0.0f; }
     }
 }
 

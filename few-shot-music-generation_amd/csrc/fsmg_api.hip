@@ -105,6 +105,9 @@ struct fsmg_model {
     // the h hand-off buffer, the dh-partial inboxes and the per-launch ticket counters
     bool xcd = true;                    // FSMG_XCD=0: keep the column-split persistent kernels
     int xcd_max_rows = 128;             // FSMG_XCD_MAX_ROWS: largest sequence count that takes the XCD-local kernels
+    bool dp_split = false;              // FSMG_DP_SPLIT=1: fsmg_forward_backward replays TWO graphs (forward + projection gradients | BPTT + the rest) and
+                                        // records bucket 0's readiness between them, so its all-reduce runs under the second one
+    int xcd_pipe = 0;                   // FSMG_XCD_PIPE=1: the round-3 variant of the XCD-local kernels (all-thread cell update; measured slower, kept for A/B)
     float* khx = nullptr;
     float* HX = nullptr; int64_t hx_floats = 0;
     float* inboxX = nullptr; int64_t inboxx_floats = 0;
@@ -147,6 +150,8 @@ struct fsmg_model {
     int64_t slab_cap = 0;
     // whole-phase hipGraphs, keyed by the shape of the call; dropped when scratch moves
     std::map<std::string, hipGraphExec_t> graphs;
+    struct LaunchCounts { int64_t xcd = 0, persist = 0, step = 0; };
+    std::map<std::string, LaunchCounts> graph_counts;   // recurrent launches one replay of a graph stands for (fsmg_get_stats)
     // decode
     float* dec = nullptr;
 
@@ -495,6 +500,7 @@ int ensure_scratch(fsmg_model* h, int B) {
 void drop_graphs(fsmg_model* h) {
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
     h->graphs.clear();
+    h->graph_counts.clear();
 }
 
 // A stream plus the split-K slab buffers its GEMMs may use.
@@ -539,10 +545,16 @@ int run_graphed(fsmg_model* h, const std::string& key, F&& body) {
     // schedule only overlaps with eager launches
     if (!h->cfg.use_graph || h->timing || h->ov_call || h->xov_call) return body();
     auto it = h->graphs.find(key);
+    if (it != h->graphs.end()) {           // a replay launches what the capture launched
+        const auto& c = h->graph_counts[key];
+        h->n_xcd_launches += c.xcd; h->n_persist_launches += c.persist; h->n_step_launches += c.step;
+    }
     if (it == h->graphs.end()) {
         hipGraph_t graph = nullptr;
+        const int64_t x0 = h->n_xcd_launches, p0 = h->n_persist_launches, s0 = h->n_step_launches;
         HIPCK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         const int rc = body();
+        { auto& c = h->graph_counts[key]; c.xcd = h->n_xcd_launches - x0; c.persist = h->n_persist_launches - p0; c.step = h->n_step_launches - s0; }
         const hipError_t e = hipStreamEndCapture(h->stream, &graph);
         if (rc != FSMG_OK) { if (graph) hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess || graph == nullptr)
@@ -780,7 +792,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             if (xcd) {
                 ScopedTimer tm(h, "lstm_fwd");
                 LstmFwdXcdArgs a{};
-                a.rpx = rpx;
+                a.rpx = rpx; a.pipe = h->xcd_pipe;
                 a.KhX = h->khx + (size_t)(2 * l) * Hp * G4; a.HX = h->HX; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
                 a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_fwd_xcd(s, a));
@@ -867,8 +879,11 @@ int dw_gemm(fsmg_model* h, const Lane& ln, int B) {
     return gemm(h, ln, OP_XC, OP_XC, dw_args(h, B));
 }
 
-int backward(fsmg_model* h, int B) {
-    ScopedRange rng_("fsmg.backward");
+// part 0: the whole pass; part 1: up to and including the projection gradients (dH, dW, dd: bucket 0 of the gradient exchange
+// is final behind it); part 2: the rest.  Only the single-stream order can be cut there: the two-stream and the XCD-partitioned
+// orders run everything in part 1 (they record bucket 0 themselves) and nothing in part 2.
+int backward(fsmg_model* h, int B, int part = 0) {
+    ScopedRange rng_(part == 2 ? "fsmg.backward(2)" : "fsmg.backward");
     const int T = h->T, Hp = h->Hp, G4 = h->G4;
     const int64_t rows = (int64_t)T * B;
     const Lane mainl = main_lane(h);
@@ -891,11 +906,14 @@ int backward(fsmg_model* h, int B) {
     }
     const bool xov = h->xov_call && xcd && !ov && xov_fits(gdw);
     const int rpx = xov ? lstm_xcd_packed_rows(B) : 0;
+    const bool cut = !ov && !xov;           // the order that can be cut behind the projection gradients
+    if (part == 2 && !cut) return FSMG_OK;
     PHASE(3);
     FillBatch fills(h);                     // embedding-gradient zero + the top layer's BPTT buffers: one launch
-    GEMMCK(fills.add(h->G + h->off_emb, 0u, (long long)h->V1 * h->Ep));
+    if (part != 2) GEMMCK(fills.add(h->G + h->off_emb, 0u, (long long)h->V1 * h->Ep));
     if (ov) GEMMCK(fills.flush());          // (two-stream order: the auxiliary stream forks right below)
-    if (ov) {
+    if (part == 2) {
+    } else if (ov) {
         // aux: dH chunks in the order BPTT consumes them (last chunk first), then dW
         HIPCK(h, hipEventRecord(h->ev_fork, s));
         HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
@@ -923,6 +941,7 @@ int backward(fsmg_model* h, int B) {
         GEMMCK(dhout_chunk(h, mainl, B, 0, T));
         GEMMCK(dw_gemm(h, mainl, B));
     }
+    if (part == 1 && cut) return fills.flush();
     for (int l = h->L - 1; l >= 0; --l) {
         const bool top = l == h->L - 1;
         GEMMCK(fills.add(h->dC, 0u, (long long)B * Hp));
@@ -945,7 +964,7 @@ int backward(fsmg_model* h, int B) {
             ScopedTimer tm(h, "lstm_bwd");
             if (xcd) {
                 LstmBwdXcdArgs a{};
-                a.rpx = rpx;
+                a.rpx = rpx; a.pipe = h->xcd_pipe;
                 a.KhXb = h->khx + (size_t)(2 * l + 1) * Hp * G4; a.inbox = h->inboxX; a.Z = h->Z[l]; a.Cs = h->Cs[l];
                 a.dc = h->dC; a.dH = h->dH; a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_bwd_xcd(s, a));
@@ -1027,7 +1046,7 @@ int backward(fsmg_model* h, int B) {
         HIPCK(h, launch_embed_grad(s, h->X, (int)rows, h->dXemb, h->Ep, h->G + h->off_emb));
         const int nb = sqnorm_blocks(rows * h->Ep);
         HIPCK(h, launch_sqnorm_partials(s, h->dXemb, rows * h->Ep, h->partials));
-        HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0, h->d_err));   // + tail[2] = time-out indicator
+        HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0, h->d_err));   // + tail[2] / tail[3] = time-out / token-range indicators
     }
     if (ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));     // dW / dd landed
     PHASE(6);
@@ -1103,7 +1122,14 @@ int restore_theta(fsmg_model* h) {
 void on_timeout(fsmg_model* h) {
     ++h->n_timeouts;
     h->persist_timed_out = true;
-    if (h->persist) { h->persist = false; drop_graphs(h); }
+    if (h->persist) {
+        // reached from the asynchronous path too (after_update with loss == NULL polls the host-mapped tallies): later replays
+        // of the same execs may still be queued or running, so drain both streams before the execs are destroyed
+        h->persist = false;
+        hipStreamSynchronize(h->stream);
+        if (h->aux) hipStreamSynchronize(h->aux);
+        drop_graphs(h);
+    }
     h->fallback_left = h->fallback_steps;
 }
 
@@ -1180,13 +1206,28 @@ int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&
     if ((rc = stage()) != FSMG_OK) return rc;
     const int n_sup = N * K, n_qry = N * Q;
     h->bucket0_recorded = false;
-    rc = run_graphed(h, (with_update ? "fbu:" : "fb:") + std::to_string(n_sup) + ":" + std::to_string(n_qry), [&]() -> int {
-        int r = token_prep(h, n_sup, n_qry);
-        if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1, true);
-        if (r == FSMG_OK) r = backward(h, B);
-        if (r == FSMG_OK && with_update) r = apply_update(h, 1.0f);
-        return r;
-    });
+    const std::string shape_key = std::to_string(n_sup) + ":" + std::to_string(n_qry);
+    if (h->dp_split && !with_update) {
+        // episode-parallel order: bucket 0 (softmax gradients, 56 % of the bytes at cfg-B) is final when the first graph ends and
+        // travels while the second one (BPTT, weight / input gradients, embedding gradient) runs
+        rc = run_graphed(h, "fb1:" + shape_key, [&]() -> int {
+            int r = token_prep(h, n_sup, n_qry);
+            if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1, true);
+            if (r == FSMG_OK) r = backward(h, B, 1);
+            return r;
+        });
+        if (rc != FSMG_OK) return rc;
+        if (!h->bucket0_recorded) { HIPCK(h, hipEventRecord(h->ev_bucket[0], h->stream)); h->bucket0_recorded = true; }
+        rc = run_graphed(h, "fb2:" + shape_key, [&]() -> int { return backward(h, B, 2); });
+    } else {
+        rc = run_graphed(h, (with_update ? "fbu:" : "fb:") + shape_key, [&]() -> int {
+            int r = token_prep(h, n_sup, n_qry);
+            if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1, true);
+            if (r == FSMG_OK) r = backward(h, B);
+            if (r == FSMG_OK && with_update) r = apply_update(h, 1.0f);
+            return r;
+        });
+    }
     if (rc != FSMG_OK) return rc;
     // bucket readiness for an overlapped gradient exchange: with the two-stream (eager) schedule bucket 0 was
     // recorded right behind the dW GEMM on the aux stream; a replayed graph finishes as a whole
@@ -1288,6 +1329,8 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_FALLBACK_STEPS")) h->fallback_steps = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("FSMG_BWD_RS")) h->bwd_rs = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XCD")) h->xcd = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_DP_SPLIT")) h->dp_split = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_XCD_PIPE")) h->xcd_pipe = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XCD_MAX_ROWS")) h->xcd_max_rows = std::max(1, std::min(128, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_PERSIST_FWD")) h->persist_fwd = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_FWD_RT")) h->force_fwd_rt = (e[0] != '0');

@@ -157,6 +157,8 @@ struct LstmFwdXcdArgs {
     int spin_limit;
     unsigned long long* prof;   // != nullptr: instrumented build, [256 blocks][4 waves][8] tick sums per phase (RG = 2 only)
     int rpx;                    // rows per XCD; 0 = ceil(B / 8).  lstm_xcd_packed_rows(B) packs the batch on the first XCDs
+    int pipe;                   // 1: two-chain software-pipelined kernel (>= 2 row groups per XCD), 0: one chain per XCD (round 2)
+    int dbg;                    // timing experiments only (WRONG results): 1 = no output stores / input loads, 2 = fragments taken as ready
 };
 struct LstmBwdXcdArgs {
     const float* KhXb;    // backward register image of K_h
@@ -171,6 +173,8 @@ struct LstmBwdXcdArgs {
     int spin_limit;
     unsigned long long* prof;
     int rpx;              // as LstmFwdXcdArgs
+    int pipe;             // as LstmFwdXcdArgs (the inbox is laid out per chain then: see k_lstm_bwd_xcd2)
+    int dbg;              // as LstmFwdXcdArgs
 };
 bool lstm_xcd_supported(int B, int Hp);
 long long lstm_xcd_hx_floats(int B, int T);
@@ -212,7 +216,7 @@ hipError_t launch_sqnorm_partials(hipStream_t s, const float* x, long long n, do
 struct UpdateArgs {
     float* p; float* m; float* v; const float* g; long long n;   // flat buffers
     const double* partials; int n_partials;       // squared-norm partials of everything that counts
-    const float* tail;                            // grad tail scalars (tail[0] = slices_sq, used when slices; tail[2] != 0: no update)
+    const float* tail;                            // grad tail scalars (tail[0] = slices_sq, used when slices; tail[2] / tail[3] != 0: no update)
     int use_slices;                               // add tail[0]*grad_scale^2 to the norm
     float grad_scale;                             // 1/world (g is a SUM over ranks)
     float lr, n_decay, clip;

@@ -38,6 +38,7 @@ class EpisodeParallel(object):
         self.bucketed = os.environ.get('FSMG_DP_BUCKETS', '1') != '0'      # 0: one all-reduce after backward
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.exchange = True            # False: skip the gradient exchange (bench.py's "what does the exchange cost" leg; replicas diverge)
 
     def broadcast_parameters(self, tensor):
         """One-time parameter / optimiser-state broadcast from rank 0 (after init or restore)."""
@@ -72,7 +73,9 @@ class EpisodeParallel(object):
         else:
             self.engine.forward_backward(support, query, **kw)
         buckets = getattr(self.engine, 'grad_buckets', None)
-        if self.world > 1 and buckets is not None and self.bucketed:
+        if not self.exchange:
+            pass
+        elif self.world > 1 and buckets is not None and self.bucketed:
             # overlapped exchange: each bucket is reduced on the communication stream as soon as it is final
             # (bucket 0 = softmax gradients, ready while BPTT / the weight-gradient GEMMs still run)
             works = []

@@ -75,6 +75,16 @@ class LSTMBaseline(HIPModel):
         """the last n (<= 1024) train losses, oldest first; synchronises"""
         return self._model.read_losses(int(n))
 
+    def global_step(self):
+        """train steps the device has really applied (a skipped step does not count); synchronises"""
+        return self._model.step
+
+    def log_deferred_losses(self, losses):
+        """Train/loss scalars of steps that ran with want_loss=False, written when train.train folds them in"""
+        first = self._train_calls - len(losses)
+        for i, loss in enumerate(losses):
+            self._log_scalar('Train/loss', float(loss), max(first + i, 0))
+
     def eval(self, episode):
         self._require_init()
         nll = self._model.eval_step(self._tokens(episode.query, 3))

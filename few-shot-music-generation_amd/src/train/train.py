@@ -114,10 +114,16 @@ def main(argv=None):
     model.recover_or_init(args.init_dir)
 
     def validate(split, n):
-        per_rank = max(1, n // world)
-        nll = evaluate(model, episode_sampler[split], per_rank)
+        # the n episodes are dealt round-robin to the ranks: rank r takes ceil((n - r) / world) of them, every rank contributes the
+        # SUM of its NLLs and its count, so the mean is over exactly n episodes whatever n % world is
+        mine = (n - rank + world - 1) // world if world > 1 else n
+        nll = evaluate(model, episode_sampler[split], mine) if mine > 0 else 0.0
+        if world > 1 and mine < (n + world - 1) // world:
+            episode_sampler[split].next_indices()          # keep every rank's copy of the stream at the same position
         parallel = getattr(model, '_parallel', None)
-        return parallel.mean_scalar(nll) if (world > 1 and parallel) else nll
+        if world > 1 and parallel:
+            return parallel.mean_scalar(nll * mine) * world / n
+        return nll
 
     say('Iter: %d, val-nll: %.3e' % (0, validate('val', n_val)))
 
@@ -125,18 +131,37 @@ def main(argv=None):
     # N*(K+Q) row indices, and the per-step loss stays in the device's ring until the next log line needs the window's
     # mean -- the reference's loop (train.py:83-98) pays a blocking device->host read per step for `avg_loss +=`.
     train_sampler = episode_sampler['train']
-    fast = (hasattr(model, 'attach_table') and hasattr(model, 'train_indexed') and hasattr(train_sampler, 'next_indices')
-            and os.environ.get('FSMG_TRAIN_SYNC', '0') == '0')
+    fast = (hasattr(model, 'attach_table') and hasattr(model, 'train_indexed') and hasattr(model, 'recent_losses')
+            and hasattr(train_sampler, 'next_indices') and os.environ.get('FSMG_TRAIN_SYNC', '0') == '0')
     if fast:
         model.attach_table('train', train_sampler.token_table())
     RING = 1024
-    avg_loss, pending = 0., 0
+    avg_loss, pending, counted, skipped_total = 0., 0, 0, 0
+    step_mark = model.global_step() if (fast and hasattr(model, 'global_step')) else None
 
     def drain():                                   # fold the losses still on the device into avg_loss
-        nonlocal avg_loss, pending
-        if pending:
-            avg_loss += float(sum(model.recent_losses(pending)))
-            pending = 0
+        nonlocal avg_loss, pending, counted, skipped_total, step_mark
+        if not pending:
+            return
+        # A step whose persistent kernel timed out (own or a peer rank's) or whose batch held a bad token is SKIPPED on the
+        # device: no ring slot, no global_step.  Only the steps that really ran have a loss to read; the others are counted
+        # and reported instead of being filled in with stale ring entries.
+        done = pending
+        if step_mark is not None:
+            now = model.global_step()
+            done = max(0, min(pending, now - step_mark))
+            step_mark = now
+        if done:
+            losses = model.recent_losses(done)
+            avg_loss += float(sum(losses))
+            counted += done
+            if hasattr(model, 'log_deferred_losses'):
+                model.log_deferred_losses(losses)
+        if done < pending:
+            skipped_total += pending - done
+            say('warning: %d train episode(s) were skipped on the device (persistent-kernel time-out or token-range error); '
+                '%d so far' % (pending - done, skipped_total))
+        pending = 0
 
     for i in range(1, n_train + 1):
         if fast:
@@ -146,6 +171,7 @@ def main(argv=None):
                 drain()
         else:
             avg_loss += model.train(train_sampler.get_episode())
+            counted += 1
 
         if i % val_every_n == 0:            # val_every_n may be a float (Q11)
             drain()
@@ -155,8 +181,9 @@ def main(argv=None):
 
         if i % print_every_n == 0:
             drain()
-            say('Iter: %d, loss: %.3e' % (i, avg_loss / print_every_n))
-            avg_loss = 0.
+            # mean over the steps of this window that ran (= print_every_n unless the device skipped some)
+            say('Iter: %d, loss: %.3e' % (i, avg_loss / max(counted, 1)))
+            avg_loss, counted = 0., 0
 
     say('Train Avg NLL: %.3e' % validate('train', n_test))
     say('Validation Avg NLL: %.3e' % validate('val', n_test))

@@ -124,7 +124,9 @@ int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* 
  * are scalars that must be reduced with it: [0] = sum of squared embedding-slice gradients,
  * [1] = loss, [2] = non-zero when a persistent recurrent kernel of this rank timed out (its gradients are garbage):
  * fsmg_apply_update then leaves parameters, Adam state and step counter alone on every rank and, when it reads the
- * loss back, returns FSMG_ERR_HIP after switching the handle to one launch per time step -- repeat the step */
+ * loss back, returns FSMG_ERR_HIP after switching the handle to one launch per time step -- repeat the step;
+ * [3] = non-zero when this rank's batch held a token id outside [0, input_size): summed like [2], so EVERY rank skips the
+ * update (replicas stay identical) and every rank's read-back returns FSMG_ERR_TOKEN_RANGE */
 #define FSMG_GRAD_TAIL 16
 int fsmg_grad_buffer(fsmg_handle h, void** device_ptr, int64_t* count);
 int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss);

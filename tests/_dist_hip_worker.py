@@ -77,7 +77,8 @@ def main():
                 # Adam's first steps are sign-like (m / sqrt(v)): a 1e-7 difference in a tiny gradient (another summation
                 # order: 2 x 15 rows vs 30 rows pick different kernels) moves a weight by a fraction of lr
                 assert np.abs(got[k] - v).max() <= 2e-4 * max(np.abs(v).max(), 1e-6), k
-        print('DIST_HIP_OK world=%d hidden=%d maml=%d' % (world, hidden, maml))
+        print('DIST_HIP_OK world=%d hidden=%d maml=%d backend=%s devices=%d' % (world, hidden, maml, dist.get_backend(),
+                                                                                  1 if same_gpu else world))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,0 +1,51 @@
+"""bench.py as the driver starts it: `python bench.py --gpus N ...` with NO torchrun environment must start its own N ranks
+(VERDICT r02 next #1).  The GPU test is a dry run of that launcher on ONE GPU (FSMG_BENCH_SAME_GPU=1: all ranks on GPU 0, gloo
+instead of RCCL -- its numbers mean nothing, its structure is what the 8-GPU run will print)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(extra)
+    return env
+
+
+def test_bench_refuses_more_ranks_than_gpus_with_a_clear_message():
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('needs a box with fewer than 2 GPUs')
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300, env=_clean_env())
+    assert proc.returncode != 0
+    assert 'GPU(s) visible' in proc.stderr and 'FSMG_BENCH_SAME_GPU' in proc.stderr, proc.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_and_reports_every_schedule():
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                           '--no-cpu-baseline', '--no-breakdown'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          universal_newlines=True, timeout=900, env=_clean_env(FSMG_BENCH_SAME_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert proc.returncode == 0, (proc.stdout[-2000:], proc.stderr[-4000:])
+    last = proc.stdout.strip().splitlines()[-1]
+    out = json.loads(last)                                  # ONE JSON line, the last line of stdout
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    assert out['world']['size'] == 2 and out['world']['launcher'] == 'bench.py self-launch'
+    assert out['world']['backend'] == 'gloo' and out['world']['same_gpu_dry_run'] is True
+    assert [d['rank'] for d in out['world']['devices']] == [0, 1]
+    assert set(out['schedules']) == {'graph_end', 'split_bucket0', 'one_collective'}
+    assert out['schedule_used'] in out['schedules']
+    best = min(v['ms_per_step'] for k, v in out['schedules'].items() if v['guard_ok'] or not any(s['guard_ok'] for s in out['schedules'].values()))
+    assert abs(out['ms_per_step'] - best) < 1e-9
+    assert abs(out['value'] - 2 * 3 / (out['ms_per_step'] * 3e-3)) < 1e-6 * out['value']
+    assert len(out['guard_per_rank']) == 2 and {g['rank'] for g in out['guard_per_rank']} == {0, 1}
+    for g in out['guard_per_rank']:                         # two processes time-slicing one GPU may time out and recover: report, not hide
+        assert g['expected'] == 3 and 'timeouts' in g and 'fallback_steps_left' in g
+    assert set(out['comm']['exposed_ms']) == set(out['schedules']) and out['comm']['ms_per_step_without_exchange'] > 0
+    assert out['comm']['bytes'] > 0 and out['comm']['allreduce_ms_standalone'] > 0

@@ -23,7 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize('hidden,maml', [(48, 0), (512, 0), (48, 1)])
-def test_two_ranks_on_the_hip_engine_equal_one_rank_on_the_concatenated_batch(hidden, maml):
+def test_two_ranks_on_the_hip_engine_equal_one_rank_on_the_concatenated_batch(hidden, maml, record_property):
+    import re
+    import warnings
     import torch
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     if torch.cuda.device_count() < 2:
@@ -35,6 +37,16 @@ def test_two_ranks_on_the_hip_engine_equal_one_rank_on_the_concatenated_batch(hi
            '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dist_hip_worker.py'), str(hidden), str(maml)]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600, env=env)
     assert proc.returncode == 0 and 'DIST_HIP_OK' in proc.stdout, proc.stdout[-4000:]
+    # say which transport carried the exchange: a 1-GPU box cannot run RCCL with two ranks, and a green test must not read as
+    # "RCCL verified" there
+    m = re.search(r'backend=(\w+) devices=(\d+)', proc.stdout)
+    backend, ndev = (m.group(1), int(m.group(2))) if m else ('?', 0)
+    record_property('exchange_backend', backend)
+    record_property('distinct_gpus', ndev)
+    print('episode-parallel HIP test ran over backend=%s on %d GPU(s)' % (backend, ndev))
+    if backend != 'nccl':
+        warnings.warn('2-rank HIP-engine test exchanged gradients over %s on ONE GPU: RCCL (backend nccl) was NOT exercised '
+                      '(needs >= 2 visible GPUs)' % backend)
 
 
 def test_train_steps_beside_a_cu_hogging_workload_keep_their_numbers():

@@ -240,7 +240,8 @@ struct Dev {
     float *Kh, *KhXf, *KhXb, *KhF, *HX, *inboxX, *Z, *Zsave, *Cs, *Hs, *dC, *dH, *HF, *inbox; int *tickets, *err;
 };
 
-static int run_case(int B, int Tcheck, int Ttime) {
+static int g_variant = 0;
+static int run_case(int B, int Tcheck, int Ttime, int pipe) {
     const int H = 512, G4 = 2048;
     Problem p; p.B = B; p.T = Tcheck;
     std::mt19937 rng(1234 + B);
@@ -283,7 +284,7 @@ static int run_case(int B, int Tcheck, int Ttime) {
         for (int c = 0; c < nchunk; ++c) {
             LstmFwdXcdArgs a{};
             a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18;
+            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.pipe = pipe; a.dbg = pipe ? 0 : g_variant;
             CK(launch_lstm_fwd_xcd(s, a));
         }
     };
@@ -294,7 +295,7 @@ static int run_case(int B, int Tcheck, int Ttime) {
         for (int c = nchunk - 1; c >= 0; --c) {
             LstmBwdXcdArgs a{};
             a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18;
+            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.pipe = pipe; a.dbg = pipe ? 0 : g_variant;
             CK(launch_lstm_bwd_xcd(s, a));
         }
     };
@@ -310,7 +311,7 @@ static int run_case(int B, int Tcheck, int Ttime) {
         CK(hipMemcpy(g.data(), d.Z, g.size() * 4, hipMemcpyDeviceToHost));
         const double eh = relmax(hs.data(), p.hs.data(), hs.size()), ec = relmax(cs.data(), p.cs.data(), cs.size()), eg = relmax(g.data(), p.gates.data(), g.size());
         const bool ok = e == 0 && eh < 2e-5 && ec < 2e-5 && eg < 2e-5;
-        printf("[4] B=%d fwd_xcd  vs CPU fp64 (T=%d, 2 launches): err_flag %d, h %.2e c %.2e gates %.2e  %s\n", B, T, e, eh, ec, eg, ok ? "ok" : "FAIL");
+        printf("[4] B=%d pipe=%d fwd_xcd  vs CPU fp64 (T=%d, 2 launches): err_flag %d, h %.2e c %.2e gates %.2e  %s\n", B, pipe, T, e, eh, ec, eg, ok ? "ok" : "FAIL");
         rc += !ok;
         // backward on the GPU's own forward state
         bwd_xcd(T, 2);
@@ -319,7 +320,7 @@ static int run_case(int B, int Tcheck, int Ttime) {
         CK(hipMemcpy(dz.data(), d.Z, dz.size() * 4, hipMemcpyDeviceToHost));
         const double ed = relmax(dz.data(), p.dz.data(), dz.size());
         const bool okb = e == 0 && ed < 1e-4;
-        printf("[4] B=%d bwd_xcd  vs CPU fp64 (T=%d, 2 launches): err_flag %d, dz %.2e  %s\n", B, T, e, ed, okb ? "ok" : "FAIL");
+        printf("[4] B=%d pipe=%d bwd_xcd  vs CPU fp64 (T=%d, 2 launches): err_flag %d, dz %.2e  %s\n", B, pipe, T, e, ed, okb ? "ok" : "FAIL");
         rc += !okb;
         CK(hipMemset(d.err, 0, 4));
     }
@@ -336,7 +337,7 @@ static int run_case(int B, int Tcheck, int Ttime) {
                 for (int c = 0; c < nchunk; ++c) {
                     LstmFwdXcdArgs a{};
                     a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18;
+                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.pipe = pipe; a.dbg = pipe ? 0 : g_variant;
                     CK(launch_lstm_fwd_xcd(s, a));
                 }
                 CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
@@ -346,17 +347,61 @@ static int run_case(int B, int Tcheck, int Ttime) {
                 for (int c = nchunk - 1; c >= 0; --c) {
                     LstmBwdXcdArgs a{};
                     a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18;
+                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.pipe = pipe; a.dbg = pipe ? 0 : g_variant;
                     CK(launch_lstm_bwd_xcd(s, a));
                 }
                 CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                 CK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
             }
             const int e = read_err();
-            printf("[4] B=%d xcd-local, %d launch(es) per chain, T=%d: fwd %.3f ms = %.2f us/step = %.1f TFLOP/s (%.1f%% of 157.3) | bwd %.3f ms = %.2f us/step = %.1f TFLOP/s (%.1f%%)  err_flag %d\n",
-                   B, nchunk, T, best_f, best_f * 1e3 / T, mflop * T / best_f / 1e6, mflop * T / best_f / 1e6 / 157.3 * 100, best_b, best_b * 1e3 / T,
+            printf("[4] B=%d pipe=%d xcd-local, %d launch(es) per chain, T=%d: fwd %.3f ms = %.2f us/step = %.1f TFLOP/s (%.1f%% of 157.3) | bwd %.3f ms = %.2f us/step = %.1f TFLOP/s (%.1f%%)  err_flag %d\n",
+                   B, pipe, nchunk, T, best_f, best_f * 1e3 / T, mflop * T / best_f / 1e6, mflop * T / best_f / 1e6 / 157.3 * 100, best_b, best_b * 1e3 / T,
                    mflop * T / best_b / 1e6, mflop * T / best_b / 1e6 / 157.3 * 100, e);
             CK(hipMemset(d.err, 0, 4));
+        }
+        if (pipe == 0) {     // variants of the round-2 kernels (correct results): 16 = outputs deferred behind the next poll / dz stores behind the drain, 32 = no sleep between polls
+            for (int dbg : {16, 32, 48}) {
+                float best_f = 1e9f, best_b = 1e9f;
+                for (int rep = 0; rep < 5; ++rep) {
+                    fwd_xcd(T, 0);
+                    CK(hipEventRecord(e0, s));
+                    { LstmFwdXcdArgs a{}; a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.pipe = 0; a.dbg = dbg; CK(launch_lstm_fwd_xcd(s, a)); }
+                    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best_f = std::min(best_f, ms);
+                    bwd_xcd(T, 0);
+                    CK(hipEventRecord(e0, s));
+                    { LstmBwdXcdArgs a{}; a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.pipe = 0; a.dbg = dbg; CK(launch_lstm_bwd_xcd(s, a)); }
+                    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+                    CK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
+                }
+                printf("[4] B=%d pipe=0 variant %d (%s%s): fwd %.2f us/step | bwd %.2f us/step  err_flag %d\n", B, dbg, (dbg & 16) ? "deferred stores " : "", (dbg & 32) ? "no poll sleep" : "",
+                       best_f * 1e3 / T, best_b * 1e3 / T, read_err());
+                CK(hipMemset(d.err, 0, 4));
+            }
+        }
+        if (pipe == 1) {     // timing-only decomposition (results are wrong by construction): 1 = no output stores / input loads, 2 = fragments taken as ready
+            for (int dbg : {1, 2, 3}) {
+                float best_f = 1e9f, best_b = 1e9f;
+                for (int rep = 0; rep < 4; ++rep) {
+                    fwd_xcd(T, 0);
+                    CK(hipEventRecord(e0, s));
+                    { LstmFwdXcdArgs a{}; a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.pipe = 1; a.dbg = dbg; CK(launch_lstm_fwd_xcd(s, a)); }
+                    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best_f = std::min(best_f, ms);
+                    bwd_xcd(T, 0);
+                    CK(hipEventRecord(e0, s));
+                    { LstmBwdXcdArgs a{}; a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.pipe = 1; a.dbg = dbg; CK(launch_lstm_bwd_xcd(s, a)); }
+                    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+                    CK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
+                }
+                printf("[4] B=%d pipe=1 dbg=%d (%s%s): fwd %.2f us/step | bwd %.2f us/step  err_flag %d\n", B, dbg, (dbg & 1) ? "no slow traffic " : "", (dbg & 2) ? "no readiness wait" : "",
+                       best_f * 1e3 / T, best_b * 1e3 / T, read_err());
+                CK(hipMemset(d.err, 0, 4));
+            }
         }
         if (B == 45) {       // phase profile of the instrumented build (RG = 2)
             unsigned long long* prof; CK(hipMalloc(&prof, 8ull * 256 * 4 * 8));
@@ -367,23 +412,27 @@ static int run_case(int B, int Tcheck, int Ttime) {
                     fwd_xcd(T, 0);
                     LstmFwdXcdArgs a{};
                     a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.pipe = pipe;
                     CK(launch_lstm_fwd_xcd(s, a));
                 } else {
                     bwd_xcd(T, 0);
                     LstmBwdXcdArgs a{};
                     a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.pipe = pipe;
                     CK(launch_lstm_bwd_xcd(s, a));
                 }
                 CK(hipStreamSynchronize(s));
                 CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
-                const char* names_f[5] = {"wait h_t", "MFMA", "LDS+barrier", "cell->store", "rest"};
-                const char* names_b[5] = {"wait inbox", "psum+barrier", "cell+dzA+barrier", "LDS read+MFMA", "drain+stores+rest"};
+                const char* names_f0[5] = {"wait h_t", "MFMA", "LDS+barrier", "cell->store", "rest"};
+                const char* names_b0[5] = {"wait inbox", "psum+barrier", "cell+dzA+barrier", "LDS read+MFMA", "drain+stores+rest"};
+                const char* names_f1[5] = {"wait h_t", "outputs+x-part issue+MFMA", "LDS+barrier", "cell->store", "loop"};
+                const char* names_b1[5] = {"wait inbox", "resets+psum+barrier", "gate grads+barrier", "dz stores+input loads+MFMA", "publish+loop"};
+                const char** names_f = pipe ? names_f1 : names_f0;
+                const char** names_b = pipe ? names_b1 : names_b0;
                 for (int wc = 0; wc < 2; ++wc) {        // cell waves (0,1) vs the others (2,3)
                     double m[5] = {0, 0, 0, 0, 0};
                     for (int b = 0; b < 256; ++b) for (int w = 2 * wc; w < 2 * wc + 2; ++w) for (int i = 0; i < 5; ++i) m[i] += (double)hp[((size_t)b * 4 + w) * 8 + i];
-                    printf("[4] %s phase ticks per step, waves %d-%d:", dir ? "bwd" : "fwd", 2 * wc, 2 * wc + 1);
+                    printf("[4] pipe=%d %s phase ticks per step, waves %d-%d:", pipe, dir ? "bwd" : "fwd", 2 * wc, 2 * wc + 1);
                     double tot = 0;
                     for (int i = 0; i < 5; ++i) { printf("  %s %.0f", dir ? names_b[i] : names_f[i], m[i] / 512 / T); tot += m[i] / 512 / T; }
                     printf("  | total %.0f\n", tot);
@@ -392,7 +441,7 @@ static int run_case(int B, int Tcheck, int Ttime) {
             hipFree(prof);
             CK(hipMemset(d.err, 0, 4));
         }
-        if (lstm_fwd_chain_supported(B, H)) {
+        if (pipe == 0 && lstm_fwd_chain_supported(B, H)) {
             float best_f = 1e9f, best_b = 1e9f;
             for (int rep = 0; rep < 6; ++rep) {
                 CK(hipMemcpyAsync(d.Z, Zin.data(), 4ull * T * B * G4, hipMemcpyHostToDevice, s));
@@ -429,9 +478,14 @@ int main(int argc, char** argv) {
     }
     handoff_probe();
     if (rc) { printf("MFMA layout assumption wrong: kernels not run\n"); return 1; }
-    rc += run_case(45, 6, 128);
-    rc += run_case(100, 4, 128);
-    rc += run_case(20, 4, 128);
+    const int only_pipe = getenv("PIPE") ? atoi(getenv("PIPE")) : -1;
+    g_variant = getenv("VARIANT") ? atoi(getenv("VARIANT")) : 0;
+    for (int pipe = 0; pipe < 2; ++pipe) {
+        if (only_pipe >= 0 && pipe != only_pipe) continue;
+        rc += run_case(45, pipe ? 17 : 6, 128, pipe);
+        rc += run_case(100, pipe ? 9 : 4, 128, pipe);
+        rc += run_case(20, pipe ? 9 : 4, 128, pipe);
+    }
     printf(rc ? "FAILED\n" : "ALL OK\n");
     return rc;
 }
