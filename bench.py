@@ -84,14 +84,20 @@ def synthetic_episodes(n_episodes, N, K, Q, T, vocab, seed):
 
 
 def hbm_traffic():
-    """HBM bytes per launch of the fused-cell kernels from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
-    correction + WRITE_SIZE; profiles/r02_lstm_cell_pmc.json, written by tools/refresh_profiles.sh) -- PMC counters cannot
-    be read from inside this process, so this is the recorded figure of the same kernels on the same workload, or None"""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_lstm_cell_pmc.json')) as f:
-            return json.load(f)['traffic_bytes_per_launch']
-    except Exception:
-        return None
+    """(bytes, source): HBM bytes per launch of the fused-cell kernels as RECORDED by the committed rocprofv3 PMC passes
+    (tools/refresh_profiles.sh: raw FETCH_SIZE + WRITE_SIZE, separate passes) -- counters cannot be read from inside this
+    process, so this is not a measurement of this run.  No x2 on FETCH_SIZE: the guide's gfx950 correction is calibrated for
+    16-B/lane streaming loads, and these kernels' raw FETCH_SIZE (47.7 MB forward) already equals their algorithmic read
+    (Z: 47.2 MB).  (None, None) when no record exists."""
+    for name in ('r03_lstm_cell_pmc.json', 'r02_lstm_cell_pmc.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                rec = json.load(f)
+            per = {k: rec['fetch_size_kb'][k] * 1024 + rec['write_size_kb'].get(k, 0.0) * 1024 for k in rec['fetch_size_kb']}
+            return sum(per.values()) / max(len(per), 1), 'recorded (profiles/%s: raw FETCH_SIZE + WRITE_SIZE per launch, mean of forward and backward)' % name
+        except Exception:
+            continue
+    return None, None
 
 
 def algorithmic_gflop(cfg, B):
@@ -173,7 +179,7 @@ def cpu_baseline(cfg, pool, shape, budget_s=18.0):
         log('cpu_baseline[cxx]: unavailable (%s)' % str(e)[:80])
     best = max(variants, key=lambda v: v['train_episodes_per_s'])
     return {'value': best['train_episodes_per_s'], 'unit': 'episodes/s', 'cores': best['threads'], 'kind': 'port',
-            'cores_used': best['threads'], 'cores_available': avail, 'variants': variants,
+            'cores_used': best['threads'], 'cores_available': avail, 'cores_of': '%d of %d' % (best['threads'], avail), 'variants': variants,
             'train_eps': n, 'eval_eps': ne, 'first_eval_nll': float(first_eval),
             'sample': '%d train + %d eval episodes of the same %d-way %d-shot workload (fp32 CPU restatement of the reference '
                       'graph, best of %s; %.1f s)' % (n, ne, shape[0], shape[1], '/'.join(v['name'] for v in variants), dt + de)}
@@ -457,7 +463,7 @@ def main():
                 'kernel': 'fused LSTM cell: k_lstm_fwd_xcd + k_lstm_bwd_xcd (recurrent [B x H] x [H x 4H] contraction on v_mfma_f32_4x4x1_16B_f32 '
                           '+ gate nonlinearities / gate gradients + state update, %d dependent time steps per launch)' % int(steps_per_launch['lstm_fwd']),
                 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
-                'traffic': hbm_traffic(), 'launches': tot_n, 'avg_launch_ms': tot_ms / max(tot_n, 1),
+                'traffic': hbm_traffic()[0], 'traffic_source': hbm_traffic()[1], 'launches': tot_n, 'avg_launch_ms': tot_ms / max(tot_n, 1),
                 'algorithmic_gflop_per_launch': gf['lstm_fwd'] / max(cell['lstm_fwd'][1] / max(args.steps, 1), 1),
                 'forward': {'avg_launch_ms': cell['lstm_fwd'][0] / max(cell['lstm_fwd'][1], 1), 'us_per_time_step': 1e3 * cell['lstm_fwd'][0] / (T * cfg['n_layers'] * args.steps),
                             'frac': gf['lstm_fwd'] * args.steps / cell['lstm_fwd'][0] / PEAK_F32_MFMA_TFLOPS},

@@ -107,7 +107,7 @@ struct fsmg_model {
     int xcd_max_rows = 128;             // FSMG_XCD_MAX_ROWS: largest sequence count that takes the XCD-local kernels
     bool dp_split = false;              // FSMG_DP_SPLIT=1: fsmg_forward_backward replays TWO graphs (forward + projection gradients | BPTT + the rest) and
                                         // records bucket 0's readiness between them, so its all-reduce runs under the second one
-    int xcd_pipe = 0;                   // FSMG_XCD_PIPE=1: the round-3 variant of the XCD-local kernels (all-thread cell update; measured slower, kept for A/B)
+    int xcd_variant = -1;               // FSMG_XCD_VARIANT: XCD_* bits for both directions (-1: lstm_xcd_default_variant)
     float* khx = nullptr;
     float* HX = nullptr; int64_t hx_floats = 0;
     float* inboxX = nullptr; int64_t inboxx_floats = 0;
@@ -792,7 +792,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             if (xcd) {
                 ScopedTimer tm(h, "lstm_fwd");
                 LstmFwdXcdArgs a{};
-                a.rpx = rpx; a.pipe = h->xcd_pipe;
+                a.rpx = rpx; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, true);
                 a.KhX = h->khx + (size_t)(2 * l) * Hp * G4; a.HX = h->HX; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
                 a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_fwd_xcd(s, a));
@@ -964,7 +964,7 @@ int backward(fsmg_model* h, int B, int part = 0) {
             ScopedTimer tm(h, "lstm_bwd");
             if (xcd) {
                 LstmBwdXcdArgs a{};
-                a.rpx = rpx; a.pipe = h->xcd_pipe;
+                a.rpx = rpx; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, false);
                 a.KhXb = h->khx + (size_t)(2 * l + 1) * Hp * G4; a.inbox = h->inboxX; a.Z = h->Z[l]; a.Cs = h->Cs[l];
                 a.dc = h->dC; a.dH = h->dH; a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_bwd_xcd(s, a));
@@ -1330,7 +1330,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_BWD_RS")) h->bwd_rs = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XCD")) h->xcd = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_DP_SPLIT")) h->dp_split = (e[0] != '0');
-        if (const char* e = std::getenv("FSMG_XCD_PIPE")) h->xcd_pipe = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_XCD_VARIANT")) h->xcd_variant = std::atoi(e);
         if (const char* e = std::getenv("FSMG_XCD_MAX_ROWS")) h->xcd_max_rows = std::max(1, std::min(128, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_PERSIST_FWD")) h->persist_fwd = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_FWD_RT")) h->force_fwd_rt = (e[0] != '0');

@@ -145,6 +145,10 @@ hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* b
 // the dh partials between its own 32 CUs through its L2.  grid = 256 blocks x 256 threads; roles come from the XCC id
 // plus a per-XCD ticket (tickets: 8 ints, ZERO before every launch).  Same bounded-spin / err_flag = 2 contract as the
 // column-split persistent kernels.
+// variants of the XCD-local kernels (same results, different schedules of the cell threads' memory traffic)
+enum { XCD_DEFER_OUTPUTS = 16,      // forward: c / h / gate stores of step t are issued behind the poll of step t+1; backward: dz stores behind the drain
+       XCD_NO_POLL_SLEEP = 32 };    // no s_sleep between two polls of a hand-off
+int lstm_xcd_default_variant(int B, bool forward);
 struct LstmFwdXcdArgs {
     const float* KhX;     // forward register image of K_h (launch_repack_kh_xcd)
     float* HX;            // [T+1][8][4][RG][2][64][4] hand-off buffer; index 0 = zero state, t0+1 .. t1 = 0xFF fill
@@ -157,8 +161,7 @@ struct LstmFwdXcdArgs {
     int spin_limit;
     unsigned long long* prof;   // != nullptr: instrumented build, [256 blocks][4 waves][8] tick sums per phase (RG = 2 only)
     int rpx;                    // rows per XCD; 0 = ceil(B / 8).  lstm_xcd_packed_rows(B) packs the batch on the first XCDs
-    int pipe;                   // 1: two-chain software-pipelined kernel (>= 2 row groups per XCD), 0: one chain per XCD (round 2)
-    int dbg;                    // timing experiments only (WRONG results): 1 = no output stores / input loads, 2 = fragments taken as ready
+    int variant;                // XCD_* bits; lstm_xcd_default_variant(B, forward) has the measured choice
 };
 struct LstmBwdXcdArgs {
     const float* KhXb;    // backward register image of K_h
@@ -173,8 +176,7 @@ struct LstmBwdXcdArgs {
     int spin_limit;
     unsigned long long* prof;
     int rpx;              // as LstmFwdXcdArgs
-    int pipe;             // as LstmFwdXcdArgs (the inbox is laid out per chain then: see k_lstm_bwd_xcd2)
-    int dbg;              // as LstmFwdXcdArgs
+    int variant;          // as LstmFwdXcdArgs
 };
 bool lstm_xcd_supported(int B, int Hp);
 long long lstm_xcd_hx_floats(int B, int T);

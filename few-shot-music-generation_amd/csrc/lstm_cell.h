@@ -14,9 +14,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // tanh is a Taylor polynomial so tanh(x) ~ x keeps full relative accuracy where 1 - 2/(1+e^2x) cancels.
 __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
-#ifdef FSMG_FAST_TANH      // experiment (tools/xcd_chain_bench): no small-|x| polynomial, absolute error ~1e-7
-    return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
-#endif
     const float x2 = x * x;
     const float poly = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.05396825f + x2 * 0.02186949f))));
     const float big = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));

@@ -37,18 +37,37 @@ SHAPES = [
 ]
 
 
+@pytest.fixture(params=['bx3', 'f32'])
+def gemm_kind(request, monkeypatch):
+    """both GEMM arithmetics of the library: the default bf16-split products on the bf16 matrix pipe and the fp32 MFMA
+    (FSMG_GEMM=f32, the bench line's alt_gemm_f32_mfma leg) -- same tolerances for both"""
+    monkeypatch.setenv('FSMG_GEMM', request.param)
+    return request.param
+
+
+_ORACLE_CACHE = {}
+
+
+def cached_oracle_step(key, params, sup, qry, cfg):
+    """the fp64 oracle of a full-size episode takes seconds: computed once per (test, shape), shared by the GEMM kinds
+    (same seeded parameters, same episode)"""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = oracle_step(params, sup, qry, cfg)
+    return _ORACLE_CACHE[key]
+
+
 def _episode(cfg, N, K, Q, seed=0, realistic=True):
     (sup, qry), = O.synthetic_episodes(1, N, K, Q, cfg['max_len'], cfg['input_size'], seed=seed, realistic=realistic)
     return sup, qry
 
 
 @pytest.mark.parametrize('over,N,K,Q', SHAPES)
-def test_forward_backward_every_tensor(over, N, K, Q):
+def test_forward_backward_every_tensor(over, N, K, Q, gemm_kind):
     cfg = small_config(**over)
     sup, qry = _episode(cfg, N, K, Q, seed=3)
     model = new_model(cfg)
     params = f64_params(model)
-    loss, cache, grads, aux = oracle_step(params, sup, qry, cfg)
+    loss, cache, grads, aux = cached_oracle_step(('shape', repr(sorted(over.items())), N, K, Q), params, sup, qry, cfg)
     B, T = N * (K + Q), cfg['max_len']
 
     model.forward_backward(sup, qry)
@@ -555,6 +574,9 @@ FULL = {
     'cfg-C': (dict(input_size=4708, max_len=50, embedding_size=250, hidden_size=1024, n_layers=2), 5, 5, 4),
     'cfg-D': (dict(input_size=10000, max_len=128, embedding_size=250, hidden_size=512, n_layers=1), 20, 1, 4),
 }
+# BASELINE.json configs[4]: the MAML-style loop at its own size (freemidi vocabulary, 2-layer LSTM h=1024, 5-way / 5-shot);
+# it has its own test (a baseline step at these dims IS cfg-C)
+FULL_E = (dict(input_size=4708, max_len=50, embedding_size=250, hidden_size=1024, n_layers=2), 5, 5, 4, 1, 0.1)
 
 
 @pytest.mark.parametrize('name', sorted(FULL))
@@ -723,7 +745,7 @@ def test_nccl_allreduce_runs_on_the_gradient_tensor_and_model_stream():
 
 
 @pytest.mark.parametrize('name', sorted(FULL))
-def test_full_size_gradients_match_oracle(name):
+def test_full_size_gradients_match_oracle(name, gemm_kind):
     """One full train episode of every BASELINE config that fits one GPU -- cfg-B (B=45, T=128, V1=10001, H=512),
     cfg-C (T=50, H=1024, L=2: the all-row-tiles forward kernel, k_lstm_bwd_rs<8>, the inter-layer dx path) and cfg-D
     (B=100: 7 row tiles) -- loss and EVERY gradient tensor vs the fp64 oracle (231 / 249 / 513 GFLOP in numpy),
@@ -733,7 +755,8 @@ def test_full_size_gradients_match_oracle(name):
     (sup, qry), = O.synthetic_episodes(1, N, K, Q, cfg['max_len'], cfg['input_size'], seed=8, realistic=True)
     model = new_model(cfg)
     params = f64_params(model)
-    loss, cache, grads, aux = oracle_step(params, sup, qry, cfg)
+    loss, cache, grads, aux = cached_oracle_step(('full', name), params, sup, qry, cfg)
+    params = {k: v.copy() for k, v in params.items()}
     model.forward_backward(sup, qry)
     tail = model.debug_read('tail', 16)
     assert abs(tail[1] - loss) <= NLL_RTOL * abs(loss)
@@ -772,3 +795,81 @@ def test_lr_decay_is_exercised_from_a_resumed_step():
     for name, ref in params.items():
         assert rel_max(model.get_param(name), ref) < 5e-4, name
     assert moved > 0.02          # the parameters moved by far more than the tolerance: the check has teeth
+
+
+def test_maml_step_and_eval_match_oracle_at_the_baseline_size():
+    """cfg-E at BASELINE.json's own size -- freemidi vocabulary (V = 4708), 2-layer LSTM h = 1024, T = 50, 5-way / 5-shot /
+    4 query, one inner clipped-SGD step of 0.1 (config/maml_lstm.yaml) -- one few-shot evaluation and one outer step against
+    the fp64 oracle: query NLL at the adapted parameters, every parameter after clip + Adam, theta restored by the evaluation."""
+    over, N, K, Q, inner_steps, inner_lr = FULL_E
+    cfg = small_config(**over)
+    (sup, qry), (sup2, qry2) = O.synthetic_episodes(2, N, K, Q, cfg['max_len'], cfg['input_size'], seed=43, realistic=True)
+    model = new_model(cfg)
+    params = f64_params(model)
+    opt = O.new_opt_state(params)
+    want_eval = O.maml_eval(params, sup2, qry2, cfg, inner_steps, inner_lr)
+    got_eval = model.maml_eval(sup2, qry2, inner_steps, inner_lr)
+    assert abs(got_eval - want_eval) <= NLL_RTOL * abs(want_eval), (got_eval, want_eval)
+    for name, ref in params.items():                                    # evaluation left theta alone
+        assert rel_max(model.get_param(name), ref) == 0.0, name
+    want = O.maml_step(params, opt, sup, qry, cfg, inner_steps, inner_lr)
+    got = model.maml_step(sup, qry, inner_steps, inner_lr)
+    assert abs(got - want) <= NLL_RTOL * abs(want), (got, want)
+    assert model.step == 1
+    for name, ref in params.items():
+        assert rel_max(model.get_param(name), ref) < 1e-4, name          # one Adam step from zero slots (sign-like update)
+
+
+def test_ten_consecutive_train_losses_at_cfg_b():
+    """The reference's own regression test (src/train/test_seed.py:17-65: N_UPDATES = 10 consecutive train losses from a
+    fixed initialisation) at the headline workload's FULL size (cfg-B: V1 = 10001, T = 128, B = 45, H = 512): each of ten
+    consecutive train losses within 1e-4 relative of the fp64 oracle started from the same parameters, a fresh episode per
+    step, clip + Adam applied in between (BASELINE.md section 3 / SURVEY.md 8d parity gate)."""
+    over, N, K, Q = FULL['cfg-B']
+    cfg = small_config(**over)
+    eps = O.synthetic_episodes(10, N, K, Q, cfg['max_len'], cfg['input_size'], seed=77, realistic=True)
+    model = new_model(cfg)
+    params = f64_params(model)
+    opt = O.new_opt_state(params)
+    worst = 0.0
+    for s_, (sup, qry) in enumerate(eps):
+        want = O.train_step(params, opt, sup, qry, cfg)
+        got = model.train_step(sup, qry)
+        worst = max(worst, abs(got - want) / abs(want))
+        assert abs(got - want) <= NLL_RTOL * abs(want), (s_, got, want)
+    assert model.step == 10
+    print('ten full-size cfg-B train losses: worst relative error %.2e' % worst)
+
+
+@pytest.mark.parametrize('kind', ['bx3', 'f32'])
+def test_non_finite_weights_saturate_with_the_bf16_split_and_give_inf_with_the_fp32_mfma(kind, monkeypatch):
+    """Edge of the default GEMM (csrc/gemm.hip, "fp32 GEMM on the bf16 matrix pipe"), pinned as MEASURED on gfx950: an operand
+    that is Inf -- or finite but above bf16's largest value 3.39e38 -- does not survive the split (v_cvt_pk_bf16_f32 hands back
+    a finite leading piece), so the affected logits come out finite and huge (~3.4e38 * h) where the fp32 MFMA (FSMG_GEMM=f32)
+    produces +-Inf for an Inf weight.  No NaN appears either way, the damage stays in the column the bad weight feeds and every
+    other logit keeps its bits.  (Round 2 documented "NaN" here without a test; the hardware says otherwise.)"""
+    monkeypatch.setenv('FSMG_GEMM', kind)
+    cfg = small_config(hidden_size=32, embedding_size=16, input_size=130, max_len=5)
+    sup, qry = _episode(cfg, 3, 2, 2, seed=5)
+    B, T, V1 = 3 * 4, cfg['max_len'], cfg['input_size'] + 1
+    clean = new_model(cfg)
+    clean.forward_backward(sup, qry)
+    V1p = clean.debug_dims()['V1p']
+    ref = clean.debug_read('logits', B * T * V1p).reshape(B * T, V1p)[:, :V1].copy()
+    for bad in (np.float32(np.inf), np.float32(3.395e38)):
+        model = new_model(cfg)
+        w = model.get_param('softmax_w')
+        w[:, 7] = 0.0
+        w[3, 7] = bad                                   # column 7 of the logits = bad * h[:, 3] (+ bias)
+        model.set_param('softmax_w', w)
+        model.forward_backward(sup, qry)
+        logits = model.debug_read('logits', B * T * V1p).reshape(B * T, V1p)[:, :V1]
+        col = logits[:, 7]
+        assert not np.isnan(col).any()
+        if kind == 'f32' and np.isinf(bad):
+            assert np.isinf(col).all()
+            assert not np.isfinite(model.debug_read('tail', 16)[1])       # Inf logit -> the loss is not finite: no silent garbage
+        else:
+            assert np.isfinite(col).all() and np.abs(col).max() > 1e30
+        others = np.delete(logits, 7, axis=1)
+        np.testing.assert_array_equal(others, np.delete(ref, 7, axis=1))

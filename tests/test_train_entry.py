@@ -137,3 +137,54 @@ def test_test_seed_entry_matches_oracle_trajectory(tmp_path, golden_dir, capsys)
     assert TS.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--expect', '%.9f' % want]) == 0
     assert 'loss after 10 updates' in capsys.readouterr().out
     assert TS.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--expect', '%.9f' % (want + 0.5)]) == 1
+
+
+@pytest.mark.gpu
+def test_main_with_the_maml_plugin_trains_with_the_inner_loop(tmp_path, golden_dir, capsys):
+    """`train.train --model maml_lstm.yaml` must run MAMLLSTM's step on BOTH calling conventions.  (Round 2's fast path called
+    the inherited baseline train_indexed: inner loop skipped, training and evaluation silently disagreeing -- ADVICE r02.)
+    The window means printed by the fast path equal the fp64 oracle's maml_step on the same sampler stream."""
+    import numpy as np
+    from data.episode import load_sampler_from_config
+    from models.maml_lstm import MAMLLSTM
+    from oracle import lstm_oracle as O
+    cfg = dict(LOOP, name='maml_lstm', model_module_name='models.maml_lstm', model_class_name='MAMLLSTM',
+               n_train=4, print_every_n=2, val_every_n=4.0, n_val=2, n_test=2, n_samples=1, n_decay=10000, lr=5e-3, max_grad_norm=5,
+               embedding_size=32, hidden_size=40, n_layers=1, batch_size=3, inner_steps=1, inner_lr=0.3)
+    p = _write_configs(tmp_path, golden_dir, cfg)
+    full = {}
+    for k in ('data', 'task', 'model'):
+        full.update(yaml.safe_load(open(p[k])))
+    full['split'] = 'train'
+    sampler = load_sampler_from_config(dict(full))
+    full['input_size'] = sampler.get_num_unique_words()
+    probe = MAMLLSTM(dict(full)); probe.recover_or_init('')
+    params = {k: v.astype(np.float64) for k, v in probe.engine.get_params().items()}
+    opt = O.new_opt_state(params)
+    want = []
+    for _ in range(4):
+        ep = sampler.get_episode()
+        want.append(O.maml_step(params, opt, ep.support, ep.query, full, 1, 0.3))
+    # what the bug printed: plain baseline steps on the same stream (all rows at theta, no adaptation)
+    sampler_b = load_sampler_from_config(dict(full))
+    params_b = {k: v.astype(np.float64) for k, v in probe.engine.get_params().items()}
+    opt_b = O.new_opt_state(params_b)
+    plain = []
+    for _ in range(2):
+        ep = sampler_b.get_episode()
+        plain.append(O.train_step(params_b, opt_b, ep.support, ep.query, full))
+    out = {}
+    for sync in ('0', '1'):
+        os.environ['FSMG_TRAIN_SYNC'] = sync
+        try:
+            T.main(['--data', p['data'], '--task', p['task'], '--model', p['model'], '--checkpt_dir', str(tmp_path / ('ck' + sync))])
+        finally:
+            del os.environ['FSMG_TRAIN_SYNC']
+        out[sync] = [l for l in capsys.readouterr().out.splitlines() if l.startswith('Iter: ') or 'Avg NLL' in l]
+    assert out['0'] == out['1']                                    # fast path == the reference's calling convention
+    loss_lines = [l for l in out['0'] if ', loss: ' in l]
+    got = [float(l.split('loss: ')[1]) for l in loss_lines]
+    assert len(got) == 2
+    for g, w in zip(got, (np.mean(want[:2]), np.mean(want[2:]))):
+        assert abs(g - w) <= 2e-3 * abs(w), (got, want)           # printed with 4 significant digits
+    assert abs(np.mean(plain) - np.mean(want[:2])) > 5e-3 * abs(np.mean(want[:2]))      # the check has teeth

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the round artefacts on the GPU box into gpurun_out/ (copy the ones to keep into profiles/).
 #   gpurun -- tools/refresh_profiles.sh [tag]
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
@@ -29,11 +29,16 @@ def means(counter):
         print('no', counter, e)
     return {k: sum(v) / len(v) for k, v in agg.items()}
 f, w = means('FETCH_SIZE'), means('WRITE_SIZE')
-# rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB; gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM)
+# rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB.  The guide's gfx950 correction (FETCH_SIZE x 2) is calibrated for wide coalesced
+# streaming reads (16 B per lane) ONLY; these kernels read scattered 4-byte words (x-part / gates: 4 x 16 B per row and lane quad).
+# Calibration in their own access pattern: the forward kernel's only HBM read is Z, T*B*4H*4 B = 47.2 MB at cfg-B, and its RAW
+# FETCH_SIZE is 47.7 MB -> no correction applies here; WRITE_SIZE 85.5 MB = 47.2 (gates) + 23.6 (h, c) +
+# 16.8 (HX hand-off buffer, written through L2).
 out = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --steps 4 --warmup 2`, means per launch',
+       'correction': 'none: raw FETCH_SIZE of k_lstm_fwd_xcd equals its algorithmic read (Z, 47.2 MB at cfg-B); the x2 of the guide is for 16-B/lane streaming loads',
        'fetch_size_kb': f, 'write_size_kb': w}
 if f and w:
-    per = {k: 2.0 * f[k] * 1024 + w.get(k, 0.0) * 1024 for k in f}
+    per = {k: f[k] * 1024 + w.get(k, 0.0) * 1024 for k in f}
     out['traffic_bytes_per_launch_by_kernel'] = per
     out['traffic_bytes_per_launch'] = sum(per.values()) / max(len(per), 1)
 json.dump(out, open('%s/%s_lstm_cell_pmc.json' % (O, TAG), 'w'), indent=1)

@@ -4,7 +4,8 @@
 //   3  block -> XCD placement (XCC id of block b) and the one-way hand-off latency between two blocks of the SAME XCD
 //      vs two blocks of DIFFERENT XCDs, for write-through (sc1) and plain (L2-resident) 16-byte stores, sc1 loads
 //   4  k_lstm_fwd_xcd / k_lstm_bwd_xcd against a double-precision CPU recurrence (B = 45 and B = 100), and their time
-//      per step at T = 128 next to the column-split persistent kernels of lstm_step.hip
+//      per step at T = 128 next to the column-split persistent kernels of lstm_step.hip; VARIANT=<XCD_* bits> selects the
+//      variant the correctness / timing / profile legs run (the variant sweep line always covers 16 / 32 / 48)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ifew-shot-music-generation_amd/csrc -Iinclude -c tools/xcd_chain_bench.cpp -o /tmp/xcb.o
 //        hipcc --offload-arch=gfx950 /tmp/xcb.o few-shot-music-generation_amd/build/lstm_xcd.o few-shot-music-generation_amd/build/lstm_step.o -o tools/xcd_chain_bench.bin
 #include <hip/hip_runtime.h>
@@ -284,7 +285,7 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
         for (int c = 0; c < nchunk; ++c) {
             LstmFwdXcdArgs a{};
             a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.pipe = pipe; a.dbg = pipe ? 0 : g_variant;
+            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant;
             CK(launch_lstm_fwd_xcd(s, a));
         }
     };
@@ -295,7 +296,7 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
         for (int c = nchunk - 1; c >= 0; --c) {
             LstmBwdXcdArgs a{};
             a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.pipe = pipe; a.dbg = pipe ? 0 : g_variant;
+            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant;
             CK(launch_lstm_bwd_xcd(s, a));
         }
     };
@@ -337,7 +338,7 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
                 for (int c = 0; c < nchunk; ++c) {
                     LstmFwdXcdArgs a{};
                     a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.pipe = pipe; a.dbg = pipe ? 0 : g_variant;
+                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant;
                     CK(launch_lstm_fwd_xcd(s, a));
                 }
                 CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
@@ -347,7 +348,7 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
                 for (int c = nchunk - 1; c >= 0; --c) {
                     LstmBwdXcdArgs a{};
                     a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.pipe = pipe; a.dbg = pipe ? 0 : g_variant;
+                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant;
                     CK(launch_lstm_bwd_xcd(s, a));
                 }
                 CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
@@ -359,46 +360,24 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
                    mflop * T / best_b / 1e6, mflop * T / best_b / 1e6 / 157.3 * 100, e);
             CK(hipMemset(d.err, 0, 4));
         }
-        if (pipe == 0) {     // variants of the round-2 kernels (correct results): 16 = outputs deferred behind the next poll / dz stores behind the drain, 32 = no sleep between polls
+        {                    // variants (same results): 16 = XCD_DEFER_OUTPUTS, 32 = XCD_NO_POLL_SLEEP
             for (int dbg : {16, 32, 48}) {
                 float best_f = 1e9f, best_b = 1e9f;
                 for (int rep = 0; rep < 5; ++rep) {
                     fwd_xcd(T, 0);
                     CK(hipEventRecord(e0, s));
                     { LstmFwdXcdArgs a{}; a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.pipe = 0; a.dbg = dbg; CK(launch_lstm_fwd_xcd(s, a)); }
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; CK(launch_lstm_fwd_xcd(s, a)); }
                     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best_f = std::min(best_f, ms);
                     bwd_xcd(T, 0);
                     CK(hipEventRecord(e0, s));
                     { LstmBwdXcdArgs a{}; a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.pipe = 0; a.dbg = dbg; CK(launch_lstm_bwd_xcd(s, a)); }
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; CK(launch_lstm_bwd_xcd(s, a)); }
                     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                     CK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
                 }
                 printf("[4] B=%d pipe=0 variant %d (%s%s): fwd %.2f us/step | bwd %.2f us/step  err_flag %d\n", B, dbg, (dbg & 16) ? "deferred stores " : "", (dbg & 32) ? "no poll sleep" : "",
-                       best_f * 1e3 / T, best_b * 1e3 / T, read_err());
-                CK(hipMemset(d.err, 0, 4));
-            }
-        }
-        if (pipe == 1) {     // timing-only decomposition (results are wrong by construction): 1 = no output stores / input loads, 2 = fragments taken as ready
-            for (int dbg : {1, 2, 3}) {
-                float best_f = 1e9f, best_b = 1e9f;
-                for (int rep = 0; rep < 4; ++rep) {
-                    fwd_xcd(T, 0);
-                    CK(hipEventRecord(e0, s));
-                    { LstmFwdXcdArgs a{}; a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.pipe = 1; a.dbg = dbg; CK(launch_lstm_fwd_xcd(s, a)); }
-                    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
-                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best_f = std::min(best_f, ms);
-                    bwd_xcd(T, 0);
-                    CK(hipEventRecord(e0, s));
-                    { LstmBwdXcdArgs a{}; a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.pipe = 1; a.dbg = dbg; CK(launch_lstm_bwd_xcd(s, a)); }
-                    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
-                    CK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
-                }
-                printf("[4] B=%d pipe=1 dbg=%d (%s%s): fwd %.2f us/step | bwd %.2f us/step  err_flag %d\n", B, dbg, (dbg & 1) ? "no slow traffic " : "", (dbg & 2) ? "no readiness wait" : "",
                        best_f * 1e3 / T, best_b * 1e3 / T, read_err());
                 CK(hipMemset(d.err, 0, 4));
             }
@@ -412,23 +391,21 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
                     fwd_xcd(T, 0);
                     LstmFwdXcdArgs a{};
                     a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.pipe = pipe;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant;
                     CK(launch_lstm_fwd_xcd(s, a));
                 } else {
                     bwd_xcd(T, 0);
                     LstmBwdXcdArgs a{};
                     a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.pipe = pipe;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant;
                     CK(launch_lstm_bwd_xcd(s, a));
                 }
                 CK(hipStreamSynchronize(s));
                 CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
                 const char* names_f0[5] = {"wait h_t", "MFMA", "LDS+barrier", "cell->store", "rest"};
                 const char* names_b0[5] = {"wait inbox", "psum+barrier", "cell+dzA+barrier", "LDS read+MFMA", "drain+stores+rest"};
-                const char* names_f1[5] = {"wait h_t", "outputs+x-part issue+MFMA", "LDS+barrier", "cell->store", "loop"};
-                const char* names_b1[5] = {"wait inbox", "resets+psum+barrier", "gate grads+barrier", "dz stores+input loads+MFMA", "publish+loop"};
-                const char** names_f = pipe ? names_f1 : names_f0;
-                const char** names_b = pipe ? names_b1 : names_b0;
+                const char** names_f = names_f0;
+                const char** names_b = names_b0;
                 for (int wc = 0; wc < 2; ++wc) {        // cell waves (0,1) vs the others (2,3)
                     double m[5] = {0, 0, 0, 0, 0};
                     for (int b = 0; b < 256; ++b) for (int w = 2 * wc; w < 2 * wc + 2; ++w) for (int i = 0; i < 5; ++i) m[i] += (double)hp[((size_t)b * 4 + w) * 8 + i];
@@ -441,7 +418,7 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
             hipFree(prof);
             CK(hipMemset(d.err, 0, 4));
         }
-        if (pipe == 0 && lstm_fwd_chain_supported(B, H)) {
+        if (lstm_fwd_chain_supported(B, H)) {
             float best_f = 1e9f, best_b = 1e9f;
             for (int rep = 0; rep < 6; ++rep) {
                 CK(hipMemcpyAsync(d.Z, Zin.data(), 4ull * T * B * G4, hipMemcpyHostToDevice, s));
@@ -480,12 +457,10 @@ int main(int argc, char** argv) {
     if (rc) { printf("MFMA layout assumption wrong: kernels not run\n"); return 1; }
     const int only_pipe = getenv("PIPE") ? atoi(getenv("PIPE")) : -1;
     g_variant = getenv("VARIANT") ? atoi(getenv("VARIANT")) : 0;
-    for (int pipe = 0; pipe < 2; ++pipe) {
-        if (only_pipe >= 0 && pipe != only_pipe) continue;
-        rc += run_case(45, pipe ? 17 : 6, 128, pipe);
-        rc += run_case(100, pipe ? 9 : 4, 128, pipe);
-        rc += run_case(20, pipe ? 9 : 4, 128, pipe);
-    }
+    (void)only_pipe;
+    rc += run_case(45, 6, 128, 0);
+    rc += run_case(100, 4, 128, 0);
+    rc += run_case(20, 4, 128, 0);
     printf(rc ? "FAILED\n" : "ALL OK\n");
     return rc;
 }
