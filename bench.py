@@ -270,21 +270,14 @@ def main():
     shape = (N_WAY, K_SHOT, Q_QUERY)
     kw = dict(maml=maml) if maml else {}
 
-    def make(env_over):
-        """a fresh model + its episode-parallel driver, created under the given environment overrides (the library and
-        fsmg.dist read their schedule knobs at creation)"""
-        saved = {k: os.environ.get(k) for k in env_over}
-        os.environ.update(env_over)
-        try:
-            m = Model(cfg)
-            m.recover_or_init('')
-            return m, EpisodeParallel(m)
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+    def make(over):
+        """a fresh model + its episode-parallel driver; `over`: model-config keys the plugin hands to fsmg_config (gemm,
+        schedule, recurrence, dp_split_backward) plus `bucketed` for the exchange"""
+        over = dict(over)
+        bucketed = over.pop('bucketed', None)
+        m = Model(dict(cfg, **over))
+        m.recover_or_init('')
+        return m, EpisodeParallel(m, bucketed=bucketed)
 
     def barrier():
         torch.cuda.synchronize()
@@ -331,7 +324,7 @@ def main():
     if world == 1:
         plans = [('single_gpu_one_graph', {})]
     else:
-        plans = [('graph_end', {}), ('split_bucket0', {'FSMG_DP_SPLIT': '1'}), ('one_collective', {'FSMG_DP_BUCKETS': '0'})]
+        plans = [('graph_end', {}), ('split_bucket0', {'dp_split_backward': True}), ('one_collective', {'bucketed': False})]
         if os.environ.get('FSMG_BENCH_SCHEDULES'):
             keep = os.environ['FSMG_BENCH_SCHEDULES'].split(',')
             plans = [pl for pl in plans if pl[0] in keep] or plans[:1]
@@ -544,9 +537,8 @@ def main():
         log('breakdown done')
     if rank == 0 and world == 1 and not args.no_breakdown and not maml and os.environ.get('FSMG_GEMM', 'bx3') != 'f32':
         # the same timed loop with every GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32): what the bf16-split GEMMs buy
-        os.environ['FSMG_GEMM'] = 'f32'
         try:
-            alt = Model(cfg)
+            alt = Model(dict(cfg, gemm='f32'))
             alt.recover_or_init('')
             par_alt = EpisodeParallel(alt)
             def step_alt(i):
@@ -565,10 +557,10 @@ def main():
             l_alt = alt.engine.read_losses(min(n_alt, 1024))
             out['alt_gemm_f32_mfma'] = {'value': n_alt / dt, 'unit': 'episodes/s', 'ms_per_step': 1e3 * dt / n_alt, 'steps': n_alt,
                                         'advanced_by': alt.engine.step - a0, 'final_loss': float(l_alt[-1]),
-                                        'note': 'same workload and schedule, every GEMM on v_mfma_f32_32x32x2_f32 (FSMG_GEMM=f32)'}
+                                        'note': 'same workload and schedule, every GEMM on v_mfma_f32_32x32x2_f32 (fsmg_config.gemm = FSMG_GEMM_F32)'}
             del alt, par_alt
         finally:
-            del os.environ['FSMG_GEMM']
+            pass
         log('fp32-MFMA GEMM leg done')
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not maml:
         out['cpu_baseline'] = cpu_baseline(base, pool_host, shape)

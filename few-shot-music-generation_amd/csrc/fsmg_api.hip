@@ -155,6 +155,9 @@ struct fsmg_model {
     // decode
     float* dec = nullptr;
 
+#ifdef FSMG_PHASE_DEBUG
+    hipEvent_t ph[8] = {}; bool ph_init = false; int ph_step = 0;      // per handle (was file scope: shared by all handles)
+#endif
     int lastB = 0;
     bool have_grads = false;
     std::string err;
@@ -617,17 +620,16 @@ inline bool use_overlap(const fsmg_model* h) { return h->ov_call && !h->timing &
 #ifdef FSMG_PHASE_DEBUG
 // compile-time debugging aid (make EXTRA=-DFSMG_PHASE_DEBUG): GPU time of the phases of the eager overlap
 // schedule, from events on the main stream; printed every 20th step
-static hipEvent_t g_ph[8]; static bool g_ph_init = false; static int g_ph_step = 0;
 static void phase_mark(fsmg_model* h, int i) {
-    if (!g_ph_init) { for (auto& e : g_ph) hipEventCreate(&e); g_ph_init = true; }
-    hipEventRecord(g_ph[i], h->stream);
+    if (!h->ph_init) { for (auto& e : h->ph) hipEventCreate(&e); h->ph_init = true; }
+    hipEventRecord(h->ph[i], h->stream);
 }
 static void phase_report(fsmg_model* h) {
-    if (++g_ph_step % 20) return;
+    if (++h->ph_step % 20) return;
     hipStreamSynchronize(h->stream);
     const char* nm[] = {"zx+memsets", "fwd chain", "fwd join+loss", "to bwd chain", "bwd chain", "dk/dx/embed + dW join", "update"};
     float tot = 0;
-    for (int i = 0; i < 7; ++i) { float ms = 0; hipEventElapsedTime(&ms, g_ph[i], g_ph[i + 1]); tot += ms; fprintf(stderr, "[phase] %-24s %7.1f us\n", nm[i], ms * 1000); }
+    for (int i = 0; i < 7; ++i) { float ms = 0; hipEventElapsedTime(&ms, h->ph[i], h->ph[i + 1]); tot += ms; fprintf(stderr, "[phase] %-24s %7.1f us\n", nm[i], ms * 1000); }
     fprintf(stderr, "[phase] total %.1f us\n", tot * 1000);
 }
 #define PHASE(i) phase_mark(h, i)
@@ -1283,6 +1285,12 @@ uint64_t fsmg_state_bytes(const fsmg_config* cfg) {
 int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     if (!cfg || !out) return fail(nullptr, FSMG_ERR_INVALID, "null config/out");
     *out = nullptr;
+    if (cfg->config_version != FSMG_CONFIG_VERSION)
+        return fail(nullptr, FSMG_ERR_INVALID, "fsmg_config.config_version is " + std::to_string(cfg->config_version) + ", this library expects " +
+                                                   std::to_string(FSMG_CONFIG_VERSION) + " (caller built against another include/fsmg.h)");
+    if (cfg->gemm < 0 || cfg->gemm > FSMG_GEMM_F32 || cfg->schedule < 0 || cfg->schedule > FSMG_SCHEDULE_XCD_PARTITIONED ||
+        cfg->recurrence < 0 || cfg->recurrence > FSMG_RECURRENCE_XCD_LOCAL)
+        return fail(nullptr, FSMG_ERR_INVALID, "fsmg_config.gemm / schedule / recurrence out of range");
     if (cfg->input_size <= 0 || cfg->max_len <= 0 || cfg->embedding_size <= 0 || cfg->hidden_size <= 0 ||
         cfg->n_layers <= 0 || cfg->n_layers > 16 || cfg->embedding_size > 1024 || !(cfg->n_decay > 0.f) ||
         !(cfg->max_grad_norm > 0.f))
@@ -1315,9 +1323,17 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         // two-stream schedule: pays when the vocabulary projection dominates the recurrence (measured: +13 % at
         // cfg-B/D where V1/(4H*L) = 4.9; -7 % at cfg-C where it is 0.6), so by default it is chosen from the
         // shapes; FSMG_OVERLAP=0/1 forces the single-stream (hipGraph-replayed) / two-stream (eager) order
+        // the configuration first, the environment (debugging overrides) on top of it
+        h->overlap = (int64_t)h->V1 >= 8LL * h->H * h->L;
+        if (cfg->schedule == FSMG_SCHEDULE_SINGLE_STREAM) { h->overlap = false; h->overlap_forced = true; }
+        if (cfg->schedule == FSMG_SCHEDULE_TWO_STREAM) { h->overlap = true; h->overlap_forced = true; }
+        if (cfg->schedule == FSMG_SCHEDULE_XCD_PARTITIONED) h->xov = true;
+        if (cfg->gemm == FSMG_GEMM_F32) h->bx3 = 0;
+        if (cfg->recurrence == FSMG_RECURRENCE_PER_STEP) h->persist = false;
+        if (cfg->recurrence == FSMG_RECURRENCE_COLUMN_SPLIT) h->xcd = false;
+        if (cfg->dp_split_backward) h->dp_split = true;
         const char* env = std::getenv("FSMG_OVERLAP");
-        h->overlap = env ? (env[0] != '0') : ((int64_t)h->V1 >= 8LL * h->H * h->L);
-        h->overlap_forced = env != nullptr;
+        if (env) { h->overlap = env[0] != '0'; h->overlap_forced = true; }
         if (const char* e = std::getenv("FSMG_GEMM")) h->bx3 = std::strcmp(e, "f32") != 0;
         if (const char* e = std::getenv("FSMG_XCD_OVERLAP")) h->xov = std::atoi(e) != 0;
         if (const char* e = std::getenv("FSMG_XOV_HEAD")) h->xov_head = std::max(1, std::atoi(e));

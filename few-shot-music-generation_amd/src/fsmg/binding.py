@@ -12,6 +12,10 @@ from fsmg.build import LIB
 
 FSMG_GRAD_TAIL = 16
 CLIP_MODES = {'tf1_slices': 0, 'dense': 1}
+FSMG_CONFIG_VERSION = 3
+GEMM_KINDS = {'auto': 0, 'bx3': 1, 'f32': 2}
+SCHEDULES = {'auto': 0, 'single_stream': 1, 'two_stream': 2, 'xcd_partitioned': 3}
+RECURRENCES = {'auto': 0, 'per_step': 1, 'column_split': 2, 'xcd_local': 3}
 
 ERRORS = {-1: 'FSMG_ERR_INVALID', -2: 'FSMG_ERR_NO_DEVICE', -3: 'FSMG_ERR_HIP', -4: 'FSMG_ERR_NOMEM',
           -5: 'FSMG_ERR_NAME', -6: 'FSMG_ERR_SIZE', -7: 'FSMG_ERR_TOKEN_RANGE', -8: 'FSMG_ERR_STATE'}
@@ -28,7 +32,9 @@ class FsmgConfig(C.Structure):
                 ('hidden_size', C.c_int32), ('n_layers', C.c_int32), ('lr', C.c_float),
                 ('max_grad_norm', C.c_float), ('n_decay', C.c_float), ('clip_norm_mode', C.c_int32),
                 ('device', C.c_int32), ('max_sequences', C.c_int32), ('use_graph', C.c_int32),
-                ('stream', C.c_void_p), ('state_arena', C.c_void_p), ('state_arena_bytes', C.c_uint64)]
+                ('stream', C.c_void_p), ('state_arena', C.c_void_p), ('state_arena_bytes', C.c_uint64),
+                ('config_version', C.c_int32), ('gemm', C.c_int32), ('schedule', C.c_int32), ('recurrence', C.c_int32),
+                ('dp_split_backward', C.c_int32), ('reserved', C.c_int32 * 7)]
 
 
 class FsmgStats(C.Structure):
@@ -129,8 +135,15 @@ class FsmgModel(object):
     """One model handle == one LSTM language model resident on one MI355X."""
 
     def __init__(self, config, device=0, stream=None, state_arena=None, state_arena_bytes=0,
-                 max_sequences=0, clip_norm_mode='tf1_slices', use_graph=True):
+                 max_sequences=0, clip_norm_mode='tf1_slices', use_graph=True, gemm=None, schedule=None, recurrence=None,
+                 dp_split_backward=None):
         self._lib = load_library()
+        # schedule / arithmetic knobs: explicit arguments, else optional keys of the model config, else the library's choice
+        gemm = gemm or config.get('gemm', 'auto')
+        schedule = schedule or config.get('schedule', 'auto')
+        recurrence = recurrence or config.get('recurrence', 'auto')
+        if dp_split_backward is None:
+            dp_split_backward = bool(config.get('dp_split_backward', False))
         self.cfg = FsmgConfig(
             input_size=int(config['input_size']), max_len=int(config['max_len']),
             embedding_size=int(config['embedding_size']), hidden_size=int(config['hidden_size']),
@@ -138,7 +151,8 @@ class FsmgModel(object):
             max_grad_norm=float(config['max_grad_norm']), n_decay=float(config['n_decay']),
             clip_norm_mode=CLIP_MODES[clip_norm_mode], device=int(device), max_sequences=int(max_sequences),
             use_graph=int(bool(use_graph)), stream=stream, state_arena=state_arena,
-            state_arena_bytes=int(state_arena_bytes))
+            state_arena_bytes=int(state_arena_bytes), config_version=FSMG_CONFIG_VERSION, gemm=GEMM_KINDS[gemm],
+            schedule=SCHEDULES[schedule], recurrence=RECURRENCES[recurrence], dp_split_backward=int(bool(dp_split_backward)))
         self.max_len = int(config['max_len'])
         handle = _P()
         rc = self._lib.fsmg_create(C.byref(self.cfg), C.byref(handle))
@@ -157,7 +171,8 @@ class FsmgModel(object):
         lib = load_library()
         cfg = FsmgConfig(input_size=int(config['input_size']), max_len=int(config['max_len']),
                          embedding_size=int(config['embedding_size']), hidden_size=int(config['hidden_size']),
-                         n_layers=int(config['n_layers']), lr=1.0, max_grad_norm=1.0, n_decay=1.0)
+                         n_layers=int(config['n_layers']), lr=1.0, max_grad_norm=1.0, n_decay=1.0,
+                         config_version=FSMG_CONFIG_VERSION)
         return int(lib.fsmg_state_bytes(C.byref(cfg)))
 
     def _ck(self, rc):

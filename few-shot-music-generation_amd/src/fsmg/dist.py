@@ -31,11 +31,12 @@ def init_from_env(backend=None):
 
 
 class EpisodeParallel(object):
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, bucketed=None):
         self.engine = engine
         self.group = group
         import os
-        self.bucketed = os.environ.get('FSMG_DP_BUCKETS', '1') != '0'      # 0: one all-reduce after backward
+        # bucketed exchange on the communication stream (default) or ONE all-reduce on the compute stream
+        self.bucketed = (os.environ.get('FSMG_DP_BUCKETS', '1') != '0') if bucketed is None else bool(bucketed)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.exchange = True            # False: skip the gradient exchange (bench.py's "what does the exchange cost" leg; replicas diverge)

@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define FSMG_VERSION 200 /* 0.2.0 */
+#define FSMG_VERSION 300 /* 0.3.0 */
+#define FSMG_CONFIG_VERSION 3 /* layout of struct fsmg_config; fsmg_create rejects any other value in .config_version */
 
 enum {
     FSMG_OK = 0,
@@ -50,6 +51,15 @@ enum {
 };
 
 enum { FSMG_CLIP_TF1_SLICES = 0, FSMG_CLIP_DENSE = 1 };
+/* arithmetic of the dense contractions: AUTO = BX3 (fp32 products assembled exactly from bf16 pieces on the bf16 matrix pipe,
+ * fp32 accumulation: DESIGN.md section 4); F32 = v_mfma_f32_32x32x2_f32 */
+enum { FSMG_GEMM_AUTO = 0, FSMG_GEMM_BX3 = 1, FSMG_GEMM_F32 = 2 };
+/* order of a pass: AUTO picks from the shapes; SINGLE_STREAM = one hipGraph per pass; TWO_STREAM = projection GEMMs on an
+ * auxiliary stream beside the recurrence (eager); XCD_PARTITIONED = recurrence packed on six XCDs, work-queue GEMMs on the rest */
+enum { FSMG_SCHEDULE_AUTO = 0, FSMG_SCHEDULE_SINGLE_STREAM = 1, FSMG_SCHEDULE_TWO_STREAM = 2, FSMG_SCHEDULE_XCD_PARTITIONED = 3 };
+/* recurrent kernels: AUTO = the fastest family the shape admits; PER_STEP = one launch per time step; COLUMN_SPLIT = persistent,
+ * gate columns over the chip (round 1); XCD_LOCAL = persistent, rows over the XCDs (hidden size 512) */
+enum { FSMG_RECURRENCE_AUTO = 0, FSMG_RECURRENCE_PER_STEP = 1, FSMG_RECURRENCE_COLUMN_SPLIT = 2, FSMG_RECURRENCE_XCD_LOCAL = 3 };
 
 typedef struct fsmg_model* fsmg_handle;
 
@@ -72,6 +82,15 @@ typedef struct fsmg_config {
     void* state_arena;       /* optional caller-owned DEVICE memory for params+grads+Adam state
                                 (fsmg_state_bytes() bytes, 256-B aligned); NULL = hipMalloc  */
     uint64_t state_arena_bytes;
+    /* ---- since config version 3: what used to be environment variables read at create time.  The variables still exist as
+     * debugging overrides (FSMG_GEMM, FSMG_OVERLAP, FSMG_XCD_OVERLAP, FSMG_PERSISTENT, FSMG_XCD, FSMG_DP_SPLIT, ...: they win) */
+    int32_t config_version;     /* must be FSMG_CONFIG_VERSION: a caller built against another header is refused            */
+    int32_t gemm;               /* FSMG_GEMM_*                                                                               */
+    int32_t schedule;           /* FSMG_SCHEDULE_*                                                                           */
+    int32_t recurrence;         /* FSMG_RECURRENCE_*                                                                         */
+    int32_t dp_split_backward;  /* 1: fsmg_forward_backward replays two graphs and bucket 0 of the gradient exchange
+                                   (softmax gradients) is final behind the first one (fsmg_stream_wait_bucket)               */
+    int32_t reserved[7];        /* zero                                                                                       */
 } fsmg_config;
 
 /* ---- lifetime -------------------------------------------------------------------------- */

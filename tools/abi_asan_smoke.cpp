@@ -15,7 +15,7 @@ int main() {
     for (int hidden : {40, 512}) {
         fsmg_config c; std::memset(&c, 0, sizeof(c));
         c.input_size = 97; c.max_len = 9; c.embedding_size = 20; c.hidden_size = hidden; c.n_layers = hidden == 40 ? 2 : 1;
-        c.lr = 5e-3f; c.max_grad_norm = 5.f; c.n_decay = 100.f; c.use_graph = 1;
+        c.lr = 5e-3f; c.max_grad_norm = 5.f; c.n_decay = 100.f; c.use_graph = 1; c.config_version = FSMG_CONFIG_VERSION;
         if (fsmg_create(&c, &h) != 0) { printf("create: %s\n", fsmg_last_error(nullptr)); return 1; }
         CK(fsmg_init_params(h, 7));
         const int N = 3, K = 2, Q = 2, T = c.max_len;
