@@ -18,7 +18,7 @@ once per exchange schedule IN THE SAME RUN (`schedules`): "graph_end" (one graph
 buckets reduced on the communication stream when it ends), "split_bucket0" (two graphs: bucket 0 = softmax gradients, 56 %
 of the bytes, is released behind the projection-gradient GEMMs and travels under BPTT) and "one_collective" (a single
 all-reduce on the compute stream); `value` is the fastest, `comm.exposed_ms` what each one adds to the same loop without
-any exchange.
+any exchange.  FSMG_BENCH_LIBRARY_RCCL=1 adds "library_rccl": the collectives issued by libfsmg itself (fsmg_comm_init).
 
 Prints ONE JSON line (rank 0, the LAST line of stdout).  `roofline` is the kernel BASELINE.json's north star sets a
 target for -- the fused LSTM cell (recurrent 4x GEMV on MFMA + gate nonlinearities + state update: k_lstm_fwd_xcd and
@@ -325,6 +325,10 @@ def main():
         plans = [('single_gpu_one_graph', {})]
     else:
         plans = [('graph_end', {}), ('split_bucket0', {'dp_split_backward': True}), ('one_collective', {'bucketed': False})]
+        if os.environ.get('FSMG_BENCH_LIBRARY_RCCL', '0') == '1' and not same_gpu:
+            # opt-in: the exchange issued by libfsmg itself (fsmg_comm_*; tested with one rank on the GPU box, never yet with
+            # N > 1 -- kept out of the default plans so that a first multi-GPU run cannot be lost to it)
+            plans.append(('library_rccl', {'dp_exchange': 'library', 'dp_split_backward': True}))
         if os.environ.get('FSMG_BENCH_SCHEDULES'):
             keep = os.environ['FSMG_BENCH_SCHEDULES'].split(',')
             plans = [pl for pl in plans if pl[0] in keep] or plans[:1]

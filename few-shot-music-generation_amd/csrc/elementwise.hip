@@ -36,6 +36,16 @@ __global__ __launch_bounds__(256) void k_fill32(uint32_t* __restrict__ p, uint32
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = word;
 }
 
+// the same fill, done only when *cond != 0 (every thread reads the word; whoever changes it does so in a LATER kernel)
+__global__ __launch_bounds__(256) void k_fill32_if(const int* __restrict__ cond, uint32_t* __restrict__ p, uint32_t word, long long n) {
+    if (*cond == 0) return;
+    const long long n4 = n >> 2;
+    const uint4 w4 = make_uint4(word, word, word, word);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        reinterpret_cast<uint4*>(p)[i] = w4;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = word;
+}
+
 // several fills in one launch (blockIdx.y = range): a step needs ~10 small fills, each a ~5 us dispatch on its own
 __global__ __launch_bounds__(256) void k_fill_multi(const FillRanges r) {
     const int k = blockIdx.y;
@@ -393,9 +403,12 @@ __global__ __launch_bounds__(256) void k_sgd_update(const UpdateArgs a) {
 // seen, no read-back needed) and the flag is CLEARED, so that the next step starts clean instead of every later launch
 // bailing out on a stale flag.
 __global__ void k_step_increment(long long* step, const float* loss_src, float loss_scale, float* ring,
-                                 int ring_cap, int* err_flag, long long* counters) {
+                                 int ring_cap, int* err_flag, long long* counters, int* handoff_dirty) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int e = err_flag != nullptr ? *err_flag : 0;
+    // a pass that was aborted by a time-out leaves dh partials in the BPTT inboxes: the next pass refills them (k_fill32_if);
+    // a pass that completed left every word reset by its reader
+    if (handoff_dirty != nullptr) *handoff_dirty = (e == 2) ? 1 : 0;
     const bool peer_timeout = loss_src != nullptr && loss_src[1] != 0.0f;      // loss_src is tail[1]; tail[2] is the indicator
     const bool peer_token = loss_src != nullptr && loss_src[2] != 0.0f;        // tail[3]: some rank's batch held an out-of-range id
     if (e != 0 || peer_timeout || peer_token) {
@@ -560,6 +573,15 @@ hipError_t launch_gather_rows(hipStream_t s, const int* table, const int* idx, i
     return hipGetLastError();
 }
 
+hipError_t launch_fill32_if(hipStream_t s, const int* cond, void* p, uint32_t word, long long n_words) {
+    if (n_words <= 0) return hipSuccess;
+    long long blocks = (n_words / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_fill32_if, dim3((int)blocks), dim3(256), 0, s, cond, (uint32_t*)p, word, n_words);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill32(hipStream_t s, void* p, uint32_t word, long long n_words) {
     if (n_words <= 0) return hipSuccess;
     long long blocks = (n_words / 4 + 255) / 256;
@@ -597,8 +619,8 @@ hipError_t launch_sgd_update(hipStream_t s, const UpdateArgs& a) {
 }
 
 hipError_t launch_step_increment(hipStream_t s, long long* step, const float* loss_src, float loss_scale,
-                                 float* loss_ring, int ring_cap, int* err_flag, long long* counters) {
-    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(64), 0, s, step, loss_src, loss_scale, loss_ring, ring_cap, err_flag, counters);
+                                 float* loss_ring, int ring_cap, int* err_flag, long long* counters, int* handoff_dirty) {
+    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(64), 0, s, step, loss_src, loss_scale, loss_ring, ring_cap, err_flag, counters, handoff_dirty);
     return hipGetLastError();
 }
 

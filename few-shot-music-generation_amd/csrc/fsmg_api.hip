@@ -107,10 +107,14 @@ struct fsmg_model {
     int xcd_max_rows = 128;             // FSMG_XCD_MAX_ROWS: largest sequence count that takes the XCD-local kernels
     bool dp_split = false;              // FSMG_DP_SPLIT=1: fsmg_forward_backward replays TWO graphs (forward + projection gradients | BPTT + the rest) and
                                         // records bucket 0's readiness between them, so its all-reduce runs under the second one
+    int pair_mode = 2;                  // hidden size 1024 (one copy of K_h per XCD pair): 0 = column-split kernels, 1 = pair kernel forward only
+                                        // (6.4 against 7.0 us per step; the backward pair kernel ties with the column-split one), 2 = both directions
     int xcd_variant = -1;               // FSMG_XCD_VARIANT: XCD_* bits for both directions (-1: lstm_xcd_default_variant)
     float* khx = nullptr;
     float* HX = nullptr; int64_t hx_floats = 0;
     float* inboxX = nullptr; int64_t inboxx_floats = 0;
+    int* d_inbox_dirty = nullptr;       // device word: != 0 -> the next BPTT pass refills the inboxes first (set at creation, when the scratch moves,
+                                        // and by k_step_increment after a time-out; a completed pass leaves every word reset by its reader)
     int* tickets = nullptr;             // [TICKET_LAUNCHES][8]
     static constexpr int TICKET_LAUNCHES = 64;
     int ticket_next = 0;
@@ -158,6 +162,10 @@ struct fsmg_model {
 #ifdef FSMG_PHASE_DEBUG
     hipEvent_t ph[8] = {}; bool ph_init = false; int ph_step = 0;      // per handle (was file scope: shared by all handles)
 #endif
+    // gradient exchange inside the library (fsmg_comm_*): RCCL communicator, its stream, the event the compute stream waits on
+    void* comm = nullptr; bool own_comm = false; int world = 1, rank = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_comm = nullptr;
     int lastB = 0;
     bool have_grads = false;
     std::string err;
@@ -425,9 +433,10 @@ int ensure_scratch(fsmg_model* h, int B) {
     const int64_t n_inbox = want_inbox ? lstm_bwd_rs_inbox_floats(rows_rs, (int)Hp) : 0;
     const int64_t o_inbox = place(want_inbox ? 4 * n_inbox : 256);
     // XCD-local kernels: sized for the largest row count they take (not for B, same reason)
-    const int xrows = (h->persist && h->xcd && lstm_xcd_supported(h->xcd_max_rows, (int)Hp)) ? h->xcd_max_rows : 0;
-    const int64_t n_hx = xrows ? lstm_xcd_hx_floats(xrows, (int)T) : 0, n_inx = xrows ? lstm_xcd_inbox_floats(xrows) : 0;
-    const int64_t o_hx = place(xrows ? 4 * n_hx : 256), o_inx = place(xrows ? 4 * n_inx : 256);
+    const int xrows = (h->persist && h->xcd && lstm_xcd_max_rows((int)Hp) > 0 && (Hp == 512 || h->pair_mode >= 1)) ? std::min(h->xcd_max_rows, lstm_xcd_max_rows((int)Hp)) : 0;
+    const int64_t n_hx = xrows ? lstm_xcd_hx_floats(xrows, (int)T, (int)Hp) : 0;
+    const int64_t n_inx = (xrows && (Hp == 512 || h->pair_mode >= 2)) ? lstm_xcd_inbox_floats(xrows, (int)Hp) : 0;
+    const int64_t o_hx = place(xrows ? 4 * n_hx : 256), o_inx = place(n_inx ? 4 * n_inx : 256);
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
     const int64_t o_lg = place(4 * rows * h->V1p), o_dlg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
     const int64_t o_dx = place(4 * rows * h->Ep);
@@ -485,7 +494,8 @@ int ensure_scratch(fsmg_model* h, int B) {
     h->dzF_all = want_dzfa ? (float*)(s + o_dzfa) : nullptr; h->dzfa_floats = n_dzfa;
     h->inbox = want_inbox ? (float*)(s + o_inbox) : nullptr; h->inbox_floats = n_inbox;
     h->HX = xrows ? (float*)(s + o_hx) : nullptr; h->hx_floats = n_hx;
-    h->inboxX = xrows ? (float*)(s + o_inx) : nullptr; h->inboxx_floats = n_inx;
+    h->inboxX = n_inx ? (float*)(s + o_inx) : nullptr; h->inboxx_floats = n_inx;
+    if (h->d_inbox_dirty) { static const int one = 1; HIPCK(h, hipMemcpy(h->d_inbox_dirty, &one, sizeof(int), hipMemcpyHostToDevice)); }
     // pad rows of the fragment buffers are never written: clear once so they hold finite values
     HIPCK(h, hipMemsetAsync(s + o_hf[0], 0, (size_t)(o_dc - o_hf[0]), h->stream));
     h->dC = (float*)(s + o_dc); h->dH = (float*)(s + o_dh); h->logits = (float*)(s + o_lg);
@@ -581,7 +591,7 @@ int ensure_khf(fsmg_model* h) {
         HIPCK(h, launch_repack_kh(h->stream, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
                                   h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
         if (h->khx) HIPCK(h, launch_repack_kh_xcd(h->stream, h->P + h->off_kh[l], h->khx + (size_t)(2 * l) * h->Hp * h->G4,
-                                                  h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4));
+                                                  h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
     }
     h->khf_dirty = false;
     return FSMG_OK;
@@ -657,9 +667,11 @@ struct FillBatch {
 };
 
 // the XCD-local kernels take this row count at this hidden size (and their buffers exist)
-inline bool use_xcd(const fsmg_model* h, int B) {
+inline bool use_xcd(const fsmg_model* h, int B, bool backward = false) {
+    if (h->Hp != 512 && h->pair_mode < (backward ? 2 : 1)) return false;
     return h->persist && h->xcd && h->khx != nullptr && h->HX != nullptr && B <= h->xcd_max_rows && lstm_xcd_supported(B, h->Hp) &&
-           lstm_xcd_hx_floats(B, h->T) <= h->hx_floats && lstm_xcd_inbox_floats(B) <= h->inboxx_floats;
+           lstm_xcd_hx_floats(B, h->T, h->Hp) <= h->hx_floats &&
+           ((h->Hp != 512 && !backward) || lstm_xcd_inbox_floats(B, h->Hp) <= h->inboxx_floats);
 }
 // Two-stream (eager) or single-stream (hipGraph replay) order for a pass over B sequences.  The XCD-local recurrent kernels
 // put a high-priority wave on every SIMD of the chip and spend half of their time in hand-offs; GEMM waves beside them
@@ -668,7 +680,7 @@ inline bool use_xcd(const fsmg_model* h, int B) {
 inline void choose_schedule(fsmg_model* h, int B, bool train = false) {
     h->ov_call = h->overlap && (h->overlap_forced || !use_xcd(h, B));
     h->xov_call = false;
-    if (train && h->xov && !h->ov_call && !h->timing && h->aux != nullptr && use_xcd(h, B) && h->persist_fwd && h->persist_bwd) {
+    if (train && h->xov && h->Hp == 512 && !h->ov_call && !h->timing && h->aux != nullptr && use_xcd(h, B) && h->persist_fwd && h->persist_bwd) {
         const int rpx = lstm_xcd_packed_rows(B);
         h->xov_call = (B + rpx - 1) / rpx < 8;          // packing frees at least one XCD
     }
@@ -780,7 +792,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
         if (xcd) {       // the same for the XCD-local hand-off buffer, and fresh ticket counters for this layer's launches
             GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
             h->ticket_next = 0;
-            const long long step_f = lstm_xcd_hx_floats(B, 0);
+            const long long step_f = lstm_xcd_hx_floats(B, 0, Hp);
             GEMMCK(fills.add(h->HX, 0u, step_f));
             GEMMCK(fills.add(h->HX + step_f, 0xFFFFFFFFu, step_f * T));
             if (xov && top) GEMMCK(fills.add(h->xov_ctl, 0u, 4 + gemm_items(ghead)));
@@ -794,7 +806,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             if (xcd) {
                 ScopedTimer tm(h, "lstm_fwd");
                 LstmFwdXcdArgs a{};
-                a.rpx = rpx; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, true);
+                a.rpx = rpx; a.Hp = Hp; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, true, Hp);
                 a.KhX = h->khx + (size_t)(2 * l) * Hp * G4; a.HX = h->HX; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
                 a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_fwd_xcd(s, a));
@@ -891,7 +903,7 @@ int backward(fsmg_model* h, int B, int part = 0) {
     const Lane mainl = main_lane(h);
     hipStream_t s = h->stream;
     const bool ov = use_overlap(h);
-    const bool xcd = use_xcd(h, B) && h->persist_bwd;
+    const bool xcd = use_xcd(h, B, true) && h->persist_bwd;
     const bool rs = !xcd && h->persist && h->persist_bwd && h->inbox != nullptr && lstm_bwd_rs_supported(B, Hp) && lstm_bwd_rs_inbox_floats(B, Hp) <= h->inbox_floats;
     const bool chain = xcd || rs || (h->persist && h->persist_bwd && h->dzF_all != nullptr && lstm_bwd_chain_supported(B, Hp) &&
                               (int64_t)T * ((B + 15) / 16 * 16) * G4 <= h->dzfa_floats);
@@ -950,7 +962,11 @@ int backward(fsmg_model* h, int B, int part = 0) {
         if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[nch - 1], 0));
         PHASE(4);
         if (xcd) {
-            GEMMCK(fills.add(h->inboxX, 0xFFFFFFFFu, lstm_xcd_inbox_floats(B)));
+            // the dh-partial inboxes are refilled only when the device flag says so: every word a pass writes is read and reset
+            // by its consumer, so a completed pass leaves them all-"not written" (33 MB per pass at hidden 512, 100 MB per
+            // layer at hidden 1024 otherwise)
+            GEMMCK(fills.flush());
+            HIPCK(h, launch_fill32_if(s, h->d_inbox_dirty, h->inboxX, 0xFFFFFFFFu, lstm_xcd_inbox_floats(B, Hp)));
             GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
             h->ticket_next = 0;
         } else if (rs) {        // "not written yet" fill pattern of the dh partial inboxes
@@ -966,7 +982,7 @@ int backward(fsmg_model* h, int B, int part = 0) {
             ScopedTimer tm(h, "lstm_bwd");
             if (xcd) {
                 LstmBwdXcdArgs a{};
-                a.rpx = rpx; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, false);
+                a.rpx = rpx; a.Hp = Hp; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, false, Hp);
                 a.KhXb = h->khx + (size_t)(2 * l + 1) * Hp * G4; a.inbox = h->inboxX; a.Z = h->Z[l]; a.Cs = h->Cs[l];
                 a.dc = h->dC; a.dH = h->dH; a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_bwd_xcd(s, a));
@@ -1075,9 +1091,9 @@ int apply_update(fsmg_model* h, float grad_scale) {
         HIPCK(h, launch_repack_kh(s, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
                                   h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
         if (h->khx) HIPCK(h, launch_repack_kh_xcd(s, h->P + h->off_kh[l], h->khx + (size_t)(2 * l) * h->Hp * h->G4,
-                                                  h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4));
+                                                  h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
     }
-    HIPCK(h, launch_step_increment(s, h->d_step, h->G + h->n_flat + 1, grad_scale, h->d_ring, RING_CAP, h->d_err, h->d_counters));
+    HIPCK(h, launch_step_increment(s, h->d_step, h->G + h->n_flat + 1, grad_scale, h->d_ring, RING_CAP, h->d_err, h->d_counters, h->d_inbox_dirty));
     PHASE(7);
 #ifdef FSMG_PHASE_DEBUG
     phase_report(h);
@@ -1250,9 +1266,87 @@ int after_update(fsmg_model* h, float grad_scale, float* loss) {
     return FSMG_OK;
 }
 
+// ---- RCCL, looked up at run time (the library has no link-time dependency on it; a process that already loaded torch's
+// librccl.so gets that one)
+struct Rccl {
+    typedef struct { char internal[128]; } UniqueId;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+    bool ok = false;
+    Rccl() {
+        static const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        void* lib = nullptr;
+        for (const char* name : names) if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // the copy already in the process first
+        for (const char* name : names) if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { why = "librccl.so not found (dlopen)"; return; }
+        GetUniqueId = (int (*)(UniqueId*))dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (int (*)(void**, int, UniqueId, int))dlsym(lib, "ncclCommInitRank");
+        CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+        AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
+        Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclBroadcast");
+        GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
+        GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
+        GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+        ok = GetUniqueId && CommInitRank && CommDestroy && AllReduce && Broadcast && GroupStart && GroupEnd && GetErrorString;
+        if (!ok) why = "librccl.so lacks an expected symbol";
+    }
+};
+inline Rccl& rccl() { static Rccl r; return r; }
+constexpr int NCCL_FLOAT = 7, NCCL_SUM = 0, NCCL_CHAR = 0;
+#define NCCLCK(h, call)                                                                                   \
+    do {                                                                                                  \
+        const int e_ = (call);                                                                            \
+        if (e_ != 0) return fail(h, FSMG_ERR_HIP, std::string(#call) + ": " + rccl().GetErrorString(e_)); \
+    } while (0)
+
+// sum of the gradient buffer over the ranks: three buckets on the communication stream, each behind its readiness event
+// (bucket 0 = softmax gradients: final behind the projection-gradient GEMMs when the backward pass is cut there); the compute
+// stream (not the host) then waits for the communication stream
+int exchange_gradients(fsmg_model* h) {
+    Rccl& r = rccl();
+    HIPCK(h, hipStreamWaitEvent(h->comm_stream, h->ev_bucket[0], 0));
+    NCCLCK(h, r.AllReduce(h->G + h->off_w, h->G + h->off_w, (size_t)(h->n_flat - h->off_w), NCCL_FLOAT, NCCL_SUM, h->comm, h->comm_stream));
+    HIPCK(h, hipStreamWaitEvent(h->comm_stream, h->ev_bucket[1], 0));
+    NCCLCK(h, r.GroupStart());
+    NCCLCK(h, r.AllReduce(h->G, h->G, (size_t)h->off_w, NCCL_FLOAT, NCCL_SUM, h->comm, h->comm_stream));
+    NCCLCK(h, r.AllReduce(h->G + h->n_flat, h->G + h->n_flat, (size_t)FSMG_GRAD_TAIL, NCCL_FLOAT, NCCL_SUM, h->comm, h->comm_stream));
+    NCCLCK(h, r.GroupEnd());
+    HIPCK(h, hipEventRecord(h->ev_comm, h->comm_stream));
+    HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_comm, 0));
+    return FSMG_OK;
+}
+
+int after_update(fsmg_model* h, float grad_scale, float* loss);
+// the episode-parallel step with the exchange inside the library: forward + backward, all-reduce, clip + Adam (1 / world)
+template <class FB>
+int dp_train_step(fsmg_model* h, float* loss, FB&& forward_backward) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc = forward_backward();
+        if (rc == FSMG_OK) rc = exchange_gradients(h);
+        const float scale = 1.0f / (float)h->world;
+        if (rc == FSMG_OK) {
+            uint32_t bits; std::memcpy(&bits, &scale, 4);
+            rc = run_graphed(h, "up:" + std::to_string(bits), [&]() -> int { return apply_update(h, scale); });
+        }
+        if (rc == FSMG_OK) rc = after_update(h, scale, loss);
+        // a time-out on ANY rank travelled in the reduced tail: every rank skipped the update, reports it here and repeats the
+        // step on per-step launches, in lock-step
+        if (rc == FSMG_ERR_HIP && h->persist_timed_out && attempt == 0) { h->persist_timed_out = false; continue; }
+        return rc;
+    }
+    return FSMG_OK;
+}
+
 // forward + backward + update as ONE captured graph (17 us between two graph launches at cfg-B otherwise)
 template <class Stage>
 int fused_train_step(fsmg_model* h, int32_t N, int32_t K, int32_t Q, float* loss, Stage&& stage) {
+    if (h->comm != nullptr) return dp_train_step(h, loss, [&]() { return forward_backward_core(h, N, K, Q, stage, false); });
     int rc = forward_backward_core(h, N, K, Q, stage, true);
     if (rc == FSMG_OK) rc = after_update(h, 1.0f, loss);
     if (rc == FSMG_ERR_HIP && h->persist_timed_out) {
@@ -1331,6 +1425,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (cfg->gemm == FSMG_GEMM_F32) h->bx3 = 0;
         if (cfg->recurrence == FSMG_RECURRENCE_PER_STEP) h->persist = false;
         if (cfg->recurrence == FSMG_RECURRENCE_COLUMN_SPLIT) h->xcd = false;
+        if (cfg->recurrence == FSMG_RECURRENCE_XCD_LOCAL) h->pair_mode = 2;
         if (cfg->dp_split_backward) h->dp_split = true;
         const char* env = std::getenv("FSMG_OVERLAP");
         if (env) { h->overlap = env[0] != '0'; h->overlap_forced = true; }
@@ -1347,6 +1442,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_XCD")) h->xcd = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_DP_SPLIT")) h->dp_split = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XCD_VARIANT")) h->xcd_variant = std::atoi(e);
+        if (const char* e = std::getenv("FSMG_XCD_PAIR")) h->pair_mode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_XCD_MAX_ROWS")) h->xcd_max_rows = std::max(1, std::min(128, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_PERSIST_FWD")) h->persist_fwd = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_FWD_RT")) h->force_fwd_rt = (e[0] != '0');
@@ -1390,6 +1486,8 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     if (hipMalloc((void**)&small, small_bytes) != hipSuccess) return bail(FSMG_ERR_NOMEM, "hipMalloc(scalars) failed");
     hipMemsetAsync(small, 0, small_bytes, h->stream);
     h->d_step = (long long*)small; h->d_err = (int*)(small + 256); h->d_gnorm = (float*)(small + 512);
+    h->d_inbox_dirty = (int*)(small + 768);
+    { static const int one = 1; hipStreamSynchronize(h->stream); hipMemcpy(h->d_inbox_dirty, &one, sizeof(int), hipMemcpyHostToDevice); }
     h->d_ring = (float*)(small + 1024);
     if (hipHostMalloc((void**)&h->host_counters, 64, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->d_counters, h->host_counters, 0) != hipSuccess)
@@ -1407,7 +1505,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     if (hipMalloc((void**)&h->khf, sizeof(float) * (size_t)h->L * 2 * h->Hp * h->G4) != hipSuccess)
         return bail(FSMG_ERR_NOMEM, "hipMalloc(fragment weights) failed");
     if (h->persist && h->xcd && lstm_xcd_supported(1, h->Hp)) {
-        if (hipMalloc((void**)&h->khx, sizeof(float) * (size_t)h->L * 2 * lstm_xcd_weight_floats()) != hipSuccess)
+        if (hipMalloc((void**)&h->khx, sizeof(float) * (size_t)h->L * 2 * lstm_xcd_weight_floats(h->Hp)) != hipSuccess)
             return bail(FSMG_ERR_NOMEM, "hipMalloc(XCD-local weight images) failed");
     }
     const int b0 = cfg->max_sequences > 0 ? cfg->max_sequences : 45;
@@ -1440,6 +1538,9 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->ev_bucket[1]) hipEventDestroy(h->ev_bucket[1]);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->comm && h->own_comm && rccl().ok) rccl().CommDestroy(h->comm);
+    if (h->ev_comm) hipEventDestroy(h->ev_comm);
+    if (h->comm_stream) hipStreamDestroy(h->comm_stream);
     if (h->aux) hipStreamDestroy(h->aux);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1620,6 +1721,75 @@ int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss) {
     return after_update(h, grad_scale, loss);
 }
 
+// ---- the gradient exchange inside the library
+static int comm_prepare(fsmg_handle h) {
+    if (!rccl().ok) return fail(h, FSMG_ERR_STATE, "RCCL is not available: " + rccl().why);
+    hipSetDevice(h->device);
+    if (!h->comm_stream) HIPCK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    if (!h->ev_comm) HIPCK(h, hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
+    return FSMG_OK;
+}
+
+int fsmg_comm_unique_id(char id[FSMG_COMM_ID_BYTES]) {
+    if (!id) return FSMG_ERR_INVALID;
+    if (!rccl().ok) return fail(nullptr, FSMG_ERR_STATE, "RCCL is not available: " + rccl().why);
+    Rccl::UniqueId u;
+    const int e = rccl().GetUniqueId(&u);
+    if (e != 0) return fail(nullptr, FSMG_ERR_HIP, std::string("ncclGetUniqueId: ") + rccl().GetErrorString(e));
+    std::memcpy(id, u.internal, FSMG_COMM_ID_BYTES);
+    return FSMG_OK;
+}
+
+int fsmg_comm_init(fsmg_handle h, const char id[FSMG_COMM_ID_BYTES], int32_t world_size, int32_t rank) {
+    if (!h || !id || world_size < 1 || rank < 0 || rank >= world_size) return FSMG_ERR_INVALID;
+    if (h->comm) return fail(h, FSMG_ERR_STATE, "a communicator is already attached");
+    int rc = comm_prepare(h);
+    if (rc != FSMG_OK) return rc;
+    Rccl::UniqueId u;
+    std::memcpy(u.internal, id, FSMG_COMM_ID_BYTES);
+    void* c = nullptr;
+    NCCLCK(h, rccl().CommInitRank(&c, world_size, u, rank));
+    h->comm = c; h->own_comm = true; h->world = world_size; h->rank = rank;
+    drop_graphs(h);
+    return FSMG_OK;
+}
+
+int fsmg_comm_attach(fsmg_handle h, void* nccl_comm, int32_t world_size, int32_t rank) {
+    if (!h || !nccl_comm || world_size < 1 || rank < 0 || rank >= world_size) return FSMG_ERR_INVALID;
+    if (h->comm) return fail(h, FSMG_ERR_STATE, "a communicator is already attached");
+    int rc = comm_prepare(h);
+    if (rc != FSMG_OK) return rc;
+    h->comm = nccl_comm; h->own_comm = false; h->world = world_size; h->rank = rank;
+    drop_graphs(h);
+    return FSMG_OK;
+}
+
+int fsmg_comm_broadcast_state(fsmg_handle h, int32_t root) {
+    if (!h) return FSMG_ERR_INVALID;
+    if (!h->comm || root < 0 || root >= h->world) return fail(h, FSMG_ERR_STATE, "no communicator attached / bad root");
+    hipSetDevice(h->device);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    NCCLCK(h, rccl().GroupStart());
+    NCCLCK(h, rccl().Broadcast(h->P, h->P, (size_t)h->n_flat, NCCL_FLOAT, root, h->comm, h->comm_stream));
+    NCCLCK(h, rccl().Broadcast(h->M, h->M, (size_t)2 * h->n_flat, NCCL_FLOAT, root, h->comm, h->comm_stream));     // m and v are adjacent
+    NCCLCK(h, rccl().Broadcast(h->d_step, h->d_step, sizeof(long long), NCCL_CHAR, root, h->comm, h->comm_stream));
+    NCCLCK(h, rccl().GroupEnd());
+    HIPCK(h, hipStreamSynchronize(h->comm_stream));
+    h->khf_dirty = true;
+    return FSMG_OK;
+}
+
+int fsmg_comm_release(fsmg_handle h) {
+    if (!h) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIPCK(h, hipStreamSynchronize(h->comm_stream));
+    if (h->comm && h->own_comm && rccl().ok) rccl().CommDestroy(h->comm);
+    h->comm = nullptr; h->own_comm = false; h->world = 1; h->rank = 0;
+    drop_graphs(h);
+    return FSMG_OK;
+}
+
 int fsmg_train_step(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K, int32_t Q,
                     int32_t tokens_on_device, float* loss) {
     if (!h || !support || !query) return FSMG_ERR_INVALID;
@@ -1649,6 +1819,8 @@ int fsmg_maml_forward_backward(fsmg_handle h, const int32_t* support, const int3
 
 int fsmg_maml_step(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K, int32_t Q,
                    int32_t inner_steps, float inner_lr, int32_t tokens_on_device, float* loss) {
+    if (h && h->comm != nullptr)           // per-rank inner loop (no communication), query gradients exchanged like a plain step's
+        return dp_train_step(h, loss, [&]() { return fsmg_maml_forward_backward(h, support, query, N, K, Q, inner_steps, inner_lr, tokens_on_device); });
     int rc = fsmg_maml_forward_backward(h, support, query, N, K, Q, inner_steps, inner_lr, tokens_on_device);
     if (rc != FSMG_OK) return rc;
     rc = fsmg_apply_update(h, 1.0f, loss);

@@ -148,7 +148,7 @@ hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* b
 // variants of the XCD-local kernels (same results, different schedules of the cell threads' memory traffic)
 enum { XCD_DEFER_OUTPUTS = 16,      // forward: c / h / gate stores of step t are issued behind the poll of step t+1; backward: dz stores behind the drain
        XCD_NO_POLL_SLEEP = 32 };    // no s_sleep between two polls of a hand-off
-int lstm_xcd_default_variant(int B, bool forward);
+int lstm_xcd_default_variant(int B, bool forward, int Hp = 512);
 struct LstmFwdXcdArgs {
     const float* KhX;     // forward register image of K_h (launch_repack_kh_xcd)
     float* HX;            // [T+1][8][4][RG][2][64][4] hand-off buffer; index 0 = zero state, t0+1 .. t1 = 0xFF fill
@@ -162,6 +162,7 @@ struct LstmFwdXcdArgs {
     unsigned long long* prof;   // != nullptr: instrumented build, [256 blocks][4 waves][8] tick sums per phase (RG = 2 only)
     int rpx;                    // rows per XCD; 0 = ceil(B / 8).  lstm_xcd_packed_rows(B) packs the batch on the first XCDs
     int variant;                // XCD_* bits; lstm_xcd_default_variant(B, forward) has the measured choice
+    int Hp;                     // 512 (0 = 512): one copy of K_h per XCD; 1024: one copy per XCD PAIR (k_lstm_fwd_pair)
 };
 struct LstmBwdXcdArgs {
     const float* KhXb;    // backward register image of K_h
@@ -177,13 +178,15 @@ struct LstmBwdXcdArgs {
     unsigned long long* prof;
     int rpx;              // as LstmFwdXcdArgs
     int variant;          // as LstmFwdXcdArgs
+    int Hp;               // as LstmFwdXcdArgs
 };
-bool lstm_xcd_supported(int B, int Hp);
-long long lstm_xcd_hx_floats(int B, int T);
-long long lstm_xcd_inbox_floats(int B);
-long long lstm_xcd_weight_floats();           // floats per register image
-int lstm_xcd_packed_rows(int B);               // rows per XCD that leave whole XCDs free without adding row groups
-hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd);
+bool lstm_xcd_supported(int B, int Hp);        // Hp 512: up to 128 rows; Hp 1024 (one copy of K_h per XCD pair): up to 64 rows
+int lstm_xcd_max_rows(int Hp);                 // 128 / 64 / 0
+long long lstm_xcd_hx_floats(int B, int T, int Hp = 512);
+long long lstm_xcd_inbox_floats(int B, int Hp = 512);
+long long lstm_xcd_weight_floats(int Hp = 512);   // floats per register image
+int lstm_xcd_packed_rows(int B);               // rows per XCD that leave whole XCDs free without adding row groups (hidden 512)
+hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp = 512);
 hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a);
 hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);
 
@@ -196,6 +199,8 @@ hipError_t launch_fill_multi(hipStream_t s, const FillRanges& r);
 hipError_t launch_gather_rows(hipStream_t s, const int* table, const int* idx, int n_rows, int T, int n_songs, int* out, int* err_flag);
 // p[0 .. n_words) = word (p 16-byte aligned); the step uses this instead of hipMemsetAsync so that its hipGraph holds kernel nodes only
 hipError_t launch_fill32(hipStream_t s, void* p, uint32_t word, long long n_words);
+// the same, skipped on the device when *cond == 0
+hipError_t launch_fill32_if(hipStream_t s, const int* cond, void* p, uint32_t word, long long n_words);
 // tokens [nseq][T] (support rows then query rows) -> time-major input ids X[t][b] (start word at t=0)
 // and targets Y[t][b]; sets *err_flag if any id is outside [0, vocab).
 hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, const int* query, int n_query,
@@ -233,7 +238,7 @@ hipError_t launch_sgd_update(hipStream_t s, const UpdateArgs& a);
 // all-reduced time-out indicator tail[2] is set, tallies it in counters ([0] time-outs, [1] token-range rejections;
 // host-mapped memory) and clears the flag
 hipError_t launch_step_increment(hipStream_t s, long long* step, const float* loss_src, float loss_scale,
-                                 float* loss_ring, int ring_cap, int* err_flag, long long* counters);
+                                 float* loss_ring, int ring_cap, int* err_flag, long long* counters, int* handoff_dirty = nullptr);
 // dst[0] = (float) sum of partials[0..n) (fixed order)
 hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst, const int* flag_src = nullptr);
 // greedy decode step pieces (sample)

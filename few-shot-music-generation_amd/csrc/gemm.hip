@@ -516,9 +516,9 @@ __global__ __launch_bounds__(256, 4) void k_gemm_queue(const GemmArgs g) {
 //     a b ~= a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2),   dropped: a2 b3 + a3 b2 + a3 b3 <= 2^-23 |a b|
 // i.e. one half-ulp of the fp32 product, unbiased -- the accumulation (fp32, as in the fp32 MFMA) dominates the error
 // either way.  6 MFMAs of 32x32x16 (32 cycles each) replace 8 of 32x32x2 (64 cycles each) per 16 k: 2.67x the rate.
-// (Finite inputs below bf16's largest value, 3.39e38, that is.  Beyond it, and for Inf, the leading piece comes back finite
-// from v_cvt_pk_bf16_f32 and the product is finite and huge where the fp32 MFMA produces Inf -- measured, pinned by
-// tests/test_gpu_parity.py::test_non_finite_weights_saturate_...; NaN inputs give NaN in both.)
+// (Finite inputs, that is -- values above bf16's largest, 3.39e38, included: measured finite.  An Inf operand makes the
+// second piece NaN (bf16(Inf - Inf)) and the products it feeds NaN where the fp32 MFMA produces Inf; pinned by
+// tests/test_gpu_parity.py::test_non_finite_weights_give_nan_...; NaN inputs give NaN in both.)
 // The split runs on the VALU between the global load and the LDS write (5.5 instructions per element), the LDS holds
 // the three planes as [plane][k half][128 x][8 bf16] so that a fragment is one conflict-free ds_read_b128 per lane.
 // Same tiling, epilogue, split-K and XCD-aware tile order as k_gemm; same A / B conventions.

@@ -470,31 +470,371 @@ __global__ void k_repack_kh_xcd(const float* __restrict__ Kh, float* __restrict_
     }
 }
 
+// ================================================================ XCD-PAIR-local recurrence, hidden size 1024 (cfg-C / cfg-E)
+// K_h of a 1024-unit layer is 16 MiB in fp32 -- exactly the register file of one XCD, so a copy cannot live in one XCD beside
+// anything else.  It lives in the registers of an XCD PAIR instead: 64 CUs x 4 waves x 256 weight VGPRs.  The chip holds four
+// copies, the batch is split four ways (ceil(B / 4) rows per pair: 12 at B = 45 = THREE full row groups, no padding), and h_t /
+// the dh partials are handed around inside a pair only -- 2 of the 8 XCDs take part in a step's exchange instead of all 8
+// as in the column-split kernels of lstm_step.hip (round 1: 7.0 / 9.2 us per step at cfg-C).
+// Differences from the one-XCD kernels above: a hand-off crosses an XCD boundary for half of its producers, so every hand-off
+// store is write-through (`sc1`: the line leaves the writer's L2) and every hand-off load an `sc1` load; a wave's K slice is 256
+// wide (four fragments per row group, 256 MFMAs per row group and step); the BPTT inbox is laid out [dest][row group]
+// [producer][unit], so that a lane's words of one row group differ in the producer only and three row groups need no padding.
+// Measured (profiles/r03_pair_probe1.log, B = 45, T = 50): forward 6.38 us per step (37.6 % of the fp32-MFMA peak) against 7.0 for
+// the column-split kernel, backward 9.26 against 9.2 -- the MFMA floor is 2.8 us, the rest is the cross-XCD hand-off, which costs
+// the same three microseconds whether 2 or 8 XCDs take part.  A variant with separate flag words (producer: tile -> wait for
+// the write-through acknowledgement -> one dword per consumer wave; consumer: poll 64 bytes, fetch the 12 KB once, no data
+// resets) was built too and is slower (9.68 / 9.58, profiles/r03_pair_probe2.log): three serialised fabric round trips instead
+// of one.  So these kernels are correct, tested and NOT the default at hidden size 1024 (fsmg_config.recurrence =
+// FSMG_RECURRENCE_XCD_LOCAL selects them); what would pay here is several independent row-group chains per pair (the
+// hand-off is longer than a chain's MFMA phase) -- see DESIGN.md section 4.
+constexpr int PH = 1024, PG4 = 4 * PH;
+constexpr int PNX = 2, PGRP = NXCD / PNX;       // XCDs per weight copy; copies (= row splits) on the chip
+constexpr int PCU = NCU * PNX;                  // CUs per copy
+constexpr int PKW = PH / 4;                     // K range of a wave
+constexpr int PNQ = PKW / 64;                   // hand-off fragments per wave and row group
+constexpr int PNW = PKW / 4;                    // 16-byte weight words per lane (64 -> 256 VGPRs)
+
+// HX  [T+1][4 pairs][4 w][RG][4 q][64 lanes][4], KhX [64 cu][4 w][64][64 lanes][4] (k_repack_kh_pair)
+template <int RG>
+__global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair(const LstmFwdXcdArgs a) {
+    constexpr int NF = PNQ * RG;
+    __shared__ __attribute__((aligned(16))) float red[2][RG][4][64 * 4];
+    __shared__ int s_role[2];
+    __shared__ int s_fail;
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_fail = 0;
+    Role role;
+    if (!take_role(a.tickets, a.err_flag, s_role, role)) return;
+    const int grp = role.xcd / PNX, cu = (role.xcd % PNX) * NCU + role.cu;
+    const int B = a.B;
+    const int rpx = a.rpx > 0 ? a.rpx : (B + PGRP - 1) / PGRP, row0 = grp * rpx;
+    if (row0 >= B) return;
+
+    f32x4 W[PNW];
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.KhX) + ((size_t)(cu * 4 + wave) * PNW) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < PNW; ++i) W[i] = wp[i * 64];
+    }
+    const int ci = lane >> 4, cbb = (lane >> 2) & 3, ce = lane & 3;
+    const int lrow = 4 * wave + ci, row = row0 + lrow, unit = 16 * cu + 4 * cbb + ce;
+    const bool cellw = wave < RG;
+    const bool act = cellw && lrow < rpx && row < B;
+    float cp = act ? a.Cs[((size_t)a.t0 * B + row) * PH + unit] : 0.0f;
+    const size_t hx_step = (size_t)PGRP * 4 * RG * PNQ * 64;
+    const f32x4* hx_in = reinterpret_cast<const f32x4*>(a.HX) + (((size_t)grp * 4 + wave) * RG) * PNQ * 64 + lane;
+    // CU c produces k = 16 c .. 16 c + 15: wave c / 16, fragment (c / 4) % 4, lanes 16 (c % 4) .. + 15 of it
+    f32x4* hx_out = reinterpret_cast<f32x4*>(a.HX) + ((((size_t)grp * 4 + (cu >> 4)) * RG + wave) * PNQ + ((cu >> 2) & 3)) * 64 +
+                    16 * (cu & 3) + 4 * cbb + ci;
+    const int wofs = ((lane >> 4) * 4 + (lane & 3)) * 4 + ((lane >> 2) & 3);
+    float zq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float o_c = 0.f, o_hh = 0.f, o_g[4] = {0.f, 0.f, 0.f, 0.f};
+    bool o_have = false;
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (a.t0 + k < a.t1) {
+                const float* zn = a.Z + ((size_t)(a.t0 + k) * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) zq[k][g] = zn[4 * g];
+            }
+    }
+
+    for (int t = a.t0; t < a.t1; ++t) {
+        f32x4 av[NF];
+        {
+            const bool fail = !wait_all_fragments<NF>(hx_in + (size_t)t * hx_step, av, a.spin_limit, a.err_flag, (a.variant & XCD_NO_POLL_SLEEP) != 0);
+            if (fail && lane == 0) {
+                __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_fail = 1;
+            }
+        }
+        if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {          // outputs of the step before: behind a successful poll, under the MFMAs
+            a.Cs[((size_t)t * B + row) * PH + unit] = o_c;
+            a.Hs[((size_t)t * B + row) * PH + unit] = o_hh;
+            float* zo = a.Z + ((size_t)(t - 1) * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
+            zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+        }
+        float zin[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { zin[g] = zq[0][g]; zq[0][g] = zq[1][g]; zq[1][g] = 0.0f; }
+        float* zp = a.Z + ((size_t)t * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
+        if (act && t + 2 < a.t1) {
+            const float* zn = zp + 2 * (size_t)B * PG4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) zq[1][g] = zn[4 * g];
+        }
+        f32x4 acc[RG];
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define PAIR_FWD_B(B_)                                                                   \
+        _Pragma("unroll") for (int rg = 0; rg < RG; ++rg) { XCD_MFMA_B(B_, av[PNQ * rg + q], W[16 * q + B_], acc[rg]) }
+#pragma unroll
+        for (int q = 0; q < PNQ; ++q) {
+            PAIR_FWD_B(0) PAIR_FWD_B(1) PAIR_FWD_B(2) PAIR_FWD_B(3) PAIR_FWD_B(4) PAIR_FWD_B(5) PAIR_FWD_B(6) PAIR_FWD_B(7)
+            PAIR_FWD_B(8) PAIR_FWD_B(9) PAIR_FWD_B(10) PAIR_FWD_B(11) PAIR_FWD_B(12) PAIR_FWD_B(13) PAIR_FWD_B(14) PAIR_FWD_B(15)
+        }
+#undef PAIR_FWD_B
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+            float* rp = &red[t & 1][rg][wave][0] + wofs;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rp[64 * i] = acc[rg][i];
+        }
+        __syncthreads();
+        if (s_fail) return;
+
+        if (cellw) {
+            float hn = 0.0f, g_si = 0.f, g_tj = 0.f, g_sf = 0.f, g_so = 0.f;
+            if (act) {
+                const f32x4* rsrc = reinterpret_cast<const f32x4*>(&red[t & 1][wave][0][0]) + lane;
+                const f32x4 r0 = rsrc[0], r1 = rsrc[64], r2 = rsrc[128], r3 = rsrc[192];
+                float zg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float zs = 0.0f;
+                    zs += r0[g]; zs += r1[g]; zs += r2[g]; zs += r3[g];
+                    zg[g] = zin[g] + zs;
+                }
+                const CellOut co = cell_forward(zg, cp);
+                hn = co.h; cp = co.c;
+                g_si = co.si; g_tj = co.tj; g_sf = co.sf; g_so = co.so;
+            }
+            f32x4 hv;
+            hv[0] = quad_bcast<0>(hn); hv[1] = quad_bcast<1>(hn); hv[2] = quad_bcast<2>(hn); hv[3] = quad_bcast<3>(hn);
+            if (ce == 0) store_sc1(hx_out + (size_t)(t + 1) * hx_step, hv);       // write-through: half of the consumers sit on the other XCD
+            if (a.variant & XCD_DEFER_OUTPUTS) {
+                o_c = cp; o_hh = hn; o_g[0] = g_si; o_g[1] = g_tj; o_g[2] = g_sf; o_g[3] = g_so; o_have = true;
+            } else if (act) {
+                a.Cs[((size_t)(t + 1) * B + row) * PH + unit] = cp;
+                a.Hs[((size_t)(t + 1) * B + row) * PH + unit] = hn;
+                zp[0] = g_si; zp[4] = g_tj; zp[8] = g_sf; zp[12] = g_so;
+            }
+        }
+    }
+    if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {
+        a.Cs[((size_t)a.t1 * B + row) * PH + unit] = o_c;
+        a.Hs[((size_t)a.t1 * B + row) * PH + unit] = o_hh;
+        float* zo = a.Z + ((size_t)(a.t1 - 1) * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
+        zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+    }
+}
+
+// inbox [2 slots][4 pairs][64 dest][RG][64 producers][16 units][4 rows]; KhXb [64 cu][4 w][64][64 lanes][4]
+template <int RG>
+__global__ __launch_bounds__(256, 1) void k_lstm_bwd_pair(const LstmBwdXcdArgs a) {
+    constexpr int LPR = 4;                        // inbox words per lane and row group: 16 producers x 16 units / 64 lanes
+    __shared__ __attribute__((aligned(16))) float psum[RG][4][64][4];
+    __shared__ __attribute__((aligned(16))) float dzA[RG][64][4];
+    __shared__ int s_role[2];
+    __shared__ int s_fail;
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_fail = 0;
+    Role role;
+    if (!take_role(a.tickets, a.err_flag, s_role, role)) return;
+    const int grp = role.xcd / PNX, cu = (role.xcd % PNX) * NCU + role.cu;
+    const int B = a.B;
+    const int rpx = a.rpx > 0 ? a.rpx : (B + PGRP - 1) / PGRP, row0 = grp * rpx;
+    if (row0 >= B) return;
+
+    f32x4 W[PNW];         // component e' of word i = weight register 4i + e' = (cg = /64, k = %64): Kh[256w + 64cg + lane][64cu + k]
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.KhXb) + ((size_t)(cu * 4 + wave) * PNW) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < PNW; ++i) W[i] = wp[i * 64];
+    }
+    const int ci = lane >> 4, cbb = (lane >> 2) & 3, ce = lane & 3;
+    const int lrow = 4 * wave + ci, row = row0 + lrow, unit = 16 * cu + 4 * cbb + ce;
+    const bool cellw = wave < RG;
+    const bool act = cellw && lrow < rpx && row < B;
+    const size_t hi = (size_t)row * PH + unit;
+    float dcv = act ? a.dc[hi] : 0.0f;
+    const size_t slot_w = (size_t)PGRP * PCU * RG * PCU * 16;                // f32x4 words per slot
+    f32x4* const inbox = reinterpret_cast<f32x4*>(a.inbox);
+
+    // consumer: (dest = cu, row group rg): 64 producers x 16 units; wave w takes producers 16w .. 16w+15, 4 words per lane
+    const size_t in_base = (((size_t)grp * PCU + cu) * RG) * PCU * 16 + (size_t)(16 * wave) * 16 + lane;
+    // producer: lane l of column group cg -> destination 16w + 4cg + l/16, word (dest, rg, producer = cu, l % 16)
+    size_t out_ofs[4];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg)
+        out_ofs[cg] = (((size_t)grp * PCU + 16 * wave + 4 * cg + (lane >> 4)) * RG) * PCU * 16 + (size_t)cu * 16 + (lane & 15);
+    const f32x4 fill = f32x4{__uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu)};
+
+    float n_si = 0.f, n_tj = 0.f, n_sf = 0.f, n_so = 0.f, n_ct = 0.f, n_cp = 0.f, n_dh = 0.f;
+    if (act && a.t1 > a.t0) {
+        const int t = a.t1 - 1;
+        const float* gp = a.Z + ((size_t)t * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
+        n_si = gp[0]; n_tj = gp[4]; n_sf = gp[8]; n_so = gp[12];
+        n_ct = a.Cs[(size_t)(t + 1) * B * PH + hi]; n_cp = a.Cs[(size_t)t * B * PH + hi];
+        n_dh = a.dH[(size_t)t * B * PH + hi];
+    }
+
+    for (int t = a.t1 - 1; t >= a.t0; --t) {
+        const float si = n_si, tj = n_tj, sf = n_sf, so = n_so, ct = n_ct, cpv = n_cp, dht = n_dh;
+        float* gp = a.Z + ((size_t)t * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
+        // ---- A: consume
+        f32x4 wsum[RG];
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) wsum[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < a.T) {
+            f32x4* in = inbox + (size_t)((t + 1) & 1) * slot_w + in_base;
+            f32x4 v[RG][LPR];
+            bool fail = false;
+            for (int spins = 0;; ++spins) {
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                    for (int k = 0; k < LPR; ++k) v[rg][k] = load_sc1(in + (size_t)rg * PCU * 16 + k * 64);
+                drain_vmem();
+                bool ok = true;
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                    for (int k = 0; k < LPR; ++k) { asm volatile("" : "+v"(v[rg][k])); ok &= frag_ready(v[rg][k]); }
+                if (__all(ok)) break;
+                if (!(a.variant & XCD_NO_POLL_SLEEP)) __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
+                if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+            }
+            if (fail && lane == 0) {
+                __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_fail = 1;
+            }
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                for (int k = 0; k < LPR; ++k) {
+                    store_sc1(in + (size_t)rg * PCU * 16 + k * 64, fill);
+                    wsum[rg] = (k == 0) ? v[rg][0] : wsum[rg] + v[rg][k];
+                }
+        }
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) *reinterpret_cast<f32x4*>(&psum[rg][wave][lane][0]) = wsum[rg];
+        __syncthreads();
+        if (s_fail) return;
+
+        // ---- B: gate gradients (wave rg < RG: lane = 16 i + 4 bb + e); lane group l/16 of a wave holds producers 16w + 4k + l/16
+        float di = 0.f, dj = 0.f, df = 0.f, dg = 0.f;
+        if (cellw) {
+            if (act) {
+                float dh_rec = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        dh_rec += psum[wave][w][16 * g4 + 4 * cbb + ce][ci];
+                const CellGrad cg = cell_backward(si, tj, sf, so, ct, cpv, dcv, dht + dh_rec);
+                di = cg.di; dj = cg.dj; df = cg.df; dg = cg.dg;
+                if (!(a.variant & XCD_DEFER_OUTPUTS)) { gp[0] = di; gp[4] = dj; gp[8] = df; gp[12] = dg; }
+                dcv = cg.dc_out;
+            }
+            float* f = &dzA[wave][4 * ce + ci][cbb];
+            f[0] = di; f[16 * 4] = dj; f[32 * 4] = df; f[48 * 4] = dg;
+        }
+        __syncthreads();
+        drain_vmem();                      // resets (and dz stores) landed before anything is published: see k_lstm_bwd_xcd
+        if ((a.variant & XCD_DEFER_OUTPUTS) && act) { gp[0] = di; gp[4] = dj; gp[8] = df; gp[12] = dg; }
+        if (act && t > a.t0) {
+            const float* gn = a.Z + ((size_t)(t - 1) * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
+            n_si = gn[0]; n_tj = gn[4]; n_sf = gn[8]; n_so = gn[12];
+            n_ct = cpv; n_cp = a.Cs[(size_t)(t - 1) * B * PH + hi];
+            n_dh = a.dH[(size_t)(t - 1) * B * PH + hi];
+        }
+
+        // ---- C: produce the partials of dh_{t-1}: 256 destination units per wave = 4 column groups of 64
+        if (t > 0) {
+            f32x4 av[RG];
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) av[rg] = *reinterpret_cast<const f32x4*>(&dzA[rg][lane][0]);
+            f32x4 acc[RG][4];
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) acc[rg][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define PAIR_BWD_B(B_)                                                                                      \
+            _Pragma("unroll") for (int rg = 0; rg < RG; ++rg)                                               \
+                _Pragma("unroll") for (int cg = 0; cg < 4; ++cg)                                            \
+                    acc[rg][cg] = mfma44<B_>(av[rg][v], W[16 * cg + 4 * v + (B_ >> 2)][B_ & 3], acc[rg][cg]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                PAIR_BWD_B(0) PAIR_BWD_B(1) PAIR_BWD_B(2) PAIR_BWD_B(3) PAIR_BWD_B(4) PAIR_BWD_B(5) PAIR_BWD_B(6) PAIR_BWD_B(7)
+                PAIR_BWD_B(8) PAIR_BWD_B(9) PAIR_BWD_B(10) PAIR_BWD_B(11) PAIR_BWD_B(12) PAIR_BWD_B(13) PAIR_BWD_B(14) PAIR_BWD_B(15)
+            }
+#undef PAIR_BWD_B
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            f32x4* out = inbox + (size_t)(t & 1) * slot_w;
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) store_sc1(out + out_ofs[cg] + (size_t)rg * PCU * 16, acc[rg][cg]);
+        }
+    }
+    if (act) a.dc[hi] = dcv;
+}
+
+// Kh [1024][4096] (packed gate columns) -> the register images of the pair kernels (same convention as k_repack_kh_xcd):
+//   fwd word i (= 16q + b, q < 4), component e of (cu, w), lane l:  Kh[256w + 64q + 16(b/4) + 4(b%4) + e][64cu + l]
+//   bwd word i, component e' of (cu, w), lane l, r = 4i + e' = 64cg + k (cg < 4):  Kh[256w + 64cg + l][64cu + k]
+__global__ void k_repack_kh_pair(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd) {
+    const int total = PCU * 4 * PNW * 64;           // f32x4 words per copy
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int l = idx & 63, i = (idx >> 6) & 63, w = (idx >> 12) & 3, cu = idx >> 14;
+        {
+            const int q = i >> 4, b = i & 15;
+            const int k0 = PKW * w + 64 * q + 16 * (b >> 2) + 4 * (b & 3);
+            const float* src = Kh + (size_t)k0 * PG4 + 64 * cu + l;
+            float4 v;
+            v.x = src[0]; v.y = src[PG4]; v.z = src[2 * (size_t)PG4]; v.w = src[3 * (size_t)PG4];
+            reinterpret_cast<float4*>(fwd)[idx] = v;
+        }
+        {
+            const int r = 4 * i, cg = r >> 6, k = r & 63;
+            reinterpret_cast<float4*>(bwd)[idx] =
+                *reinterpret_cast<const float4*>(Kh + (size_t)(PKW * w + 64 * cg + l) * PG4 + 64 * cu + k);
+        }
+    }
+}
+
 }  // namespace
 
-static int xcd_row_groups(int B) {
+// row groups of 4 rows per weight copy: hidden 512 -> 8 copies (one per XCD), 3 is padded to 4 (the lane mapping of
+// k_lstm_bwd_xcd needs a divisor of 4); hidden 1024 -> 4 copies (one per XCD pair), 1 .. 4
+static int xcd_row_groups(int B, int Hp = XH) {
+    if (Hp == PH) return ((B + PGRP - 1) / PGRP + 3) / 4;
     const int rpx = (B + NXCD - 1) / NXCD;
     const int rg = (rpx + 3) / 4;
     return rg == 3 ? 4 : rg;
 }
 
-bool lstm_xcd_supported(int B, int Hp) { return Hp == XH && B >= 1 && xcd_row_groups(B) <= 4; }
+bool lstm_xcd_supported(int B, int Hp) { return (Hp == XH || Hp == PH) && B >= 1 && xcd_row_groups(B, Hp) <= 4; }
+int lstm_xcd_max_rows(int Hp) { return Hp == PH ? 16 * PGRP : (Hp == XH ? 16 * NXCD : 0); }
 
-long long lstm_xcd_hx_floats(int B, int T) { return (long long)(T + 1) * NXCD * 4 * xcd_row_groups(B) * 2 * 64 * 4; }
-long long lstm_xcd_inbox_floats(int B) { return 2LL * NXCD * NCU * NCU * xcd_row_groups(B) * 16 * 4; }
-long long lstm_xcd_weight_floats() { return (long long)XH * XG4; }
+long long lstm_xcd_hx_floats(int B, int T, int Hp) {
+    if (Hp == PH) return (long long)(T + 1) * PGRP * 4 * xcd_row_groups(B, Hp) * PNQ * 64 * 4;
+    return (long long)(T + 1) * NXCD * 4 * xcd_row_groups(B) * 2 * 64 * 4;
+}
+long long lstm_xcd_inbox_floats(int B, int Hp) {
+    if (Hp == PH) return 2LL * PGRP * PCU * xcd_row_groups(B, Hp) * PCU * 16 * 4;
+    return 2LL * NXCD * NCU * NCU * xcd_row_groups(B) * 16 * 4;
+}
+long long lstm_xcd_weight_floats(int Hp) { return (long long)Hp * 4 * Hp; }
 // Rows per XCD that fill the row groups the 8-way split already pays for: the batch then sits on the first
 // ceil(B / rows) XCDs and the others are free for another stream's GEMMs (B = 45: 8 rows on 6 XCDs instead of 6 on 8).
 int lstm_xcd_packed_rows(int B) { return 4 * xcd_row_groups(B); }
-
-hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd) {
-    hipLaunchKernelGGL(k_repack_kh_xcd, dim3(1024), dim3(256), 0, s, Kh, fwd, bwd);
+hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp) {
+    if (Hp == PH) hipLaunchKernelGGL(k_repack_kh_pair, dim3(2048), dim3(256), 0, s, Kh, fwd, bwd);
+    else hipLaunchKernelGGL(k_repack_kh_xcd, dim3(1024), dim3(256), 0, s, Kh, fwd, bwd);
     return hipGetLastError();
 }
 
 // Variants chosen per shape (tools/xcd_chain_bench, profiles/r03_xcd_probe6*.log; B = 45: forward 2.21 -> 2.14 us per step with
 // the outputs deferred, backward 2.40 -> 2.34 without the sleep; B = 100: deferring costs 4 %, no sleep is neutral)
-int lstm_xcd_default_variant(int B, bool forward) {
+int lstm_xcd_default_variant(int B, bool forward, int Hp) {
+    if (Hp == PH) return XCD_NO_POLL_SLEEP;
     if (!forward) return XCD_NO_POLL_SLEEP;
     return xcd_row_groups(B) <= 2 ? (XCD_DEFER_OUTPUTS | XCD_NO_POLL_SLEEP) : XCD_NO_POLL_SLEEP;
 }
@@ -502,6 +842,17 @@ int lstm_xcd_default_variant(int B, bool forward) {
 hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {
     if (a.t1 <= a.t0) return hipSuccess;
     const dim3 grid(NXCD * NCU), block(256);
+    if (a.Hp == PH) {
+        if (a.prof) return hipErrorInvalidValue;
+        switch (xcd_row_groups(a.B, PH)) {
+            case 1: hipLaunchKernelGGL((k_lstm_fwd_pair<1>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((k_lstm_fwd_pair<2>), grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((k_lstm_fwd_pair<3>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((k_lstm_fwd_pair<4>), grid, block, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (a.prof) {
         if (xcd_row_groups(a.B) != 2) return hipErrorInvalidValue;
         hipLaunchKernelGGL((k_lstm_fwd_xcd<2, true>), grid, block, 0, s, a);
@@ -519,6 +870,17 @@ hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {
 hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a) {
     if (a.t1 <= a.t0) return hipSuccess;
     const dim3 grid(NXCD * NCU), block(256);
+    if (a.Hp == PH) {
+        if (a.prof) return hipErrorInvalidValue;
+        switch (xcd_row_groups(a.B, PH)) {
+            case 1: hipLaunchKernelGGL((k_lstm_bwd_pair<1>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((k_lstm_bwd_pair<2>), grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((k_lstm_bwd_pair<3>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((k_lstm_bwd_pair<4>), grid, block, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (a.prof) {
         if (xcd_row_groups(a.B) != 2) return hipErrorInvalidValue;
         hipLaunchKernelGGL((k_lstm_bwd_xcd<2, true>), grid, block, 0, s, a);

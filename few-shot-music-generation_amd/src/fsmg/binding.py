@@ -70,6 +70,11 @@ SIGNATURES = {
     'fsmg_grad_bucket': (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
     'fsmg_stream_wait_bucket': (C.c_int, [_P, _P, C.c_int32]),
     'fsmg_apply_update': (C.c_int, [_P, C.c_float, _F32P]),
+    'fsmg_comm_unique_id': (C.c_int, [C.c_char_p]),
+    'fsmg_comm_init': (C.c_int, [_P, C.c_char_p, C.c_int32, C.c_int32]),
+    'fsmg_comm_attach': (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    'fsmg_comm_broadcast_state': (C.c_int, [_P, C.c_int32]),
+    'fsmg_comm_release': (C.c_int, [_P]),
     'fsmg_upload_table': (C.c_int, [_P, C.c_int32, _P, C.c_int64]),
     'fsmg_forward_backward_indexed': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32]),
     'fsmg_train_step_indexed': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _F32P]),
@@ -285,6 +290,28 @@ class FsmgModel(object):
         loss = C.c_float()
         self._ck(self._lib.fsmg_apply_update(self._h, float(grad_scale), C.byref(loss) if want_loss else None))
         return loss.value if want_loss else None
+
+    # -- gradient exchange inside the library (RCCL) ---------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        '''rank 0: 128 opaque bytes to hand to every rank (ncclGetUniqueId)'''
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.fsmg_comm_unique_id(buf)
+        if rc != 0:
+            raise FsmgError(rc, lib.fsmg_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, world_size, rank):
+        '''collective: every rank of the job calls it with the id rank 0 made; from then on train_step / train_step_indexed /
+        maml_step exchange the gradients themselves (grad_scale 1 / world_size)'''
+        self._ck(self._lib.fsmg_comm_init(self._h, C.c_char_p(bytes(unique_id)), int(world_size), int(rank)))
+
+    def comm_broadcast_state(self, root=0):
+        self._ck(self._lib.fsmg_comm_broadcast_state(self._h, int(root)))
+
+    def comm_release(self):
+        self._ck(self._lib.fsmg_comm_release(self._h))
 
     # -- device-resident episode table ----------------------------------------------------------------
     def upload_table(self, table_id, table):

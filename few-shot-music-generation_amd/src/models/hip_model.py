@@ -82,6 +82,23 @@ class HIPModel(BaseModel):
     def apply_update(self, grad_scale=1.0, want_loss=True):
         return self._model.apply_update(grad_scale, want_loss=want_loss)
 
+    def fused_maml_step(self, support, query, inner_steps, inner_lr, want_loss=True, **kw):
+        return self._model.maml_step(support, query, inner_steps, inner_lr, want_loss=want_loss, **kw)
+
+    # -- the gradient exchange inside the library (fsmg_comm_*: RCCL calls issued by libfsmg on its own stream) ----------
+    library_comm = False
+
+    def attach_library_comm(self):
+        """Every rank of an initialised torch.distributed job: rank 0's ncclUniqueId travels through the job's own store, each
+        rank joins with ncclCommInitRank, and from then on train steps are ONE library call per rank -- PyTorch is left with
+        the memory (model config key `dp_exchange: 'library'`)."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(), dist.get_rank()
+        ids = [FsmgModel.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        self._model.comm_init(ids[0], world, rank)
+        self.library_comm = True
+
     @property
     def engine(self):
         return self._model

@@ -12,7 +12,8 @@ are replaced by libfsmg (hand-written gfx950 kernels behind include/fsmg.h):
                   the reference                              (reference :135-156)
 
 Optional config keys beyond the reference's: device, clip_norm_mode ('tf1_slices' | 'dense'),
-max_sequences, use_graph.  When torch.distributed is initialised, train() runs episode-parallel
+max_sequences, use_graph, gemm / schedule / recurrence / dp_split_backward (fsmg_config), dp_exchange ('torch': the
+all-reduce is issued through torch.distributed; 'library': libfsmg issues the RCCL calls itself).  When torch.distributed is initialised, train() runs episode-parallel
 (one episode per rank, one gradient all-reduce per step, see fsmg/dist.py).
 """
 import numpy as np
@@ -31,6 +32,8 @@ class LSTMBaseline(HIPModel):
         self._start_word = int(config['input_size'])
         self._time_steps = int(config['max_len'])
         self._parallel = EpisodeParallel(self)
+        if config.get('dp_exchange', 'torch') == 'library' and self._parallel.world > 1:
+            self.attach_library_comm()
 
     def recover_or_init(self, init_path):
         super(LSTMBaseline, self).recover_or_init(init_path)

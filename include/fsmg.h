@@ -158,6 +158,25 @@ int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss);
 int fsmg_grad_bucket(fsmg_handle h, int32_t bucket, void** device_ptr, int64_t* count);
 int fsmg_stream_wait_bucket(fsmg_handle h, void* stream, int32_t bucket);
 
+/* The gradient exchange INSIDE the library ("fsmg_allreduce_grads internal to train_step when world > 1").
+ * With a communicator attached, fsmg_train_step / fsmg_train_step_indexed / fsmg_maml_step are the episode-parallel step by
+ * themselves: forward + backward graph(s) -> ncclAllReduce(SUM) of the three gradient buckets on the library's own
+ * communication stream (bucket 0 as soon as the projection gradients are final when fsmg_config.dp_split_backward is set) ->
+ * clip + Adam with grad_scale = 1 / world_size; the caller (PyTorch or anything else) only owns the memory.  RCCL is looked up
+ * at run time (dlopen of the librccl.so already in the process, else /opt/rocm/lib): no link-time dependency.
+ *   fsmg_comm_unique_id        rank 0: a fresh ncclUniqueId to hand to the other ranks by whatever means the job has;
+ *   fsmg_comm_init             every rank: ncclCommInitRank on the handle's device (a collective call);
+ *   fsmg_comm_attach           instead of the two above: an ncclComm_t the caller already owns (never destroyed by the library);
+ *   fsmg_comm_broadcast_state  parameters, Adam slots and global_step of rank `root` to every rank (after init / restore);
+ *   fsmg_comm_release          detach (and destroy a communicator the library created).
+ * fsmg_forward_backward / fsmg_apply_update stay for callers that own the exchange. */
+#define FSMG_COMM_ID_BYTES 128
+int fsmg_comm_unique_id(char id[FSMG_COMM_ID_BYTES]);
+int fsmg_comm_init(fsmg_handle h, const char id[FSMG_COMM_ID_BYTES], int32_t world_size, int32_t rank);
+int fsmg_comm_attach(fsmg_handle h, void* nccl_comm, int32_t world_size, int32_t rank);
+int fsmg_comm_broadcast_state(fsmg_handle h, int32_t root);
+int fsmg_comm_release(fsmg_handle h);
+
 /* Device-resident episode table.  The reference fills an episode from a host cache of per-song rows
  * (src/data/episode.py:62-74, src/data/dataset.py:187-199); here the packed split -- int32 [n_songs][max_len], the
  * `.npy` sidecars of the split in artist/song order -- is uploaded once and an episode is N*K + N*Q ROW INDICES gathered on

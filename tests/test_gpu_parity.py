@@ -842,12 +842,12 @@ def test_ten_consecutive_train_losses_at_cfg_b():
 
 
 @pytest.mark.parametrize('kind', ['bx3', 'f32'])
-def test_non_finite_weights_saturate_with_the_bf16_split_and_give_inf_with_the_fp32_mfma(kind, monkeypatch):
-    """Edge of the default GEMM (csrc/gemm.hip, "fp32 GEMM on the bf16 matrix pipe"), pinned as MEASURED on gfx950: an operand
-    that is Inf -- or finite but above bf16's largest value 3.39e38 -- does not survive the split (v_cvt_pk_bf16_f32 hands back
-    a finite leading piece), so the affected logits come out finite and huge (~3.4e38 * h) where the fp32 MFMA (FSMG_GEMM=f32)
-    produces +-Inf for an Inf weight.  No NaN appears either way, the damage stays in the column the bad weight feeds and every
-    other logit keeps its bits.  (Round 2 documented "NaN" here without a test; the hardware says otherwise.)"""
+def test_non_finite_weights_give_nan_with_the_bf16_split_and_inf_with_the_fp32_mfma(kind, monkeypatch):
+    """Edge of the default GEMM (csrc/gemm.hip, "fp32 GEMM on the bf16 matrix pipe"), pinned as MEASURED on gfx950: an Inf
+    operand makes the second piece of the split NaN (a2 = bf16(Inf - Inf)), so the logits it feeds are NaN where the fp32 MFMA
+    (FSMG_GEMM=f32) produces +-Inf; a FINITE weight above bf16's largest value (3.395e38 > 3.39e38) still gives finite, huge
+    logits with both kernels.  The damage stays in the column the bad weight feeds: every other logit keeps its bits, and an
+    Inf weight never yields a finite loss (no silent garbage)."""
     monkeypatch.setenv('FSMG_GEMM', kind)
     cfg = small_config(hidden_size=32, embedding_size=16, input_size=130, max_len=5)
     sup, qry = _episode(cfg, 3, 2, 2, seed=5)
@@ -865,11 +865,36 @@ def test_non_finite_weights_saturate_with_the_bf16_split_and_give_inf_with_the_f
         model.forward_backward(sup, qry)
         logits = model.debug_read('logits', B * T * V1p).reshape(B * T, V1p)[:, :V1]
         col = logits[:, 7]
-        assert not np.isnan(col).any()
-        if kind == 'f32' and np.isinf(bad):
-            assert np.isinf(col).all()
-            assert not np.isfinite(model.debug_read('tail', 16)[1])       # Inf logit -> the loss is not finite: no silent garbage
+        if np.isinf(bad):
+            if kind == 'bx3':
+                assert np.isnan(col).all()
+            else:
+                assert np.isinf(col).all() and not np.isnan(col).any()
+            assert not np.isfinite(model.debug_read('tail', 16)[1])
         else:
             assert np.isfinite(col).all() and np.abs(col).max() > 1e30
         others = np.delete(logits, 7, axis=1)
         np.testing.assert_array_equal(others, np.delete(ref, 7, axis=1))
+
+
+def test_library_owned_exchange_with_one_rank_equals_the_fused_step():
+    """fsmg_comm_* (include/fsmg.h): with a communicator attached the library runs forward + backward -> ncclAllReduce of the
+    three gradient buckets on its own communication stream -> clip + Adam (1 / world) inside fsmg_train_step.  One rank is all
+    a 1-GPU box can form (RCCL refuses two ranks on one device), and with one rank the exchange must change nothing: the same
+    bits as the single-graph step, for the plain step, the indexed step and the MAML-style step; the state broadcast and the
+    release leave the handle usable."""
+    from fsmg.binding import FsmgModel
+    cfg = small_config(hidden_size=512, embedding_size=24, input_size=300, max_len=9, max_grad_norm=0.5)
+    eps = O.synthetic_episodes(6, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=91, realistic=True)
+    plain = new_model(cfg)
+    want = [plain.train_step(s_, q_) for s_, q_ in eps[:3]] + [plain.maml_step(s_, q_, 1, 0.2) for s_, q_ in eps[3:5]]
+    lib = new_model(cfg)
+    lib.comm_init(FsmgModel.comm_unique_id(), 1, 0)
+    lib.comm_broadcast_state(0)
+    got = [lib.train_step(s_, q_) for s_, q_ in eps[:3]] + [lib.maml_step(s_, q_, 1, 0.2) for s_, q_ in eps[3:5]]
+    assert got == want
+    for name in plain.param_shapes:
+        np.testing.assert_array_equal(lib.get_param(name), plain.get_param(name))
+    assert lib.step == plain.step == 5
+    lib.comm_release()
+    assert lib.train_step(*eps[5]) == plain.train_step(*eps[5])

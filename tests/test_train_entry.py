@@ -150,7 +150,7 @@ def test_main_with_the_maml_plugin_trains_with_the_inner_loop(tmp_path, golden_d
     from oracle import lstm_oracle as O
     cfg = dict(LOOP, name='maml_lstm', model_module_name='models.maml_lstm', model_class_name='MAMLLSTM',
                n_train=4, print_every_n=2, val_every_n=4.0, n_val=2, n_test=2, n_samples=1, n_decay=10000, lr=5e-3, max_grad_norm=5,
-               embedding_size=32, hidden_size=40, n_layers=1, batch_size=3, inner_steps=1, inner_lr=0.3)
+               embedding_size=32, hidden_size=40, n_layers=1, inner_steps=1, inner_lr=0.3)   # batch_size 2: the golden val split has two artists
     p = _write_configs(tmp_path, golden_dir, cfg)
     full = {}
     for k in ('data', 'task', 'model'):

@@ -181,7 +181,7 @@ static inline int pcol(int u, int g) { return 16 * (u >> 2) + 4 * g + (u & 3); }
 static inline double sigm(double x) { return 1.0 / (1.0 + std::exp(-x)); }
 
 struct Problem {
-    int B, T; static constexpr int H = 512, G4 = 2048;
+    int B, T, H = 512, G4 = 2048;
     std::vector<float> Kh, Zin, dH;                 // Kh [H][G4] packed; Zin [T][B][G4]; dH [T][B][H]
     std::vector<double> hs, cs, gates, dz, dhrec;   // CPU results
 };
@@ -242,11 +242,12 @@ struct Dev {
 };
 
 static int g_variant = 0;
-static int run_case(int B, int Tcheck, int Ttime, int pipe) {
-    const int H = 512, G4 = 2048;
-    Problem p; p.B = B; p.T = Tcheck;
+static int run_case(int B, int Tcheck, int Ttime, int H) {
+    const int G4 = 4 * H;
+    Problem p; p.B = B; p.T = Tcheck; p.H = H; p.G4 = G4;
     std::mt19937 rng(1234 + B);
-    std::uniform_real_distribution<float> uk(-0.048f, 0.048f), uz(-1.5f, 1.5f), ud(-1e-3f, 1e-3f);
+    const float kl = H == 512 ? 0.048f : 0.034f;        // Glorot-uniform limit of a [H, 4H] block
+    std::uniform_real_distribution<float> uk(-kl, kl), uz(-1.5f, 1.5f), ud(-1e-3f, 1e-3f);
     p.Kh.resize((size_t)H * G4); for (auto& v : p.Kh) v = uk(rng);
     const int Tmax = std::max(Tcheck, Ttime);
     std::vector<float> Zin((size_t)Tmax * B * G4), dH((size_t)Tmax * B * H);
@@ -259,7 +260,7 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
     Dev d;
     const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
     CK(hipMalloc(&d.Kh, 4ull * H * G4)); CK(hipMalloc(&d.KhXf, 4ull * H * G4)); CK(hipMalloc(&d.KhXb, 4ull * H * G4)); CK(hipMalloc(&d.KhF, 8ull * H * G4));
-    CK(hipMalloc(&d.HX, 4ull * lstm_xcd_hx_floats(B, Tmax))); CK(hipMalloc(&d.inboxX, 4ull * lstm_xcd_inbox_floats(B)));
+    CK(hipMalloc(&d.HX, 4ull * lstm_xcd_hx_floats(B, Tmax, H))); CK(hipMalloc(&d.inboxX, 4ull * lstm_xcd_inbox_floats(B, H)));
     CK(hipMalloc(&d.Z, 4ull * Tmax * B * G4)); CK(hipMalloc(&d.Zsave, 4ull * Tmax * B * G4));
     CK(hipMalloc(&d.Cs, 4ull * (Tmax + 1) * B * H)); CK(hipMalloc(&d.Hs, 4ull * (Tmax + 1) * B * H));
     CK(hipMalloc(&d.dC, 4ull * B * H)); CK(hipMalloc(&d.dH, 4ull * Tmax * B * H));
@@ -271,32 +272,32 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
     CK(hipMemcpy(d.dH, dH.data(), 4ull * Tmax * B * H, hipMemcpyHostToDevice));
     CK(hipMemset(d.err, 0, 256));
     hipStream_t s; CK(hipStreamCreate(&s));
-    CK(launch_repack_kh_xcd(s, d.Kh, d.KhXf, d.KhXb));
+    CK(launch_repack_kh_xcd(s, d.Kh, d.KhXf, d.KhXb, H));
     CK(launch_repack_kh(s, d.Kh, d.KhF, d.KhF + (size_t)H * G4, H));
     int rc = 0;
 
     auto fwd_xcd = [&](int T, int nchunk) {
         CK(hipMemcpyAsync(d.Z, Zin.data(), 4ull * T * B * G4, hipMemcpyHostToDevice, s));
         CK(hipMemsetAsync(d.Cs, 0, 4ull * B * H, s)); CK(hipMemsetAsync(d.Hs, 0, 4ull * B * H, s));
-        const size_t step_f = (size_t)lstm_xcd_hx_floats(B, 0);
+        const size_t step_f = (size_t)lstm_xcd_hx_floats(B, 0, H);
         CK(hipMemsetAsync(d.HX, 0, 4 * step_f, s));
         CK(hipMemsetAsync(d.HX + step_f, 0xFF, 4 * step_f * T, s));
         CK(hipMemsetAsync(d.tickets, 0, 64 * 4, s));
         for (int c = 0; c < nchunk; ++c) {
             LstmFwdXcdArgs a{};
             a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant;
+            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H;
             CK(launch_lstm_fwd_xcd(s, a));
         }
     };
     auto bwd_xcd = [&](int T, int nchunk) {
         CK(hipMemsetAsync(d.dC, 0, 4ull * B * H, s));
-        CK(hipMemsetAsync(d.inboxX, 0xFF, 4ull * lstm_xcd_inbox_floats(B), s));
+        CK(hipMemsetAsync(d.inboxX, 0xFF, 4ull * lstm_xcd_inbox_floats(B, H), s));
         CK(hipMemsetAsync(d.tickets, 0, 64 * 4, s));
         for (int c = nchunk - 1; c >= 0; --c) {
             LstmBwdXcdArgs a{};
             a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant;
+            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H;
             CK(launch_lstm_bwd_xcd(s, a));
         }
     };
@@ -312,7 +313,7 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
         CK(hipMemcpy(g.data(), d.Z, g.size() * 4, hipMemcpyDeviceToHost));
         const double eh = relmax(hs.data(), p.hs.data(), hs.size()), ec = relmax(cs.data(), p.cs.data(), cs.size()), eg = relmax(g.data(), p.gates.data(), g.size());
         const bool ok = e == 0 && eh < 2e-5 && ec < 2e-5 && eg < 2e-5;
-        printf("[4] B=%d pipe=%d fwd_xcd  vs CPU fp64 (T=%d, 2 launches): err_flag %d, h %.2e c %.2e gates %.2e  %s\n", B, pipe, T, e, eh, ec, eg, ok ? "ok" : "FAIL");
+        printf("[4] B=%d H=%d fwd_xcd  vs CPU fp64 (T=%d, 2 launches): err_flag %d, h %.2e c %.2e gates %.2e  %s\n", B, H, T, e, eh, ec, eg, ok ? "ok" : "FAIL");
         rc += !ok;
         // backward on the GPU's own forward state
         bwd_xcd(T, 2);
@@ -321,7 +322,7 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
         CK(hipMemcpy(dz.data(), d.Z, dz.size() * 4, hipMemcpyDeviceToHost));
         const double ed = relmax(dz.data(), p.dz.data(), dz.size());
         const bool okb = e == 0 && ed < 1e-4;
-        printf("[4] B=%d pipe=%d bwd_xcd  vs CPU fp64 (T=%d, 2 launches): err_flag %d, dz %.2e  %s\n", B, pipe, T, e, ed, okb ? "ok" : "FAIL");
+        printf("[4] B=%d H=%d bwd_xcd  vs CPU fp64 (T=%d, 2 launches): err_flag %d, dz %.2e  %s\n", B, H, T, e, ed, okb ? "ok" : "FAIL");
         rc += !okb;
         CK(hipMemset(d.err, 0, 4));
     }
@@ -338,7 +339,7 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
                 for (int c = 0; c < nchunk; ++c) {
                     LstmFwdXcdArgs a{};
                     a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant;
+                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H;
                     CK(launch_lstm_fwd_xcd(s, a));
                 }
                 CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
@@ -348,15 +349,15 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
                 for (int c = nchunk - 1; c >= 0; --c) {
                     LstmBwdXcdArgs a{};
                     a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant;
+                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H;
                     CK(launch_lstm_bwd_xcd(s, a));
                 }
                 CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                 CK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
             }
             const int e = read_err();
-            printf("[4] B=%d pipe=%d xcd-local, %d launch(es) per chain, T=%d: fwd %.3f ms = %.2f us/step = %.1f TFLOP/s (%.1f%% of 157.3) | bwd %.3f ms = %.2f us/step = %.1f TFLOP/s (%.1f%%)  err_flag %d\n",
-                   B, pipe, nchunk, T, best_f, best_f * 1e3 / T, mflop * T / best_f / 1e6, mflop * T / best_f / 1e6 / 157.3 * 100, best_b, best_b * 1e3 / T,
+            printf("[4] B=%d H=%d xcd-local, %d launch(es) per chain, T=%d: fwd %.3f ms = %.2f us/step = %.1f TFLOP/s (%.1f%% of 157.3) | bwd %.3f ms = %.2f us/step = %.1f TFLOP/s (%.1f%%)  err_flag %d\n",
+                   B, H, nchunk, T, best_f, best_f * 1e3 / T, mflop * T / best_f / 1e6, mflop * T / best_f / 1e6 / 157.3 * 100, best_b, best_b * 1e3 / T,
                    mflop * T / best_b / 1e6, mflop * T / best_b / 1e6 / 157.3 * 100, e);
             CK(hipMemset(d.err, 0, 4));
         }
@@ -367,22 +368,22 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
                     fwd_xcd(T, 0);
                     CK(hipEventRecord(e0, s));
                     { LstmFwdXcdArgs a{}; a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; CK(launch_lstm_fwd_xcd(s, a)); }
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; a.Hp = H; CK(launch_lstm_fwd_xcd(s, a)); }
                     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best_f = std::min(best_f, ms);
                     bwd_xcd(T, 0);
                     CK(hipEventRecord(e0, s));
                     { LstmBwdXcdArgs a{}; a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; CK(launch_lstm_bwd_xcd(s, a)); }
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; a.Hp = H; CK(launch_lstm_bwd_xcd(s, a)); }
                     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                     CK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
                 }
-                printf("[4] B=%d pipe=0 variant %d (%s%s): fwd %.2f us/step | bwd %.2f us/step  err_flag %d\n", B, dbg, (dbg & 16) ? "deferred stores " : "", (dbg & 32) ? "no poll sleep" : "",
+                printf("[4] B=%d H=%d variant %d (%s%s): fwd %.2f us/step | bwd %.2f us/step  err_flag %d\n", B, H, dbg, (dbg & 16) ? "deferred stores " : "", (dbg & 32) ? "no poll sleep" : "",
                        best_f * 1e3 / T, best_b * 1e3 / T, read_err());
                 CK(hipMemset(d.err, 0, 4));
             }
         }
-        if (B == 45) {       // phase profile of the instrumented build (RG = 2)
+        if (B == 45 && H == 512) {       // phase profile of the instrumented build (RG = 2)
             unsigned long long* prof; CK(hipMalloc(&prof, 8ull * 256 * 4 * 8));
             std::vector<unsigned long long> hp(256 * 4 * 8);
             for (int dir = 0; dir < 2; ++dir) {
@@ -391,13 +392,13 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
                     fwd_xcd(T, 0);
                     LstmFwdXcdArgs a{};
                     a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H;
                     CK(launch_lstm_fwd_xcd(s, a));
                 } else {
                     bwd_xcd(T, 0);
                     LstmBwdXcdArgs a{};
                     a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H;
                     CK(launch_lstm_bwd_xcd(s, a));
                 }
                 CK(hipStreamSynchronize(s));
@@ -409,7 +410,7 @@ static int run_case(int B, int Tcheck, int Ttime, int pipe) {
                 for (int wc = 0; wc < 2; ++wc) {        // cell waves (0,1) vs the others (2,3)
                     double m[5] = {0, 0, 0, 0, 0};
                     for (int b = 0; b < 256; ++b) for (int w = 2 * wc; w < 2 * wc + 2; ++w) for (int i = 0; i < 5; ++i) m[i] += (double)hp[((size_t)b * 4 + w) * 8 + i];
-                    printf("[4] pipe=%d %s phase ticks per step, waves %d-%d:", pipe, dir ? "bwd" : "fwd", 2 * wc, 2 * wc + 1);
+                    printf("[4] %s phase ticks per step, waves %d-%d:", dir ? "bwd" : "fwd", 2 * wc, 2 * wc + 1);
                     double tot = 0;
                     for (int i = 0; i < 5; ++i) { printf("  %s %.0f", dir ? names_b[i] : names_f[i], m[i] / 512 / T); tot += m[i] / 512 / T; }
                     printf("  | total %.0f\n", tot);
@@ -458,9 +459,18 @@ int main(int argc, char** argv) {
     const int only_pipe = getenv("PIPE") ? atoi(getenv("PIPE")) : -1;
     g_variant = getenv("VARIANT") ? atoi(getenv("VARIANT")) : 0;
     (void)only_pipe;
-    rc += run_case(45, 6, 128, 0);
-    rc += run_case(100, 4, 128, 0);
-    rc += run_case(20, 4, 128, 0);
+    const int only_h = getenv("HID") ? atoi(getenv("HID")) : 0;
+    if (only_h != 1024) {
+        rc += run_case(45, 6, 128, 512);
+        rc += run_case(100, 4, 128, 512);
+        rc += run_case(20, 4, 128, 512);
+    }
+    if (only_h != 512) {             // hidden 1024: one copy of K_h per XCD pair (cfg-C / cfg-E shapes: 45 / 25 / 20 rows, T = 50)
+        rc += run_case(45, 5, 50, 1024);
+        rc += run_case(25, 4, 50, 1024);
+        rc += run_case(20, 4, 50, 1024);
+        rc += run_case(64, 3, 50, 1024);
+    }
     printf(rc ? "FAILED\n" : "ALL OK\n");
     return rc;
 }
