@@ -49,6 +49,7 @@
 // column-split kernels: placement decides speed, never results.
 #include "fsmg_kernels.h"
 #include "lstm_cell.h"
+#include <type_traits>
 
 namespace fsmg {
 namespace {
@@ -97,6 +98,29 @@ __device__ __forceinline__ bool wait_all_fragments(const f32x4* af, f32x4 (&av)[
 #pragma unroll
         for (int j = 0; j < N; ++j) { asm volatile("" : "+v"(av[j])); ok &= frag_ready(av[j]); }
         if (__all(ok)) return true;
+        if (!nosleep) __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
+        if (spins >= spin_limit || ((spins & 255) == 255 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) return false;
+    }
+}
+
+// The same with memory of what has arrived: a round fetches only the fragments that were not complete in the round before.
+// For hand-offs that cross the fabric (XCD pairs: a write-through line is in nobody's L2) a round of N fragments moves N KB
+// per wave, and the early rounds of a step would move all of them again for the sake of the one producer that is late.
+template <int N>
+__device__ __forceinline__ bool wait_fragments_incremental(const f32x4* af, f32x4 (&av)[N], int spin_limit, int* err_flag, bool nosleep) {
+    unsigned need = (1u << N) - 1u;
+    for (int spins = 0;; ++spins) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (need & (1u << j)) av[j] = load_sc1(af + j * 64);
+        drain_vmem();
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (need & (1u << j)) {
+                asm volatile("" : "+v"(av[j]));
+                if (__all(frag_ready(av[j]))) need &= ~(1u << j);
+            }
+        if (need == 0) return true;
         if (!nosleep) __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
         if (spins >= spin_limit || ((spins & 255) == 255 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) return false;
     }
@@ -545,7 +569,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair(const LstmFwdXcdArgs a
     for (int t = a.t0; t < a.t1; ++t) {
         f32x4 av[NF];
         {
-            const bool fail = !wait_all_fragments<NF>(hx_in + (size_t)t * hx_step, av, a.spin_limit, a.err_flag, (a.variant & XCD_NO_POLL_SLEEP) != 0);
+            const bool nosleep = (a.variant & XCD_NO_POLL_SLEEP) != 0;
+            const bool fail = (a.variant & XCD_INCREMENTAL_POLL)
+                                  ? !wait_fragments_incremental<NF>(hx_in + (size_t)t * hx_step, av, a.spin_limit, a.err_flag, nosleep)
+                                  : !wait_all_fragments<NF>(hx_in + (size_t)t * hx_step, av, a.spin_limit, a.err_flag, nosleep);
             if (fail && lane == 0) {
                 __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_fail = 1;
@@ -619,6 +646,249 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair(const LstmFwdXcdArgs a
         a.Hs[((size_t)a.t1 * B + row) * PH + unit] = o_hh;
         float* zo = a.Z + ((size_t)(a.t1 - 1) * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
         zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+    }
+}
+
+// ---------------------------------------------------------------- row-group CHAINS on an XCD pair (hidden size 1024)
+// The pair kernels above spend ~3 us of a 6.4 / 9.3 us step in the cross-XCD hand-off while the MFMAs of one row group take
+// ~1 us: the regime in which independent chains pay (at hidden size 512 they did not: header of this file).  The RG row groups
+// of a pair are independent sequences, so they become RG chains that the same four waves advance round-robin: phase (c, t) =
+// fragments of row group c at time t -> 256 MFMAs -> K-split partials through LDS -> cell update by wave c -> hand-off store.
+// While h_{t+1} of row group c crosses the fabric, the block runs the phases of the other row groups; the poll of a phase is
+// ISSUED at the end of the previous phase's MFMA stream and only CHECKED when the phase starts.
+// Memory-queue discipline (a CU returns vector-memory operations in order, and vmcnt counts loads and stores alike):
+//   * a wait is `s_waitcnt vmcnt(N)` with N = the number of operations this wave issued AFTER the one it needs, so that a poll
+//     never waits for the slower loads / stores behind it;
+//   * a cell wave's outputs (c, h, gates / dz) and next inputs are issued one phase after its update, right behind that phase's
+//     poll; all of them unconditionally (inactive lanes: exec-masked stores, clamped load addresses), so the counts depend on
+//     the wave's role only; around the ends of a pass, where an operation is missing, waits fall back to vmcnt(0) (`cons`);
+//   * a load that is in flight across phases must not target a register the compiler manages (hipcc copies / re-uses the
+//     destination of an inline-asm load at will): such loads land in FIXED accumulation registers a[176:245], far above what
+//     the compiler allocates in these kernels, and an empty "adopt" asm hands them over after the wait.
+//     tools/check_xcd_asm.py verifies both properties on the final ISA.
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+#define CHAIN_LOAD_X4(REG, PTR) do { f32x4 d_; asm volatile("global_load_dwordx4 %0, %1, off sc1" : "={" REG "}"(d_) : "v"(PTR) : "memory"); } while (0)
+#define CHAIN_LOAD_DW(REG, PTR, OFS) do { float d_; asm volatile("global_load_dword %0, %1, off offset:" #OFS : "={" REG "}"(d_) : "v"(PTR) : "memory"); } while (0)
+#define CHAIN_ADOPT(REG, VAR) asm volatile("" : "={" REG "}"(VAR))
+
+// the four hand-off words of chain C: a[176 + 16 C : + 15]
+template <int C>
+__device__ __forceinline__ void chain_issue_fragments(const f32x4* p0, const f32x4* p1, const f32x4* p2, const f32x4* p3) {
+    static_assert(C >= 0 && C < 4, "chain");
+    if constexpr (C == 0) { CHAIN_LOAD_X4("a[176:179]", p0); CHAIN_LOAD_X4("a[180:183]", p1); CHAIN_LOAD_X4("a[184:187]", p2); CHAIN_LOAD_X4("a[188:191]", p3); }
+    if constexpr (C == 1) { CHAIN_LOAD_X4("a[192:195]", p0); CHAIN_LOAD_X4("a[196:199]", p1); CHAIN_LOAD_X4("a[200:203]", p2); CHAIN_LOAD_X4("a[204:207]", p3); }
+    if constexpr (C == 2) { CHAIN_LOAD_X4("a[208:211]", p0); CHAIN_LOAD_X4("a[212:215]", p1); CHAIN_LOAD_X4("a[216:219]", p2); CHAIN_LOAD_X4("a[220:223]", p3); }
+    if constexpr (C == 3) { CHAIN_LOAD_X4("a[224:227]", p0); CHAIN_LOAD_X4("a[228:231]", p1); CHAIN_LOAD_X4("a[232:235]", p2); CHAIN_LOAD_X4("a[236:239]", p3); }
+}
+template <int C>
+__device__ __forceinline__ void chain_adopt_fragments(f32x4 (&v)[4]) {
+    if constexpr (C == 0) { CHAIN_ADOPT("a[176:179]", v[0]); CHAIN_ADOPT("a[180:183]", v[1]); CHAIN_ADOPT("a[184:187]", v[2]); CHAIN_ADOPT("a[188:191]", v[3]); }
+    if constexpr (C == 1) { CHAIN_ADOPT("a[192:195]", v[0]); CHAIN_ADOPT("a[196:199]", v[1]); CHAIN_ADOPT("a[200:203]", v[2]); CHAIN_ADOPT("a[204:207]", v[3]); }
+    if constexpr (C == 2) { CHAIN_ADOPT("a[208:211]", v[0]); CHAIN_ADOPT("a[212:215]", v[1]); CHAIN_ADOPT("a[216:219]", v[2]); CHAIN_ADOPT("a[220:223]", v[3]); }
+    if constexpr (C == 3) { CHAIN_ADOPT("a[224:227]", v[0]); CHAIN_ADOPT("a[228:231]", v[1]); CHAIN_ADOPT("a[232:235]", v[2]); CHAIN_ADOPT("a[236:239]", v[3]); }
+}
+__device__ __forceinline__ bool chain_fragments_ready(f32x4 (&v)[4]) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(v[j])); ok &= frag_ready(v[j]); }
+    return __all(ok);
+}
+// a cell wave's own inputs (every wave is the cell wave of at most one chain): four dwords 16 bytes apart -> a[240:243], two
+// more scalars -> a244, a245
+__device__ __forceinline__ void chain_issue_dw4(const float* p) {
+    CHAIN_LOAD_DW("a240", p, 0); CHAIN_LOAD_DW("a241", p, 16); CHAIN_LOAD_DW("a242", p, 32); CHAIN_LOAD_DW("a243", p, 48);
+}
+__device__ __forceinline__ void chain_adopt_dw4(float (&z)[4]) {
+    CHAIN_ADOPT("a240", z[0]); CHAIN_ADOPT("a241", z[1]); CHAIN_ADOPT("a242", z[2]); CHAIN_ADOPT("a243", z[3]);
+}
+__device__ __forceinline__ void chain_issue_dw_a(const float* p) { CHAIN_LOAD_DW("a244", p, 0); }
+__device__ __forceinline__ void chain_issue_dw_b(const float* p) { CHAIN_LOAD_DW("a245", p, 0); }
+__device__ __forceinline__ void chain_adopt_dw2(float& x, float& y) { CHAIN_ADOPT("a244", x); CHAIN_ADOPT("a245", y); }
+// a wave-uniform 64-bit value as an SGPR pair (the "s" constraint of an inline asm does not move a VGPR-resident value itself)
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// exec-masked stores that are issued whatever the mask (an instruction with exec = 0 still takes its slot in the vmcnt order)
+__device__ __forceinline__ void store_dw4_stride16_masked(unsigned long long mask, float* p, float g0, float g1, float g2, float g3) {
+    mask = uniform64(mask);
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "global_store_dword %2, %3, off\n\t"
+                 "global_store_dword %2, %4, off offset:16\n\t"
+                 "global_store_dword %2, %5, off offset:32\n\t"
+                 "global_store_dword %2, %6, off offset:48\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(mask), "v"(p), "v"(g0), "v"(g1), "v"(g2), "v"(g3) : "memory");
+}
+__device__ __forceinline__ void store_dw2_masked(unsigned long long mask, float* p0, float v0, float* p1, float v1) {
+    mask = uniform64(mask);
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "global_store_dword %2, %3, off\n\t"
+                 "global_store_dword %4, %5, off\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(mask), "v"(p0), "v"(v0), "v"(p1), "v"(v1) : "memory");
+}
+
+// forward, RG >= 2 chains.  Buffers exactly as k_lstm_fwd_pair.
+template <int RG>
+__global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair_chains(const LstmFwdXcdArgs a) {
+    static_assert(RG >= 2 && RG <= 4, "chains");
+    __shared__ __attribute__((aligned(16))) float red[RG][4][64 * 4];        // [chain][wave][cell lane][gate]
+    __shared__ int s_role[2];
+    __shared__ int s_fail;
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) s_fail = 0;
+    Role role;
+    if (!take_role(a.tickets, a.err_flag, s_role, role)) return;
+    const int grp = role.xcd / PNX, cu = (role.xcd % PNX) * NCU + role.cu;
+    const int B = a.B;
+    const int rpx = a.rpx > 0 ? a.rpx : (B + PGRP - 1) / PGRP, row0 = grp * rpx;
+    if (row0 >= B) return;
+
+    f32x4 W[PNW];
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.KhX) + ((size_t)(cu * 4 + wave) * PNW) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < PNW; ++i) W[i] = wp[i * 64];
+    }
+    // wave c < RG is the cell wave of chain (= row group) c: lane = 16 i + 4 bb + e -> row 4c + i, unit 16 cu + 4 bb + e
+    const int ci = lane >> 4, cbb = (lane >> 2) & 3, ce = lane & 3;
+    const int lrow = 4 * wave + ci, row = row0 + lrow, unit = 16 * cu + 4 * cbb + ce;
+    const bool cellw = wave < RG;
+    const bool act = cellw && lrow < rpx && row < B;
+    const unsigned long long actmask = uniform64(__builtin_amdgcn_ballot_w64(act));
+    const int rowc = row < B ? row : B - 1;                          // inactive lanes load a valid row and discard it
+    float cp = act ? a.Cs[((size_t)a.t0 * B + row) * PH + unit] : 0.0f;
+    const size_t hx_step = (size_t)PGRP * 4 * RG * PNQ * 64;
+    const f32x4* hx_in = reinterpret_cast<const f32x4*>(a.HX) + (((size_t)grp * 4 + wave) * RG) * PNQ * 64 + lane;   // + chain * PNQ * 64
+    f32x4* hx_out = reinterpret_cast<f32x4*>(a.HX) + ((((size_t)grp * 4 + (cu >> 4)) * RG + wave) * PNQ + ((cu >> 2) & 3)) * 64 +
+                    16 * (cu & 3) + 4 * cbb + ci;
+    const int wofs = ((lane >> 4) * 4 + (lane & 3)) * 4 + ((lane >> 2) & 3);
+    const float* zload = a.Z + (size_t)rowc * PG4 + 64 * cu + 16 * cbb + ce;             // + t * B * PG4
+    float* zstore = a.Z + (size_t)rowc * PG4 + 64 * cu + 16 * cbb + ce;
+    const size_t hofs = (size_t)rowc * PH + unit;
+    float o_h = 0.f, o_g[4] = {0.f, 0.f, 0.f, 0.f};
+    int o_t = a.t0;
+    unsigned long long omask = 0;                                    // nothing to write back yet
+    if (cellw) chain_issue_dw4(zload + (size_t)a.t0 * B * PG4);     // x-part of every chain's first update
+    vm_wait<0>();
+    // the compiler's own loads (weights, cell state) are waited for HERE: its waitcnt bookkeeping must be empty inside the loop
+#pragma unroll
+    for (int i = 0; i < PNW; ++i) asm volatile("" : "+v"(W[i]));
+    asm volatile("" : "+v"(cp));
+    int cons = RG + 1;                                               // phases left whose waits must be vmcnt(0)
+
+    auto phase = [&](auto Cc, const int t) __attribute__((always_inline)) -> bool {
+        constexpr int C = decltype(Cc)::value, CN = (C + 1) % RG;
+        constexpr int W10 = (C + RG - 2) % RG, W1 = (C + RG - 1) % RG;      // issued 10 operations / 1 store behind this phase's poll
+        const int tn = C + 1 < RG ? t : t + 1;                               // time index of the next phase
+        const bool pending = !(C == 0 && t == a.t0);
+        const bool issue_next = !(C == RG - 1 && t + 1 >= a.t1);
+        // ---- 1: the fragments of (C, t)
+        f32x4 av[4];
+        {
+            bool ready = false;
+            if (pending) {
+                if (cons > 0) vm_wait<0>();
+                else if (wave == W10) vm_wait<10>();
+                else if (wave == W1) vm_wait<1>();
+                else vm_wait<0>();
+                chain_adopt_fragments<C>(av);
+                ready = chain_fragments_ready(av);
+                if (a.prof != nullptr && lane == 0) {          // diagnostics: early polls checked / found not ready, per wave
+                    atomicAdd(a.prof + wave, 1ull);
+                    if (!ready) atomicAdd(a.prof + 4 + wave, 1ull);
+                }
+            }
+            if (!ready) {
+                const bool fail = !wait_all_fragments<4>(hx_in + (size_t)t * hx_step + C * PNQ * 64, av, a.spin_limit, a.err_flag, (a.variant & XCD_NO_POLL_SLEEP) != 0);
+                if (fail && lane == 0) {
+                    __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_fail = 1;
+                }
+            }
+        }
+        // ---- 2: 256 MFMAs, two accumulators (fragment pairs) issued alternately
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#define CHAIN_FWD_B(B_)                                                                             \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                          \
+            acc0 = mfma44<B_>(av[2 * qp][e_], W[32 * qp + B_][e_], acc0);                           \
+            acc1 = mfma44<B_>(av[2 * qp + 1][e_], W[32 * qp + 16 + B_][e_], acc1);                  \
+        }
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            CHAIN_FWD_B(0) CHAIN_FWD_B(1) CHAIN_FWD_B(2) CHAIN_FWD_B(3) CHAIN_FWD_B(4) CHAIN_FWD_B(5) CHAIN_FWD_B(6) CHAIN_FWD_B(7)
+            CHAIN_FWD_B(8) CHAIN_FWD_B(9) CHAIN_FWD_B(10) CHAIN_FWD_B(11) CHAIN_FWD_B(12) CHAIN_FWD_B(13) CHAIN_FWD_B(14) CHAIN_FWD_B(15)
+        }
+#undef CHAIN_FWD_B
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 3: the poll of the next phase goes out now (checked when it starts); behind it the slow traffic of the cell wave
+        // that updated in the phase before: its outputs, and the x-part of its next update
+        if (issue_next) {
+            const f32x4* pn = hx_in + (size_t)tn * hx_step + CN * PNQ * 64;
+            chain_issue_fragments<CN>(pn, pn + 64, pn + 128, pn + 192);
+        }
+        if (wave == W1) {
+            store_dw2_masked(omask, a.Cs + (size_t)(o_t + 1) * B * PH + hofs, cp, a.Hs + (size_t)(o_t + 1) * B * PH + hofs, o_h);
+            store_dw4_stride16_masked(omask, zstore + (size_t)o_t * B * PG4, o_g[0], o_g[1], o_g[2], o_g[3]);
+            const int tz = C == 0 ? t : (t + 1 < a.t1 ? t + 1 : t);         // time index of that wave's next update
+            chain_issue_dw4(zload + (size_t)tz * B * PG4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 4: K-split partials meet in LDS
+        {
+            const f32x4 s = acc0 + acc1;
+            float* rp = &red[C][wave][0] + wofs;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rp[64 * i] = s[i];
+        }
+        __syncthreads();
+        if (s_fail) return false;
+        // ---- 5: cell update of chain C by wave C.  Its x-part was issued (last) in step 3 of the phase after its previous update;
+        // behind it: the polls of the phases in between and of this one, 4 loads each
+        if (wave == C) {
+            if (cons > 0 || !issue_next) vm_wait<0>(); else vm_wait<4 * (RG - 1)>();
+            float zin[4];
+            chain_adopt_dw4(zin);
+            float hn = 0.0f, g_si = 0.f, g_tj = 0.f, g_sf = 0.f, g_so = 0.f;
+            if (act) {
+                const f32x4* rsrc = reinterpret_cast<const f32x4*>(&red[C][0][0]) + lane;
+                const f32x4 r0 = rsrc[0], r1 = rsrc[64], r2 = rsrc[128], r3 = rsrc[192];
+                float zg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float zs = 0.0f;
+                    zs += r0[g]; zs += r1[g]; zs += r2[g]; zs += r3[g];
+                    zg[g] = zin[g] + zs;
+                }
+                const CellOut co = cell_forward(zg, cp);
+                hn = co.h; cp = co.c;
+                g_si = co.si; g_tj = co.tj; g_sf = co.sf; g_so = co.so;
+            }
+            f32x4 hv;
+            hv[0] = quad_bcast<0>(hn); hv[1] = quad_bcast<1>(hn); hv[2] = quad_bcast<2>(hn); hv[3] = quad_bcast<3>(hn);
+            if (ce == 0) store_sc1(hx_out + (size_t)(t + 1) * hx_step, hv);
+            o_h = hn; o_g[0] = g_si; o_g[1] = g_tj; o_g[2] = g_sf; o_g[3] = g_so; o_t = t; omask = actmask;
+        }
+        if (cons > 0) --cons;
+        return true;
+    };
+
+    for (int t = a.t0; t < a.t1; ++t) {
+        if (!phase(std::integral_constant<int, 0>{}, t)) return;
+        if (!phase(std::integral_constant<int, 1>{}, t)) return;
+        if constexpr (RG > 2) { if (!phase(std::integral_constant<int, 2 % RG>{}, t)) return; }
+        if constexpr (RG > 3) { if (!phase(std::integral_constant<int, 3 % RG>{}, t)) return; }
+    }
+    // the last chain's last outputs (every other chain's went out in the phase behind its update)
+    if (wave == RG - 1) {
+        store_dw2_masked(omask, a.Cs + (size_t)(o_t + 1) * B * PH + hofs, cp, a.Hs + (size_t)(o_t + 1) * B * PH + hofs, o_h);
+        store_dw4_stride16_masked(omask, zstore + (size_t)o_t * B * PG4, o_g[0], o_g[1], o_g[2], o_g[3]);
     }
 }
 
@@ -776,6 +1046,197 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_pair(const LstmBwdXcdArgs a
     if (act) a.dc[hi] = dcv;
 }
 
+// backward, RG >= 2 chains.  Buffers exactly as k_lstm_bwd_pair.  Phase (c, t):
+//   A  the 4 inbox words per lane of row group c [issued during the previous phase] -> resets -> per-wave sums to LDS -> barrier
+//   B  wave c: gate gradients of its rows, dz slice in A-register order to LDS -> barrier
+//   C  poll of the next phase, then (wave c) the row-major dz stores and the inputs of its next update; 256 MFMAs; the resets of
+//      A are awaited by COUNT (they are the oldest operations in the queue), then the partials are published.
+template <int RG>
+__global__ __launch_bounds__(256, 1) void k_lstm_bwd_pair_chains(const LstmBwdXcdArgs a) {
+    static_assert(RG >= 2 && RG <= 4, "chains");
+    __shared__ __attribute__((aligned(16))) float psum[4][64][4];
+    __shared__ __attribute__((aligned(16))) float dzA[64][4];
+    __shared__ int s_role[2];
+    __shared__ int s_fail;
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) s_fail = 0;
+    Role role;
+    if (!take_role(a.tickets, a.err_flag, s_role, role)) return;
+    const int grp = role.xcd / PNX, cu = (role.xcd % PNX) * NCU + role.cu;
+    const int B = a.B;
+    const int rpx = a.rpx > 0 ? a.rpx : (B + PGRP - 1) / PGRP, row0 = grp * rpx;
+    if (row0 >= B) return;
+
+    f32x4 W[PNW];
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.KhXb) + ((size_t)(cu * 4 + wave) * PNW) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < PNW; ++i) W[i] = wp[i * 64];
+    }
+    const int ci = lane >> 4, cbb = (lane >> 2) & 3, ce = lane & 3;
+    const int lrow = 4 * wave + ci, row = row0 + lrow, unit = 16 * cu + 4 * cbb + ce;
+    const bool cellw = wave < RG;
+    const bool act = cellw && lrow < rpx && row < B;
+    const unsigned long long actmask = uniform64(__builtin_amdgcn_ballot_w64(act));
+    const int rowc = row < B ? row : B - 1;
+    const size_t hic = (size_t)rowc * PH + unit;
+    float dcv = act ? a.dc[hic] : 0.0f;
+    float n_ct = (cellw && a.t1 > a.t0) ? a.Cs[(size_t)a.t1 * B * PH + hic] : 0.0f;
+    const size_t slot_w = (size_t)PGRP * PCU * RG * PCU * 16;                // f32x4 words per slot
+    f32x4* const inbox = reinterpret_cast<f32x4*>(a.inbox);
+    // consumer: (dest = cu, row group c): 64 producers x 16 units; wave w takes producers 16w .. 16w+15, 4 words per lane
+    const size_t in_base = (((size_t)grp * PCU + cu) * RG) * PCU * 16 + (size_t)(16 * wave) * 16 + lane;      // + c * PCU * 16
+    size_t out_ofs[4];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg)
+        out_ofs[cg] = (((size_t)grp * PCU + 16 * wave + 4 * cg + (lane >> 4)) * RG) * PCU * 16 + (size_t)cu * 16 + (lane & 15);
+    const f32x4 fill = f32x4{__uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu)};
+    const float* gload = a.Z + (size_t)rowc * PG4 + 64 * cu + 16 * cbb + ce;              // + t * B * PG4
+    float* gstore = a.Z + (size_t)rowc * PG4 + 64 * cu + 16 * cbb + ce;
+
+    // inputs of every cell wave's first update (step t1 - 1): gates, c_{t} (c_prev), dH; c_{t+1} is carried in n_ct
+    if (cellw && a.t1 > a.t0) {
+        const int t = a.t1 - 1;
+        chain_issue_dw4(gload + (size_t)t * B * PG4);
+        chain_issue_dw_a(a.Cs + (size_t)t * B * PH + hic);
+        chain_issue_dw_b(a.dH + (size_t)t * B * PH + hic);
+    }
+    vm_wait<0>();
+#pragma unroll
+    for (int i = 0; i < PNW; ++i) asm volatile("" : "+v"(W[i]));
+    asm volatile("" : "+v"(dcv)); asm volatile("" : "+v"(n_ct));
+    int cons = RG + 1;
+
+    auto phase = [&](auto Cc, const int t) __attribute__((always_inline)) -> bool {
+        constexpr int C = decltype(Cc)::value, CN = (C + 1) % RG, WP = (C + RG - 1) % RG;       // WP: the cell wave of the phase before
+        const int tn = C + 1 < RG ? t : t - 1;                               // time index of the next phase
+        const bool pending = !(C == 0 && t == a.t1 - 1);
+        const bool next_exists = !(C == RG - 1 && t == a.t0);
+        const bool has_in = t + 1 < a.T;                                     // dh partials arrive for this step
+        const bool produce = t > 0;
+        const bool issue_next = next_exists && (tn + 1 < a.T);
+        if (!has_in || !produce || !pending || !issue_next) cons = RG + 1;
+        // ---- A: consume.  Behind the poll's loads this wave issued (previous phase, part C) 10 operations if it was that phase's
+        // cell wave, and 4 publish stores
+        f32x4 wsum = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_in) {
+            f32x4* in = inbox + (size_t)((t + 1) & 1) * slot_w + in_base + (size_t)C * PCU * 16;
+            f32x4 v[4];
+            bool ready = false;
+            if (pending) {
+                if (cons > 0) vm_wait<0>();
+                else if (wave == WP) vm_wait<14>();
+                else vm_wait<4>();
+                chain_adopt_fragments<C>(v);
+                ready = chain_fragments_ready(v);
+                if (a.prof != nullptr && lane == 0) {
+                    atomicAdd(a.prof + wave, 1ull);
+                    if (!ready) atomicAdd(a.prof + 4 + wave, 1ull);
+                }
+            }
+            if (!ready) {
+                bool fail = false;
+                for (int spins = 0;; ++spins) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = load_sc1(in + k * 64);
+                    drain_vmem();
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { asm volatile("" : "+v"(v[k])); ok &= frag_ready(v[k]); }
+                    if (__all(ok)) break;
+                    if (!(a.variant & XCD_NO_POLL_SLEEP)) __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
+                    if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+                }
+                if (fail && lane == 0) {
+                    __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_fail = 1;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                store_sc1(in + k * 64, fill);
+                wsum = (k == 0) ? v[0] : wsum + v[k];
+            }
+        }
+        *reinterpret_cast<f32x4*>(&psum[wave][lane][0]) = wsum;
+        __syncthreads();
+        if (s_fail) return false;
+        // ---- B: gate gradients of chain C by wave C.  Its inputs were issued in part C of its previous phase; behind them: that
+        // phase's publish (4), the RG - 1 phases in between (4 resets + 4 poll loads + 4 publish stores each), this phase's resets (4)
+        float di = 0.f, dj = 0.f, df = 0.f, dg = 0.f;
+        if (wave == C) {
+            if (cons > 0) vm_wait<0>(); else vm_wait<12 * RG - 4>();
+            float nq[4], n_cp, n_dh;
+            chain_adopt_dw4(nq);
+            chain_adopt_dw2(n_cp, n_dh);
+            if (act) {
+                float dh_rec = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        dh_rec += psum[w][16 * g4 + 4 * cbb + ce][ci];
+                const CellGrad cg = cell_backward(nq[0], nq[1], nq[2], nq[3], n_ct, n_cp, dcv, n_dh + dh_rec);
+                di = cg.di; dj = cg.dj; df = cg.df; dg = cg.dg;
+                dcv = cg.dc_out;
+            }
+            n_ct = n_cp;                                                      // c_t of the next update (step t-1) is this step's c_{t-1}
+            float* f = &dzA[4 * ce + ci][cbb];
+            f[0] = di; f[16 * 4] = dj; f[32 * 4] = df; f[48 * 4] = dg;
+        }
+        __syncthreads();
+        // ---- C: next poll, slow traffic of wave C, MFMAs, publish
+        if (issue_next) {
+            f32x4* inn = inbox + (size_t)((tn + 1) & 1) * slot_w + in_base + (size_t)CN * PCU * 16;
+            chain_issue_fragments<CN>(inn, inn + 64, inn + 128, inn + 192);
+        }
+        if (wave == C) {
+            store_dw4_stride16_masked(actmask, gstore + (size_t)t * B * PG4, di, dj, df, dg);        // row-major dz for the weight-gradient GEMMs
+            const int tq = t > a.t0 ? t - 1 : t;
+            chain_issue_dw4(gload + (size_t)tq * B * PG4);
+            chain_issue_dw_a(a.Cs + (size_t)tq * B * PH + hic);
+            chain_issue_dw_b(a.dH + (size_t)tq * B * PH + hic);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (produce) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&dzA[lane][0]);
+            f32x4 acc[4];
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define CHAIN_BWD_B(B_)                                                                                     \
+            _Pragma("unroll") for (int cg = 0; cg < 4; ++cg)                                                \
+                acc[cg] = mfma44<B_>(av[v], W[16 * cg + 4 * v + (B_ >> 2)][B_ & 3], acc[cg]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                CHAIN_BWD_B(0) CHAIN_BWD_B(1) CHAIN_BWD_B(2) CHAIN_BWD_B(3) CHAIN_BWD_B(4) CHAIN_BWD_B(5) CHAIN_BWD_B(6) CHAIN_BWD_B(7)
+                CHAIN_BWD_B(8) CHAIN_BWD_B(9) CHAIN_BWD_B(10) CHAIN_BWD_B(11) CHAIN_BWD_B(12) CHAIN_BWD_B(13) CHAIN_BWD_B(14) CHAIN_BWD_B(15)
+            }
+#undef CHAIN_BWD_B
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // MFMA result -> VMEM store data: wait states by hand (inline-asm stores)
+            // the resets of part A must have landed before this block publishes anything (two-slot argument of k_lstm_bwd_rs);
+            // behind them: the poll (4) and, for wave C, 4 dz stores + 6 input loads
+            if (cons > 0 || !issue_next) vm_wait<0>();
+            else if (wave == C) vm_wait<14>();
+            else vm_wait<4>();
+            f32x4* out = inbox + (size_t)(t & 1) * slot_w + (size_t)C * PCU * 16;
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) store_sc1(out + out_ofs[cg], acc[cg]);
+        }
+        if (cons > 0) --cons;
+        return true;
+    };
+
+    for (int t = a.t1 - 1; t >= a.t0; --t) {
+        if (!phase(std::integral_constant<int, 0>{}, t)) return;
+        if (!phase(std::integral_constant<int, 1>{}, t)) return;
+        if constexpr (RG > 2) { if (!phase(std::integral_constant<int, 2 % RG>{}, t)) return; }
+        if constexpr (RG > 3) { if (!phase(std::integral_constant<int, 3 % RG>{}, t)) return; }
+    }
+    if (act) a.dc[hic] = dcv;
+}
+
 // Kh [1024][4096] (packed gate columns) -> the register images of the pair kernels (same convention as k_repack_kh_xcd):
 //   fwd word i (= 16q + b, q < 4), component e of (cu, w), lane l:  Kh[256w + 64q + 16(b/4) + 4(b%4) + e][64cu + l]
 //   bwd word i, component e' of (cu, w), lane l, r = 4i + e' = 64cg + k (cg < 4):  Kh[256w + 64cg + l][64cu + k]
@@ -834,7 +1295,14 @@ hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, floa
 // Variants chosen per shape (tools/xcd_chain_bench, profiles/r03_xcd_probe6*.log; B = 45: forward 2.21 -> 2.14 us per step with
 // the outputs deferred, backward 2.40 -> 2.34 without the sleep; B = 100: deferring costs 4 %, no sleep is neutral)
 int lstm_xcd_default_variant(int B, bool forward, int Hp) {
-    if (Hp == PH) return XCD_NO_POLL_SLEEP;
+    // hidden 1024 (profiles/r03_pair_probe3..5.log, us per step without / with chains): backward 9.0 -> 7.2 (three row groups),
+    // 6.75 -> 5.1 (two), 12.2 -> 9.4 (four); forward 4.65 -> 4.2 with two row groups, but 6.1 -> 6.35 / 7.4 -> 8.4 with three / four
+    // (its early polls are ready 95 % of the time: the hand-off IS hidden, the per-phase instruction overhead is what is left)
+    if (Hp == PH) {
+        const int rg = xcd_row_groups(B, PH);
+        if (rg >= 2 && (!forward || rg == 2)) return XCD_CHAINS | XCD_NO_POLL_SLEEP;
+        return XCD_NO_POLL_SLEEP;
+    }
     if (!forward) return XCD_NO_POLL_SLEEP;
     return xcd_row_groups(B) <= 2 ? (XCD_DEFER_OUTPUTS | XCD_NO_POLL_SLEEP) : XCD_NO_POLL_SLEEP;
 }
@@ -843,8 +1311,17 @@ hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {
     if (a.t1 <= a.t0) return hipSuccess;
     const dim3 grid(NXCD * NCU), block(256);
     if (a.Hp == PH) {
-        if (a.prof) return hipErrorInvalidValue;
-        switch (xcd_row_groups(a.B, PH)) {
+        const int rg = xcd_row_groups(a.B, PH);
+        if (a.prof && !((a.variant & XCD_CHAINS) && rg >= 2)) return hipErrorInvalidValue;
+        if ((a.variant & XCD_CHAINS) && rg >= 2) {
+            switch (rg) {
+                case 2: hipLaunchKernelGGL((k_lstm_fwd_pair_chains<2>), grid, block, 0, s, a); break;
+                case 3: hipLaunchKernelGGL((k_lstm_fwd_pair_chains<3>), grid, block, 0, s, a); break;
+                default: hipLaunchKernelGGL((k_lstm_fwd_pair_chains<4>), grid, block, 0, s, a); break;
+            }
+            return hipGetLastError();
+        }
+        switch (rg) {
             case 1: hipLaunchKernelGGL((k_lstm_fwd_pair<1>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((k_lstm_fwd_pair<2>), grid, block, 0, s, a); break;
             case 3: hipLaunchKernelGGL((k_lstm_fwd_pair<3>), grid, block, 0, s, a); break;
@@ -871,8 +1348,17 @@ hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a) {
     if (a.t1 <= a.t0) return hipSuccess;
     const dim3 grid(NXCD * NCU), block(256);
     if (a.Hp == PH) {
-        if (a.prof) return hipErrorInvalidValue;
-        switch (xcd_row_groups(a.B, PH)) {
+        const int rg = xcd_row_groups(a.B, PH);
+        if (a.prof && !((a.variant & XCD_CHAINS) && rg >= 2)) return hipErrorInvalidValue;
+        if ((a.variant & XCD_CHAINS) && rg >= 2) {
+            switch (rg) {
+                case 2: hipLaunchKernelGGL((k_lstm_bwd_pair_chains<2>), grid, block, 0, s, a); break;
+                case 3: hipLaunchKernelGGL((k_lstm_bwd_pair_chains<3>), grid, block, 0, s, a); break;
+                default: hipLaunchKernelGGL((k_lstm_bwd_pair_chains<4>), grid, block, 0, s, a); break;
+            }
+            return hipGetLastError();
+        }
+        switch (rg) {
             case 1: hipLaunchKernelGGL((k_lstm_bwd_pair<1>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((k_lstm_bwd_pair<2>), grid, block, 0, s, a); break;
             case 3: hipLaunchKernelGGL((k_lstm_bwd_pair<3>), grid, block, 0, s, a); break;

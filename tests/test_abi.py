@@ -72,3 +72,13 @@ def test_product_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 text = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text, os.path.join(dirpath, f)
+
+
+def test_chain_kernels_keep_their_landing_registers():
+    """tools/check_xcd_asm.py on a fresh hipcc -S of csrc/lstm_xcd.hip: the row-group-chain kernels' in-flight loads land in
+    fixed registers nothing else touches, and the compiler put no vmcnt wait of its own into their time loops."""
+    import subprocess
+    import sys
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_xcd_asm.py')], stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:]

@@ -362,7 +362,8 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
             CK(hipMemset(d.err, 0, 4));
         }
         {                    // variants (same results): 16 = XCD_DEFER_OUTPUTS, 32 = XCD_NO_POLL_SLEEP
-            for (int dbg : {16, 32, 48}) {
+            for (int dbg : {16, 32, 48, 96, 160}) {
+                if ((dbg & (64 | 128)) && H != 1024) continue;  // XCD_CHAINS / XCD_INCREMENTAL_POLL: hidden 1024 only
                 float best_f = 1e9f, best_b = 1e9f;
                 for (int rep = 0; rep < 5; ++rep) {
                     fwd_xcd(T, 0);
@@ -378,10 +379,34 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                     CK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
                 }
-                printf("[4] B=%d H=%d variant %d (%s%s): fwd %.2f us/step | bwd %.2f us/step  err_flag %d\n", B, H, dbg, (dbg & 16) ? "deferred stores " : "", (dbg & 32) ? "no poll sleep" : "",
+                printf("[4] B=%d H=%d variant %d (%s%s): fwd %.2f us/step | bwd %.2f us/step  err_flag %d\n", B, H, dbg, (dbg & 16) ? "deferred stores " : "", (dbg & 64) ? "row-group chains, no poll sleep" : (dbg & 128) ? "incremental poll, no poll sleep" : (dbg & 32) ? "no poll sleep" : "",
                        best_f * 1e3 / T, best_b * 1e3 / T, read_err());
                 CK(hipMemset(d.err, 0, 4));
             }
+        }
+        if (H == 1024) {     // chain kernels: how many of the early-issued polls were NOT ready when their phase started
+            unsigned long long* prof; CK(hipMalloc(&prof, 8ull * 64));
+            unsigned long long hp[16];
+            for (int dir = 0; dir < 2; ++dir) {
+                CK(hipMemset(prof, 0, 8ull * 64));
+                if (dir == 0) {
+                    fwd_xcd(T, 0);
+                    LstmFwdXcdArgs a{}; a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = 96; a.Hp = H;
+                    if (launch_lstm_fwd_xcd(s, a) != hipSuccess) continue;
+                } else {
+                    bwd_xcd(T, 0);
+                    LstmBwdXcdArgs a{}; a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = 96; a.Hp = H;
+                    if (launch_lstm_bwd_xcd(s, a) != hipSuccess) continue;
+                }
+                CK(hipStreamSynchronize(s));
+                CK(hipMemcpy(hp, prof, 8 * 8, hipMemcpyDeviceToHost));
+                printf("[4] B=%d H=1024 chains %s: early polls checked / not ready per wave: %llu/%llu %llu/%llu %llu/%llu %llu/%llu\n", B, dir ? "bwd" : "fwd",
+                       hp[0], hp[4], hp[1], hp[5], hp[2], hp[6], hp[3], hp[7]);
+            }
+            hipFree(prof);
+            CK(hipMemset(d.err, 0, 4));
         }
         if (B == 45 && H == 512) {       // phase profile of the instrumented build (RG = 2)
             unsigned long long* prof; CK(hipMalloc(&prof, 8ull * 256 * 4 * 8));
