@@ -148,8 +148,7 @@ hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* b
 // variants of the XCD-local kernels (same results, different schedules of the cell threads' memory traffic)
 enum { XCD_DEFER_OUTPUTS = 16,      // forward: c / h / gate stores of step t are issued behind the poll of step t+1; backward: dz stores behind the drain
        XCD_NO_POLL_SLEEP = 32,      // no s_sleep between two polls of a hand-off
-       XCD_CHAINS = 64,             // hidden 1024: the row groups of an XCD pair as independent chains (k_lstm_*_pair_chains)
-       XCD_INCREMENTAL_POLL = 128 };  // hidden 1024, forward without chains: a poll round re-fetches only the fragments that were incomplete
+       XCD_CHAINS = 64 };           // hidden 1024: the row groups of an XCD pair as independent chains (k_lstm_*_pair_chains)
 int lstm_xcd_default_variant(int B, bool forward, int Hp = 512);
 struct LstmFwdXcdArgs {
     const float* KhX;     // forward register image of K_h (launch_repack_kh_xcd)

@@ -103,29 +103,6 @@ __device__ __forceinline__ bool wait_all_fragments(const f32x4* af, f32x4 (&av)[
     }
 }
 
-// The same with memory of what has arrived: a round fetches only the fragments that were not complete in the round before.
-// For hand-offs that cross the fabric (XCD pairs: a write-through line is in nobody's L2) a round of N fragments moves N KB
-// per wave, and the early rounds of a step would move all of them again for the sake of the one producer that is late.
-template <int N>
-__device__ __forceinline__ bool wait_fragments_incremental(const f32x4* af, f32x4 (&av)[N], int spin_limit, int* err_flag, bool nosleep) {
-    unsigned need = (1u << N) - 1u;
-    for (int spins = 0;; ++spins) {
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-            if (need & (1u << j)) av[j] = load_sc1(af + j * 64);
-        drain_vmem();
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-            if (need & (1u << j)) {
-                asm volatile("" : "+v"(av[j]));
-                if (__all(frag_ready(av[j]))) need &= ~(1u << j);
-            }
-        if (need == 0) return true;
-        if (!nosleep) __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
-        if (spins >= spin_limit || ((spins & 255) == 255 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) return false;
-    }
-}
-
 struct Role { int xcd, cu; };
 
 // every block: XCC id + a ticket from that XCD's counter.  Returns false (and raises the flag) when the XCD is over-subscribed.
@@ -569,10 +546,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair(const LstmFwdXcdArgs a
     for (int t = a.t0; t < a.t1; ++t) {
         f32x4 av[NF];
         {
-            const bool nosleep = (a.variant & XCD_NO_POLL_SLEEP) != 0;
-            const bool fail = (a.variant & XCD_INCREMENTAL_POLL)
-                                  ? !wait_fragments_incremental<NF>(hx_in + (size_t)t * hx_step, av, a.spin_limit, a.err_flag, nosleep)
-                                  : !wait_all_fragments<NF>(hx_in + (size_t)t * hx_step, av, a.spin_limit, a.err_flag, nosleep);
+            const bool fail = !wait_all_fragments<NF>(hx_in + (size_t)t * hx_step, av, a.spin_limit, a.err_flag, (a.variant & XCD_NO_POLL_SLEEP) != 0);
             if (fail && lane == 0) {
                 __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_fail = 1;
@@ -1297,7 +1271,9 @@ hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, floa
 int lstm_xcd_default_variant(int B, bool forward, int Hp) {
     // hidden 1024 (profiles/r03_pair_probe3..5.log, us per step without / with chains): backward 9.0 -> 7.2 (three row groups),
     // 6.75 -> 5.1 (two), 12.2 -> 9.4 (four); forward 4.65 -> 4.2 with two row groups, but 6.1 -> 6.35 / 7.4 -> 8.4 with three / four
-    // (its early polls are ready 95 % of the time: the hand-off IS hidden, the per-phase instruction overhead is what is left)
+    // (its early polls are ready 95 % of the time: the hand-off IS hidden, the per-phase instruction overhead is what is left).
+    // Also measured and dropped for the forward kernel without chains: poll rounds that re-fetch only the incomplete fragments
+    // (6.06 -> 6.32, profiles/r03_pair_probe6.log)
     if (Hp == PH) {
         const int rg = xcd_row_groups(B, PH);
         if (rg >= 2 && (!forward || rg == 2)) return XCD_CHAINS | XCD_NO_POLL_SLEEP;

@@ -362,8 +362,8 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
             CK(hipMemset(d.err, 0, 4));
         }
         {                    // variants (same results): 16 = XCD_DEFER_OUTPUTS, 32 = XCD_NO_POLL_SLEEP
-            for (int dbg : {16, 32, 48, 96, 160}) {
-                if ((dbg & (64 | 128)) && H != 1024) continue;  // XCD_CHAINS / XCD_INCREMENTAL_POLL: hidden 1024 only
+            for (int dbg : {16, 32, 48, 96}) {
+                if ((dbg & 64) && H != 1024) continue;          // XCD_CHAINS: hidden 1024 only
                 float best_f = 1e9f, best_b = 1e9f;
                 for (int rep = 0; rep < 5; ++rep) {
                     fwd_xcd(T, 0);
@@ -379,7 +379,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                     CK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
                 }
-                printf("[4] B=%d H=%d variant %d (%s%s): fwd %.2f us/step | bwd %.2f us/step  err_flag %d\n", B, H, dbg, (dbg & 16) ? "deferred stores " : "", (dbg & 64) ? "row-group chains, no poll sleep" : (dbg & 128) ? "incremental poll, no poll sleep" : (dbg & 32) ? "no poll sleep" : "",
+                printf("[4] B=%d H=%d variant %d (%s%s): fwd %.2f us/step | bwd %.2f us/step  err_flag %d\n", B, H, dbg, (dbg & 16) ? "deferred stores " : "", (dbg & 64) ? "row-group chains, no poll sleep" : (dbg & 32) ? "no poll sleep" : "",
                        best_f * 1e3 / T, best_b * 1e3 / T, read_err());
                 CK(hipMemset(d.err, 0, 4));
             }
