@@ -528,10 +528,32 @@ inline Lane aux_lane(fsmg_model* h, bool forward_only = false, bool persistent_c
 
 // C (contiguous, ldc == N) = op(A) * op(B) with the K range split over pick_split() slabs that are
 // summed in a fixed order (deterministic); colsum likewise.
+// Which bf16-split kernel: the wave-specialised k_gemm_bx3w (same bits as k_gemm_bx3 for the same K split; two 512-thread
+// blocks per CU) pays where blocks are short-lived or few -- the projection (K = hidden size: 32 k tiles per block, +5-9 %)
+// and the weight-gradient GEMMs whose M x N is only a few dozen tiles (dKh, dKx, dx: +15-20 %, a block alone on its CU
+// needs 1700 cycles per k tile instead of 2470) -- and is a wash on the two large contractions over the vocabulary / the
+// rows (tools/gemm_bench BX3=1 vs 2, profiles/r03_gemm_prof*.log).  FSMG_GEMM_WS=0 / 2: never / always (A/B runs).
+bool use_ws_gemm(fsmg_model* h, int amode, int bmode, const GemmArgs& g, const Lane& ln) {
+    static const int mode = std::getenv("FSMG_GEMM_WS") ? std::atoi(std::getenv("FSMG_GEMM_WS")) : 1;
+    if (!h->bx3 || mode == 0 || ln.lds_pad != 0 || g.xcd_first != 0) return false;
+    if (mode == 2) return true;
+    // measured in the cfg-B step (profiles/r03b_bench_ws*.json, ms per launch without / with): projection 0.328 / 0.312,
+    // dW 0.388 / 0.365, dx 0.052 / 0.048; zx 0.046 / 0.055, dH 0.336 / 0.349, dKh + dKx 0.149 / 0.151
+    const int64_t tiles = ((g.M + 127) / 128) * (int64_t)((g.N + 127) / 128);
+    if (amode == OP_KC && bmode == OP_XC) return g.K >= 384 && tiles >= 512;                // projection-like
+    if (amode == OP_XC && bmode == OP_XC) return tiles >= 256;                              // dW
+    return g.K <= 4096;                                                                     // KC x KC: dx yes, dH no
+}
+
 int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g) {
     hipStream_t s = ln.s;
     g.bx3 = h->bx3;
-    const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K, ln.slots, g.bx3 != 0) : 1;
+    int slots = ln.slots;
+    if (use_ws_gemm(h, amode, bmode, g, ln)) {
+        g.bx3 = 2; slots = 512 * 4 / 3;             // pick_split takes 3/4 of `slots` for the bf16-split kernels: 512 here
+        if (amode == OP_KC && bmode == OP_XC) g.group_m = 4;
+    }
+    const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K, slots, g.bx3 != 0) : 1;
     if (S <= 1 || (int64_t)S * g.M * g.N > h->slab_cap) {
         g.ksplit = 1;
         HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
@@ -739,6 +761,7 @@ int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t 
         ScopedTimer tm(h, "gemm_logits");
         g.ce_part = h->ce_part + (size_t)r0 * h->ce_nparts; g.ce_tgt = h->Y + r0; g.ce_tgt_logit = h->tgt_logit + r0;
         g.ce_nvocab = h->V1; g.bx3 = h->bx3;
+        if (use_ws_gemm(h, OP_KC, OP_XC, g, ln)) { g.bx3 = 2; g.group_m = 4; }
         HIPCK(h, launch_gemm(ln.s, OP_KC, OP_XC, g, ln.lds_pad));          // K = Hp: never split
         HIPCK(h, launch_ce_combine(ln.s, h->ce_part + (size_t)r0 * h->ce_nparts, h->ce_nparts,
                                    h->tgt_logit + r0, (int)m, h->ce + r0));

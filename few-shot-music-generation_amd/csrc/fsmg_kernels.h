@@ -37,7 +37,11 @@ struct GemmArgs {
     //                  the remaining items read.
     // Placement decides speed, never results: an item is computed once, by the same code either way.
     int xcd_first; int* work; int* claim; int work_limit; const int* stop;
-    int bx3;                // 1: k_gemm_bx3 -- fp32 product from three bf16 planes per operand on the bf16 matrix pipe (gemm.hip)
+    int bx3;                // 1: k_gemm_bx3 -- fp32 product from three bf16 planes per operand on the bf16 matrix pipe (gemm.hip);
+                            // 2: k_gemm_bx3w, its wave-specialised variant (same bits; two 512-thread blocks per CU)
+    int group_m;                // bf16-split kernels: tile order, see tile_coords (gemm.hip); 0 = row tiles fastest
+    unsigned long long* prof;   // diagnostics (tools/gemm_bench PROF=1, bx3 only): [blocks][waves][8] stamps, see k_gemm_bx3
+    int dbg;                    // diagnostics, stamped instantiation only (k_gemm_bx3w): ablation bits, results are wrong
 };
 // amode/bmode in {OP_KC, OP_XC}. Supported combinations: (KC,XC) (XC,XC) (KC,KC)
 hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, int lds_pad = 0);

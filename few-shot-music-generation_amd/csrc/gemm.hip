@@ -197,6 +197,20 @@ __device__ __forceinline__ int xcd_tile(int bid, int nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// tile id (in the order an XCD walks its range) -> (row tile, column tile).  group_m = 0: row tiles fastest (a column
+// panel of B is shared by consecutive blocks, A is streamed once per column panel).  group_m = G > 0: super-rows of G row
+// tiles, inside a super-row column tiles slowest... i.e. G consecutive ids share a B panel and the next G the same A
+// panels: the blocks resident on an XCD at one time then touch few panels of EITHER operand, so both stay in its 4 MiB L2
+// (G = 1: column tiles fastest, for GEMMs whose A is the big operand).  Placement only; results do not change.
+__device__ __forceinline__ void tile_coords(int t, int tilesM, int tilesN, int group_m, int& tm, int& tn) {
+    if (group_m <= 0) { tm = t % tilesM; tn = t / tilesM; return; }
+    const int per = group_m * tilesN;
+    const int r = t / per, w = t - r * per;
+    const int gm = min(group_m, tilesM - r * group_m);
+    tn = w / gm;
+    tm = r * group_m + (w - tn * gm);
+}
+
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(NTHREADS, (BK == 16 ? 1024 : 512) / NTHREADS) void k_gemm_staged(const GemmArgs g) {
     constexpr int LDA = TileLd<AMODE, BM>::v, LDB = TileLd<BMODE, BN>::v;
@@ -538,6 +552,28 @@ __device__ __forceinline__ void split2(float x, float y, unsigned& p0, unsigned&
     p2 = cvt_pk_bf16(sx, sy);
 }
 
+// the same for eight values, the four independent chains advanced stage by stage: the instructions of one chain depend on
+// each other (a wave alone needs 62 cycles per pair that way, tools/split_probe), and the compiler keeps inline asm in
+// source order, so the interleaving is written out
+__device__ __forceinline__ float sub_f32(float a, unsigned b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split8(const float (&v)[8], unsigned (&w)[3][4]) {
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[0][j] = cvt_pk_bf16(v[2 * j], v[2 * j + 1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[2 * j] = sub_f32(v[2 * j], w[0][j] << 16); r[2 * j + 1] = sub_f32(v[2 * j + 1], w[0][j] & 0xffff0000u); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[1][j] = cvt_pk_bf16(r[2 * j], r[2 * j + 1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[2 * j] = sub_f32(r[2 * j], w[1][j] << 16); r[2 * j + 1] = sub_f32(r[2 * j + 1], w[1][j] & 0xffff0000u); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[2][j] = cvt_pk_bf16(r[2 * j], r[2 * j + 1]);
+}
+
 constexpr int BX_PLANE = 2 * 128 * 16;          // bytes: [2 k halves][128 x][8 bf16]
 constexpr int BX_OPER = 3 * BX_PLANE;           // one operand tile, three planes
 constexpr int BX_STAGE = 2 * BX_OPER;           // A + B
@@ -549,8 +585,9 @@ constexpr int BX_STAGE = 2 * BX_OPER;           // A + B
 //       the 64 bytes a row contributes to the tile); two 8-byte LDS writes per plane.
 //   XC with gathered K rows (dKx: row k of the operand is row gather[k] of the embedding): the eight row ids of the NEXT
 //       tile are fetched one tile ahead, so a tile's loads do not wait for an index load first.
-template <int MODE>
+template <int MODE, int XT = 128>         // XT: x extent of the LDS tile the stager writes into (it covers 128 of them)
 struct BxStager {
+    static constexpr int KH = XT * 16, PLANE = 2 * KH;
     const float* p[2];
     float v[8];
     long long step, ld_;
@@ -558,17 +595,18 @@ struct BxStager {
     const int* gp;          // XC + gather: &gather[k] of this thread's first row of the next tile
     int gk, gK;             // ... that k, and the K bound of the gather array
     int gi[8];
+    int kstep;              // k advance per fetch: 16, or 32 when two stagers take alternate tiles (k_gemm_bx3w)
     __device__ __forceinline__ void load_ids() {
 #pragma unroll
         for (int i = 0; i < 8; ++i) gi[i] = gp[min(i, gK - 1 - gk)];      // clamped: the id of a row past K is never used
     }
-    __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather, int kb, int tid, int K = 0) {
-        ld_ = ld; gp = nullptr;
+    __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather, int kb, int tid, int K = 0, int kstep_ = 16, int xl0 = 0) {
+        ld_ = ld; gp = nullptr; kstep = kstep_;
         if (MODE == OP_XC) {
             const int x = min(x0 + (tid & 127), X - 1), kh = tid >> 7;
             p[0] = src + (long long)(kb + 8 * kh) * ld + x; p[1] = nullptr;
-            step = (long long)16 * ld;
-            lds_ofs[0] = kh * 2048 + (tid & 127) * 16; lds_ofs[1] = 0;
+            step = (long long)kstep * ld;
+            lds_ofs[0] = kh * KH + (xl0 + (tid & 127)) * 16; lds_ofs[1] = 0;
             if (gather != nullptr) {
                 p[0] = src + x;
                 gK = K; gk = min(kb + 8 * kh, K - 1); gp = gather + gk;
@@ -581,13 +619,13 @@ struct BxStager {
                 const int xl = (tid >> 2) + 64 * i, x = min(x0 + xl, X - 1);
                 const long long row = gather ? (long long)gather[x] : (long long)x;
                 p[i] = src + row * ld + kb + 4 * kq;
-                lds_ofs[i] = (kq >> 1) * 2048 + xl * 16 + (kq & 1) * 8;
+                lds_ofs[i] = (kq >> 1) * KH + (xl0 + xl) * 16 + (kq & 1) * 8;
             }
-            step = 16;
+            step = kstep;
         }
     }
     __device__ __forceinline__ void advance_ids() {          // ids of the tile after the one just requested
-        const int nk = min(gk + 16, gK - 1);
+        const int nk = min(gk + kstep, gK - 1);
         gp += nk - gk; gk = nk;
         load_ids();
     }
@@ -637,21 +675,26 @@ struct BxStager {
     __device__ __forceinline__ float sum8() const { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
     __device__ __forceinline__ void commit(unsigned char* tile) const {
         unsigned w[3][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], w[0][j], w[1][j], w[2][j]);
+        split8(v, w);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             if (MODE == OP_XC) {
-                *reinterpret_cast<uint4*>(tile + pl * BX_PLANE + lds_ofs[0]) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+                *reinterpret_cast<uint4*>(tile + pl * PLANE + lds_ofs[0]) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
             } else {
-                *reinterpret_cast<uint2*>(tile + pl * BX_PLANE + lds_ofs[0]) = make_uint2(w[pl][0], w[pl][1]);
-                *reinterpret_cast<uint2*>(tile + pl * BX_PLANE + lds_ofs[1]) = make_uint2(w[pl][2], w[pl][3]);
+                *reinterpret_cast<uint2*>(tile + pl * PLANE + lds_ofs[0]) = make_uint2(w[pl][0], w[pl][1]);
+                *reinterpret_cast<uint2*>(tile + pl * PLANE + lds_ofs[1]) = make_uint2(w[pl][2], w[pl][3]);
             }
         }
     }
 };
 
-template <int AMODE, int BMODE>
+// PROF (tools/gemm_bench PROF=1): per (block, wave) s_memtime stamps -> g.prof[(block * 4 + wave) * 8 + ...]:
+//   [0] entry, [1] first loop iteration, [2] sum over k tiles of (fragment reads + MFMA issue), [3] sum of (wait for the
+//   next tile's loads + split + LDS writes), [4] sum of (LDS drain + barrier), [5] loop exit, [6] kernel exit,
+//   [7] XCC_ID << 32 | HW_ID
+#define BX_STAMP(i) if (PROF) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+                                __builtin_amdgcn_sched_barrier(0); pacc[i] += n_ - plast; plast = n_; }
+template <int AMODE, int BMODE, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_bx3(const GemmArgs g) {
     constexpr int EPI = 4 * 32 * 68 * 4;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[(2 * BX_STAGE > EPI) ? 2 * BX_STAGE : EPI];
@@ -661,8 +704,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(const GemmArgs g) {
     const int l31 = lane & 31, khalf = lane >> 5;
     const int tilesM = (g.M + 127) / 128, tilesN = (g.N + 127) / 128;
     const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
-    const int tm = bid % tilesM, tn = bid / tilesM, z = blockIdx.y;
+    int tm, tn; tile_coords(bid, tilesM, tilesN, g.group_m, tm, tn);
+    const int z = blockIdx.y;
     const int m0 = tm * 128, n0 = tn * 128;
+    unsigned long long pacc[5] = {0, 0, 0, 0, 0}, plast = 0, p_entry = 0, p_loop = 0;
+    if (PROF) { p_entry = plast = __builtin_amdgcn_s_memtime(); }
 
     int kb = 0, ke = g.K;
     if (g.ksplit > 1) {
@@ -699,6 +745,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(const GemmArgs g) {
     __syncthreads();
 
     const int fa = khalf * 2048 + (wm * 64 + l31) * 16, fb = khalf * 2048 + (wn * 64 + l31) * 16;
+    if (PROF) { p_loop = plast = __builtin_amdgcn_s_memtime(); }
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
@@ -724,13 +771,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(const GemmArgs g) {
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][1], acc[1][1], 0, 0, 0);
         BX_TERM(2, 0) BX_TERM(0, 2) BX_TERM(1, 1) BX_TERM(1, 0) BX_TERM(0, 1) BX_TERM(0, 0)
 #undef BX_TERM
+        BX_STAMP(2)
         if (more) {
             if (do_colsum) csum += sb.sum8();
             sa.commit(smem + (cur ^ 1) * BX_STAGE);
             sb.commit(smem + (cur ^ 1) * BX_STAGE + BX_OPER);
         }
+        BX_STAMP(3)
         __syncthreads();
+        BX_STAMP(4)
     }
+    const unsigned long long p_exit_loop = PROF ? __builtin_amdgcn_s_memtime() : 0;
 
     float* smem_f = reinterpret_cast<float*>(smem);
     if (do_colsum) {                    // the two k halves of a column live in threads tid and tid + 128
@@ -740,7 +791,174 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(const GemmArgs g) {
         if (tid < 128 && n0 + tid < g.N) g.colsum[(long long)z * g.colsum_slab + n0 + tid] = csum + s_cs[tid];
     }
     store_tile(g, acc, smem_f, z, m0, n0, tn, tilesN, wave, lane);
+    if (PROF && g.prof != nullptr && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long p_end = __builtin_amdgcn_s_memtime();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* o = g.prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        o[0] = p_entry; o[1] = p_loop; o[2] = pacc[2]; o[3] = pacc[3]; o[4] = pacc[4]; o[5] = p_exit_loop; o[6] = p_end;
+        o[7] = ((unsigned long long)xcc << 32) | hw;
+    }
 }
+
+// Wave-specialised variants (GemmArgs::bx3 == 2: MT = 1, 128 x 128 block tile; bx3 == 3: MT = 2, 256 x 128): the same LDS
+// image per 128 rows, k order and term order as k_gemm_bx3 -- hence the same bits for the same K split -- but the block has
+// 4 MT "multiplier" waves (64 x 64 each) that only read fragments and issue MFMAs, and 4 "loader" waves that only load, split
+// and write the next tile (a workgroup's waves are dealt to the SIMDs cyclically, so every SIMD gets MT multipliers and one
+// loader per block).  Why (tools/gemm_bench PROF=1, profiles/r03_gemm_prof*.log): in k_gemm_bx3 a lone 4-wave block needs
+// 2470 cycles per k tile for 768 cycles of MFMAs -- reads, MFMAs, ~100 VALU instructions of the split, LDS writes and the
+// barrier are one serial chain per wave, and three co-resident blocks only fill the matrix pipe to 70 %.  With the roles
+// split the multipliers' chain is reads + MFMAs (1060-1300 cycles), and the split issues in the MFMA shadow of other waves;
+// it then is the VALU that binds (31 cycles per value: 16 values per thread and k tile = 500 of the 768 cycles per multiplier
+// wave at MT = 1), which is what MT = 2 relieves: a 256 x 128 tile splits 0.75 x the values per MFMA.
+// The loaders fetch two tiles ahead (two register sets taking alternate tiles).
+__device__ __forceinline__ void bx_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int AMODE, int BMODE, int MT, bool PROF = false>
+__global__ __launch_bounds__(256 * (MT + 1), MT == 1 ? 2 : 1) void k_gemm_bx3w(const GemmArgs g) {
+    constexpr int XA = 128 * MT;                       // rows of the block tile
+    constexpr int A_PLANE = 2 * XA * 16, A_OPER = 3 * A_PLANE, STAGE = A_OPER + BX_OPER;
+    constexpr int EPI = 4 * MT * 32 * 68 * 4;
+    constexpr int NMW = 4 * MT;                        // multiplier waves
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[(2 * STAGE > EPI) ? 2 * STAGE : EPI];
+    __shared__ float s_cs[128];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesM = (g.M + XA - 1) / XA, tilesN = (g.N + 127) / 128;
+    const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
+    int tm, tn; tile_coords(bid, tilesM, tilesN, g.group_m, tm, tn);
+    const int z = blockIdx.y;
+    const int m0 = tm * XA, n0 = tn * 128;
+    unsigned long long pacc[5] = {0, 0, 0, 0, 0}, plast = 0, p_entry = 0, p_loop = 0, p_exit_loop = 0;
+    if (PROF) { p_entry = plast = __builtin_amdgcn_s_memtime(); }
+
+    int kb = 0, ke = g.K;
+    if (g.ksplit > 1) {
+        const int per = ((g.K + g.ksplit - 1) / g.ksplit + 15) / 16 * 16;
+        kb = z * per;
+        ke = min(g.K, kb + per);
+    }
+    const int nk = (ke > kb) ? (ke - kb + 15) / 16 : 0;
+    const int nfull = (ke > kb) ? (ke - kb) / 16 : 0;
+
+    if (wave >= NMW) {
+        // ---------------------------------------------------------------- loaders: tile kt + 1 is split and written while
+        // the others multiply tile kt; its values were requested two iterations earlier
+        const int lt = tid - 64 * NMW;
+        BxStager<AMODE, XA> sa[2][MT];
+        BxStager<BMODE, 128> sb[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) sa[q][i].init(g.A, g.lda, g.M, m0 + 128 * i, g.gather, kb + 16 * q, lt, g.K, 32, 128 * i);
+            sb[q].init(g.B, g.ldb, g.N, n0, nullptr, kb + 16 * q, lt, 0, 32);
+        }
+        const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0;
+        float csum = 0.0f;
+#define BXW_FETCH(Q, T)                                                                                        \
+        if ((T) < nfull) {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) sa[Q][i].fetch();                                   \
+            sb[Q].fetch();                                                                                     \
+        } else {                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) sa[Q][i].fetch_partial(kb + (T) * 16, ke, lt);      \
+            sb[Q].fetch_partial(kb + (T) * 16, ke, lt);                                                        \
+        }
+#define BXW_COMMIT(Q, ST)                                                                                      \
+        if (do_colsum) csum += sb[Q].sum8();                                                                   \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) sa[Q][i].commit(smem + (ST) * STAGE);                   \
+        sb[Q].commit(smem + (ST) * STAGE + A_OPER);
+        // diagnostics (PROF instantiation only; results are wrong): g.dbg & 1 = no global loads inside the loop,
+        // g.dbg & 2 = no split / LDS writes inside the loop
+        const bool ld_on = !(PROF && (g.dbg & 1)), cm_on = !(PROF && (g.dbg & 2));
+        if (nk > 0) {
+            BXW_FETCH(0, 0)
+            if (nk > 1) { BXW_FETCH(1, 1) }
+            BXW_COMMIT(0, 0)
+            if (nk > 2) { BXW_FETCH(0, 2) }
+        }
+        bx_barrier();
+        if (PROF) { p_loop = plast = __builtin_amdgcn_s_memtime(); }
+        // stamped instantiation: [2] = the wait for the tile about to be split (the loads of the tile after it are younger)
+        constexpr int NLD = MT * (AMODE == OP_KC ? 2 : 8) + (BMODE == OP_KC ? 2 : 8);
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (PROF && kt + 3 < nk && g.gather == nullptr) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory"); BX_STAMP(2) }
+            if (kt + 1 < nk) {                      // tile kt + 1 sits in set 1
+                if (cm_on) { BXW_COMMIT(1, 1) }
+                if (kt + 3 < nk && ld_on) { BXW_FETCH(1, kt + 3) }
+            }
+            BX_STAMP(3)
+            bx_barrier();
+            BX_STAMP(4)
+            if (kt + 1 >= nk) break;
+            if (PROF && kt + 4 < nk && g.gather == nullptr) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory"); BX_STAMP(2) }
+            if (kt + 2 < nk) {                      // tile kt + 2 sits in set 0
+                if (cm_on) { BXW_COMMIT(0, 0) }
+                if (kt + 4 < nk && ld_on) { BXW_FETCH(0, kt + 4) }
+            }
+            BX_STAMP(3)
+            bx_barrier();
+            BX_STAMP(4)
+        }
+#undef BXW_FETCH
+#undef BXW_COMMIT
+        if (PROF) p_exit_loop = __builtin_amdgcn_s_memtime();
+        if (do_colsum && lt >= 128) s_cs[lt - 128] = csum;
+        bx_barrier();
+        if (do_colsum && lt < 128 && n0 + lt < g.N) g.colsum[(long long)z * g.colsum_slab + n0 + lt] = csum + s_cs[lt];
+    } else {
+        // ---------------------------------------------------------------- multipliers
+        const int wm = wave >> 1, wn = wave & 1;
+        const int l31 = lane & 31, khalf = lane >> 5;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        const int fa = khalf * (XA * 16) + (wm * 64 + l31) * 16, fb = khalf * 2048 + (wn * 64 + l31) * 16;
+        bx_barrier();
+        if (PROF) { p_loop = plast = __builtin_amdgcn_s_memtime(); }
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned char* at = smem + (kt & 1) * STAGE;
+            const unsigned char* bt = at + A_OPER;
+            bf16x8_t a[3][2], b[3][2];
+#pragma unroll
+            for (int pl = 2; pl >= 0; --pl)            // the planes of the first terms first
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[pl][i] = *reinterpret_cast<const bf16x8_t*>(at + pl * A_PLANE + fa + i * 512);
+                    b[2 - pl][i] = *reinterpret_cast<const bf16x8_t*>(bt + (2 - pl) * BX_PLANE + fb + i * 512);
+                }
+#define BX_TERM(PA, PB)                                                                                        \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][0], acc[0][0], 0, 0, 0);            \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][1], acc[0][1], 0, 0, 0);            \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][0], acc[1][0], 0, 0, 0);            \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][1], acc[1][1], 0, 0, 0);
+            BX_TERM(2, 0) BX_TERM(0, 2) BX_TERM(1, 1) BX_TERM(1, 0) BX_TERM(0, 1) BX_TERM(0, 0)
+#undef BX_TERM
+            BX_STAMP(2)
+            bx_barrier();
+            BX_STAMP(4)
+        }
+        if (PROF) p_exit_loop = __builtin_amdgcn_s_memtime();
+        bx_barrier();
+        store_tile(g, acc, reinterpret_cast<float*>(smem), z, m0, n0, tn, tilesN, wave, lane);
+    }
+    if (PROF && g.prof != nullptr && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long p_end = __builtin_amdgcn_s_memtime();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* o = g.prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (NMW + 4) + wave) * 8;
+        o[0] = p_entry; o[1] = p_loop; o[2] = pacc[2]; o[3] = pacc[3]; o[4] = pacc[4]; o[5] = p_exit_loop; o[6] = p_end;
+        o[7] = ((unsigned long long)xcc << 32) | hw;
+    }
+}
+#undef BX_STAMP
 
 template <int AMODE, int BMODE>
 hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
@@ -755,8 +973,14 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
         return hipGetLastError();
     }
     dim3 grid(tilesM * tilesN, g.ksplit > 1 ? g.ksplit : 1);
+    if (g.bx3 == 2) {        // wave-specialised variant
+        if (g.prof != nullptr) hipLaunchKernelGGL((k_gemm_bx3w<AMODE, BMODE, 1, true>), grid, dim3(512), lds_pad, s, g);
+        else hipLaunchKernelGGL((k_gemm_bx3w<AMODE, BMODE, 1>), grid, dim3(512), lds_pad, s, g);
+        return hipGetLastError();
+    }
     if (g.bx3) {             // (gathered K rows included: BxStager)
-        hipLaunchKernelGGL((k_gemm_bx3<AMODE, BMODE>), grid, dim3(256), lds_pad, s, g);
+        if (g.prof != nullptr) hipLaunchKernelGGL((k_gemm_bx3<AMODE, BMODE, true>), grid, dim3(256), lds_pad, s, g);
+        else hipLaunchKernelGGL((k_gemm_bx3<AMODE, BMODE>), grid, dim3(256), lds_pad, s, g);
         return hipGetLastError();
     }
     // lds_pad: unused dynamic LDS that only lowers the number of co-resident blocks per CU

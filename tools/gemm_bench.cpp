@@ -68,6 +68,64 @@ static float* dev_random(size_t n, unsigned seed) {
     return d;
 }
 
+// PROF=1 (with BX3=1): one more launch of the shape through the stamped instantiation of k_gemm_bx3; prints where a wave's
+// cycles go per k tile, the prologue / epilogue share of a block's life and how many blocks a CU had in their k loop over time
+static void profile_launch(hipStream_t s, int amode, int bmode, GemmArgs g, int pad, int blocks, float ms_plain) {
+    const int NW = g.bx3 == 2 ? 8 : 4;                  // waves per block (bx3 == 2: 4 multipliers + 4 loaders)
+    unsigned long long* d; const size_t n = (size_t)blocks * NW * 8;
+    CK(hipMalloc(&d, n * 8)); CK(hipMemset(d, 0, n * 8));
+    g.prof = d;
+    g.dbg = getenv("DBG") ? atoi(getenv("DBG")) : 0;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(launch_gemm(s, amode, bmode, g, pad));             // warm the instantiation
+    CK(hipEventRecord(a, s)); CK(launch_gemm(s, amode, bmode, g, pad)); CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    std::vector<unsigned long long> h(n);
+    CK(hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost));
+    const int per = g.ksplit > 1 ? ((g.K + g.ksplit - 1) / g.ksplit + 15) / 16 * 16 : g.K;
+    const double nk = (per + 15) / 16;
+    // s_memtime is per XCD: normalise every stamp by the earliest entry seen on its XCD
+    unsigned long long base[16]; for (auto& v : base) v = ~0ull;
+    for (size_t w = 0; w < (size_t)blocks * NW; ++w) { const unsigned long long* o = &h[w * 8]; if (o[6]) { auto& m = base[(o[7] >> 32) & 15]; m = std::min(m, o[0]); } }
+    double span = 0;
+    for (int role = 0; role < (NW > 4 ? 2 : 1); ++role) {
+        double mf = 0, cm = 0, bar = 0, pro = 0, epi = 0, life = 0, loop = 0; size_t cnt = 0;
+        for (size_t w = 0; w < (size_t)blocks * NW; ++w) {
+            if (NW > 4 && (int)((w % NW) >= (size_t)(NW - 4)) != role) continue;
+            const unsigned long long* o = &h[w * 8];
+            if (o[6] == 0) continue;
+            mf += o[2]; cm += o[3]; bar += o[4]; pro += o[1] - o[0]; epi += o[6] - o[5]; life += o[6] - o[0]; loop += o[5] - o[1]; ++cnt;
+            span = std::max(span, (double)(o[6] - base[(o[7] >> 32) & 15]));
+        }
+        printf("    PROF %s: per wave and k tile (ticks): reads+MFMA issue %.0f  loads wait+split+LDS write %.0f  drain+barrier %.0f  (sum %.0f) | per block: prologue %.0f  loop %.0f  epilogue %.0f  -> pro+epi %.1f %% of its life\n",
+               NW > 4 ? (role ? "loaders    " : "multipliers") : "", mf / cnt / nk, cm / cnt / nk, bar / cnt / nk, (mf + cm + bar) / cnt / nk, pro / cnt, loop / cnt, epi / cnt, 100.0 * (pro + epi) / life);
+    }
+    printf("    PROF: stamped launch %.3f ms (plain %.3f); span %.0f ticks -> %.0f MHz; %.0f k tiles per block; MFMA pipe floor 768 ticks per k tile and wave\n", ms, ms_plain, span, span / (ms * 1e3), nk);
+    // blocks resident / in their k loop per CU over time (wave 0 of every block)
+    struct Iv { double a, b, c, e; unsigned key; };
+    std::vector<Iv> iv;
+    for (int bl = 0; bl < blocks; ++bl) {
+        const unsigned long long* o = &h[(size_t)bl * NW * 8];
+        if (o[6] == 0) continue;
+        const unsigned long long bs = base[(o[7] >> 32) & 15];
+        iv.push_back({(double)(o[0] - bs), (double)(o[1] - bs), (double)(o[5] - bs), (double)(o[6] - bs), (unsigned)((o[7] >> 32) & 0xf) << 8 | (unsigned)((o[7] >> 8) & 0xff)});
+    }
+    std::vector<unsigned> keys; for (auto& v : iv) keys.push_back(v.key);
+    std::sort(keys.begin(), keys.end()); keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    const int NB = 16;
+    double inloop[NB] = {0}, resident[NB] = {0};
+    for (auto& v : iv) for (int q = 0; q < NB; ++q) {
+        const double lo = span * q / NB, hi = span * (q + 1) / NB;
+        resident[q] += std::max(0.0, std::min(hi, v.e) - std::max(lo, v.a)) / (hi - lo);
+        inloop[q] += std::max(0.0, std::min(hi, v.c) - std::max(lo, v.b)) / (hi - lo);
+    }
+    printf("    PROF: %zu CUs seen; blocks per CU resident / in their k loop over %d time bins: ", keys.size(), NB);
+    double tot_r = 0, tot_l = 0;
+    for (int q = 0; q < NB; ++q) { printf("%.2f/%.2f ", resident[q] / keys.size(), inloop[q] / keys.size()); tot_r += resident[q]; tot_l += inloop[q]; }
+    printf("| mean %.2f / %.2f\n", tot_r / NB / keys.size(), tot_l / NB / keys.size());
+    CK(hipFree(d));
+}
+
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
     const int bpc = argc > 2 ? atoi(argv[2]) : 4;
@@ -121,6 +179,7 @@ int main(int argc, char** argv) {
             g.B = B; g.ldb = (sh.bmode == OP_KC) ? sh.K : sh.N;
             g.C = (S > 1) ? slabs : C; g.ldc = sh.N; g.M = sh.M; g.N = sh.N; g.K = sh.K;
             g.ksplit = S; g.c_slab = (long long)cn; g.bx3 = bx3;
+            g.group_m = getenv("GROUP_M") ? atoi(getenv("GROUP_M")) : 0;
             if (sh.colsum) { g.colsum = (S > 1) ? csl : cs; g.colsum_slab = sh.N; }
             float ms_k = 0, ms_t = 0;
             for (int r = -2; r < reps; ++r) {
@@ -154,6 +213,7 @@ int main(int argc, char** argv) {
             }
             printf("%s  M %5d N %5d K %5d  S %d  blocks %5d (%.2f rounds of %d)  gemm %.3f ms  total %.3f ms  %.1f TF\n", sh.name, sh.M, sh.N, sh.K, S,
                    tiles * S, tiles * S / (256.0 * bpc), 256 * bpc, ms_k, ms_t, 2.0 * sh.M * sh.N * sh.K / (ms_t * 1e-3) / 1e12);
+            if (getenv("PROF") && atoi(getenv("PROF")) && bx3 && xcd_first == 0) profile_launch(s, sh.amode, sh.bmode, g, pad, tiles * S, ms_k);
         }
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(cs));
         if (Cref) { CK(hipFree(Cref)); CK(hipFree(csref)); }
