@@ -332,10 +332,27 @@ def main():
         if os.environ.get('FSMG_BENCH_SCHEDULES'):
             keep = os.environ['FSMG_BENCH_SCHEDULES'].split(',')
             plans = [pl for pl in plans if pl[0] in keep] or plans[:1]
-    schedules, built = {}, {}
+    schedules, built, failed_plans = {}, {}, {}
     for name, env_over in plans:
-        m_, p_ = make(env_over)
-        el, g = timed(p_, m_.engine, name)
+        # a schedule that cannot be built or run on this box must not cost the run its result line: every rank reports whether
+        # it got through, and the schedule counts only if all did (the first plan is the one the step has always used)
+        err = None
+        try:
+            m_, p_ = make(env_over)
+            el, g = timed(p_, m_.engine, name)
+        except Exception as e:                  # noqa: BLE001 -- reported below, per rank
+            err = '%s: %s' % (type(e).__name__, e)
+            log('schedule %s FAILED on rank %d: %s' % (name, rank, err))
+        if world > 1:
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+        else:
+            errs = [err]
+        if any(errs):
+            if not schedules and name == plans[-1][0]:
+                raise SystemExit('no exchange schedule ran: %r' % errs)
+            failed_plans[name] = errs
+            continue
         per = [el]
         gs = [g]
         if world > 1:
@@ -446,6 +463,7 @@ def main():
             'per_rank_ms_per_step': [1e3 * t / max(args.steps, 1) for t in per_rank], 'comm': comm,
             'schedule_used': used,
             'schedules': {n: {k: v for k, v in sc.items() if k != 'guard_per_rank'} for n, sc in schedules.items()},
+            'schedules_failed': failed_plans,
             'guard_per_rank': schedules[used]['guard_per_rank'], 'world': world_info,
         }
         if cell:
