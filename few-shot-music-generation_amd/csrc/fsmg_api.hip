@@ -539,9 +539,11 @@ bool use_ws_gemm(fsmg_model* h, int amode, int bmode, const GemmArgs& g, const L
     if (mode == 2) return true;
     // measured in the cfg-B step (profiles/r03b_bench_ws*.json, ms per launch without / with): projection 0.328 / 0.312,
     // dW 0.388 / 0.365, dx 0.052 / 0.048; zx 0.046 / 0.055, dH 0.336 / 0.349, dKh + dKx 0.149 / 0.151
+    // At hidden size 1024 (cfg-C, profiles/r03d_cfg-C_ws*.json) the same kernel LOSES on the projection (K = 1024: 0.145 ->
+    // 0.162 ms) and on dKh / dW (M = 1024), so the rule is a table of the shapes it was measured to win on, not a model.
     const int64_t tiles = ((g.M + 127) / 128) * (int64_t)((g.N + 127) / 128);
-    if (amode == OP_KC && bmode == OP_XC) return g.K >= 384 && tiles >= 512;                // projection-like
-    if (amode == OP_XC && bmode == OP_XC) return tiles >= 256;                              // dW
+    if (amode == OP_KC && bmode == OP_XC) return g.K >= 384 && g.K <= 640 && tiles >= 512;  // projection at hidden 512
+    if (amode == OP_XC && bmode == OP_XC) return tiles >= 256 && g.M <= 512;                // dW at hidden 512
     return g.K <= 4096;                                                                     // KC x KC: dx yes, dH no
 }
 

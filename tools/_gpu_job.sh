@@ -1,9 +1,8 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r03b_pytest_gpu.log 2>&1
-tail -15 gpurun_out/r03b_pytest_gpu.log
-for m in 1 0; do FSMG_GEMM_WS=$m timeout 600 python bench.py --steps 40 --warmup 8 > gpurun_out/r03c_bench_ws$m.json 2> gpurun_out/r03c_bench_ws$m.err; tail -c 400 gpurun_out/r03c_bench_ws$m.json | head -c 10; python - <<PY
+for c in cfg-C cfg-E cfg-B; do for m in 0 1; do FSMG_GEMM_WS=$m timeout 600 python bench.py --config $c --steps 30 --warmup 6 --no-cpu-baseline > gpurun_out/r03e_${c}_ws$m.json 2> gpurun_out/r03e_${c}_ws$m.err; python - <<PY
 import json
-d=json.loads(open('gpurun_out/r03c_bench_ws$m.json').read().strip().splitlines()[-1])
-print('WS=$m', round(d['value'],1), round(d['ms_per_step'],4), d['guard']['ok'])
+d=json.loads(open('gpurun_out/r03e_${c}_ws$m.json').read().strip().splitlines()[-1])
+ks=d.get('kernels') or {}
+print('$c WS=$m', round(d['value'],1), round(d['ms_per_step'],4), d['guard']['ok'], {k: round(v['ms_per_step'],4) for k,v in ks.items() if k.startswith('gemm')})
 PY
-done
+done; done
