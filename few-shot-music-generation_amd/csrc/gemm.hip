@@ -855,6 +855,14 @@ __global__ __launch_bounds__(256 * (MT + 1), MT == 1 ? 2 : 1) void k_gemm_bx3w(c
             for (int i = 0; i < MT; ++i) sa[q][i].init(g.A, g.lda, g.M, m0 + 128 * i, g.gather, kb + 16 * q, lt, g.K, 32, 128 * i);
             sb[q].init(g.B, g.ldb, g.N, n0, nullptr, kb + 16 * q, lt, 0, 32);
         }
+        if (PROF && (g.dbg & 4)) {              // diagnostics: every k tile re-reads the block's FIRST tile (L1 / L2 resident)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) sa[q][i].step = 0;
+                sb[q].step = 0;
+            }
+        }
         const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0;
         float csum = 0.0f;
 #define BXW_FETCH(Q, T)                                                                                        \

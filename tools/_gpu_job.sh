@@ -1,8 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for c in cfg-C cfg-E cfg-B; do for m in 0 1; do FSMG_GEMM_WS=$m timeout 600 python bench.py --config $c --steps 30 --warmup 6 --no-cpu-baseline > gpurun_out/r03e_${c}_ws$m.json 2> gpurun_out/r03e_${c}_ws$m.err; python - <<PY
-import json
-d=json.loads(open('gpurun_out/r03e_${c}_ws$m.json').read().strip().splitlines()[-1])
-ks=d.get('kernels') or {}
-print('$c WS=$m', round(d['value'],1), round(d['ms_per_step'],4), d['guard']['ok'], {k: round(v['ms_per_step'],4) for k,v in ks.items() if k.startswith('gemm')})
-PY
-done; done
+( for d in 0 4 6; do for o in "logits  Hout" "dhout   dlog" "dW      (no"; do echo "== PROF BX3=2 DBG=$d $o"; DBG=$d PROF=1 BX3=2 ONLY="$o" timeout 120 tools/gemm_bench.bin 3 4 0 | grep -A3 "S 1 \|S 4 " | grep -v "CUs seen"; done; done ) > gpurun_out/r03_gemm_prof10.log 2>&1
+cut -c1-250 gpurun_out/r03_gemm_prof10.log | grep "==\|PROF mult\|PROF load\| S "
