@@ -585,9 +585,9 @@ constexpr int BX_STAGE = 2 * BX_OPER;           // A + B
 //       the 64 bytes a row contributes to the tile); two 8-byte LDS writes per plane.
 //   XC with gathered K rows (dKx: row k of the operand is row gather[k] of the embedding): the eight row ids of the NEXT
 //       tile are fetched one tile ahead, so a tile's loads do not wait for an index load first.
-template <int MODE, int XT = 128>         // XT: x extent of the LDS tile the stager writes into (it covers 128 of them)
+template <int MODE, int XT = 128, int NT = 256>   // XT: x extent of the LDS tile written into; NT threads cover NT / 2 of them
 struct BxStager {
-    static constexpr int KH = XT * 16, PLANE = 2 * KH;
+    static constexpr int KH = XT * 16, PLANE = 2 * KH, XW = NT / 2;
     const float* p[2];
     float v[8];
     long long step, ld_;
@@ -603,10 +603,10 @@ struct BxStager {
     __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather, int kb, int tid, int K = 0, int kstep_ = 16, int xl0 = 0) {
         ld_ = ld; gp = nullptr; kstep = kstep_;
         if (MODE == OP_XC) {
-            const int x = min(x0 + (tid & 127), X - 1), kh = tid >> 7;
+            const int x = min(x0 + (tid % XW), X - 1), kh = tid / XW;
             p[0] = src + (long long)(kb + 8 * kh) * ld + x; p[1] = nullptr;
             step = (long long)kstep * ld;
-            lds_ofs[0] = kh * KH + (xl0 + (tid & 127)) * 16; lds_ofs[1] = 0;
+            lds_ofs[0] = kh * KH + (xl0 + (tid % XW)) * 16; lds_ofs[1] = 0;
             if (gather != nullptr) {
                 p[0] = src + x;
                 gK = K; gk = min(kb + 8 * kh, K - 1); gp = gather + gk;
@@ -616,7 +616,7 @@ struct BxStager {
             const int kq = tid & 3;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int xl = (tid >> 2) + 64 * i, x = min(x0 + xl, X - 1);
+                const int xl = (tid >> 2) + (NT / 4) * i, x = min(x0 + xl, X - 1);
                 const long long row = gather ? (long long)gather[x] : (long long)x;
                 p[i] = src + row * ld + kb + 4 * kq;
                 lds_ofs[i] = (kq >> 1) * KH + (xl0 + xl) * 16 + (kq & 1) * 8;
@@ -652,7 +652,7 @@ struct BxStager {
     // last tile of a K range: k0 = first k of the tile, zeros from kend on
     __device__ __forceinline__ void fetch_partial(int k0, int kend, int tid) {
         if (MODE == OP_XC) {
-            const int kh = tid >> 7;
+            const int kh = tid / XW;
             if (gp != nullptr) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = (k0 + 8 * kh + i < kend) ? p[0][(long long)gi[i] * ld_] : 0.0f;

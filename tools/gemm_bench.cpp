@@ -91,7 +91,7 @@ static void profile_launch(hipStream_t s, int amode, int bmode, GemmArgs g, int 
     for (int role = 0; role < (NW > 4 ? 2 : 1); ++role) {
         double mf = 0, cm = 0, bar = 0, pro = 0, epi = 0, life = 0, loop = 0; size_t cnt = 0;
         for (size_t w = 0; w < (size_t)blocks * NW; ++w) {
-            if (NW > 4 && (int)((w % NW) >= (size_t)(NW - 4)) != role) continue;
+            if (NW > 4 && (int)((w % NW) >= (size_t)(NW / 2)) != role) continue;
             const unsigned long long* o = &h[w * 8];
             if (o[6] == 0) continue;
             mf += o[2]; cm += o[3]; bar += o[4]; pro += o[1] - o[0]; epi += o[6] - o[5]; life += o[6] - o[0]; loop += o[5] - o[1]; ++cnt;
