@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void k_fill32_if(const int* __restrict__ cond,
 // several fills in one launch (blockIdx.y = range): a step needs ~10 small fills, each a ~5 us dispatch on its own
 __global__ __launch_bounds__(256) void k_fill_multi(const FillRanges r) {
     const int k = blockIdx.y;
+    if (r.cond[k] != nullptr && *r.cond[k] == 0) return;
     uint32_t* p = r.p[k];
     const uint32_t word = r.word[k];
     const long long n = r.n[k], n4 = n >> 2;

@@ -566,8 +566,7 @@ int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g) {
     g.C = ln.slabs; g.c_slab = mn; g.ksplit = S;
     if (colsum) { g.colsum = ln.colsum_slabs; g.colsum_slab = g.N; }
     HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
-    HIPCK(h, launch_reduce_slabs(s, ln.slabs, mn, S, C, mn));
-    if (colsum) HIPCK(h, launch_reduce_slabs(s, ln.colsum_slabs, g.N, S, colsum, g.N));
+    HIPCK(h, launch_reduce_slabs2(s, ln.slabs, mn, S, C, mn, ln.colsum_slabs, g.N, colsum, colsum ? g.N : 0));
     return FSMG_OK;
 }
 #define GEMMCK(call) do { int rc_ = (call); if (rc_ != FSMG_OK) return rc_; } while (0)
@@ -676,10 +675,10 @@ struct FillBatch {
     FillRanges r{};
     fsmg_model* h;
     explicit FillBatch(fsmg_model* h_) : h(h_) { r.count = 0; }
-    int add(void* p, uint32_t word, long long n_words) {
+    int add(void* p, uint32_t word, long long n_words, const int* cond = nullptr) {     // cond: fill only when *cond != 0 on the device
         if (n_words <= 0) return FSMG_OK;
         if (r.count == FILL_MAX_RANGES) { const int rc = flush(); if (rc != FSMG_OK) return rc; }
-        r.p[r.count] = (uint32_t*)p; r.word[r.count] = word; r.n[r.count] = n_words; ++r.count;
+        r.p[r.count] = (uint32_t*)p; r.word[r.count] = word; r.n[r.count] = n_words; r.cond[r.count] = cond; ++r.count;
         return FSMG_OK;
     }
     int flush() {
@@ -990,8 +989,7 @@ int backward(fsmg_model* h, int B, int part = 0) {
             // the dh-partial inboxes are refilled only when the device flag says so: every word a pass writes is read and reset
             // by its consumer, so a completed pass leaves them all-"not written" (33 MB per pass at hidden 512, 100 MB per
             // layer at hidden 1024 otherwise)
-            GEMMCK(fills.flush());
-            HIPCK(h, launch_fill32_if(s, h->d_inbox_dirty, h->inboxX, 0xFFFFFFFFu, lstm_xcd_inbox_floats(B, Hp)));
+            GEMMCK(fills.add(h->inboxX, 0xFFFFFFFFu, lstm_xcd_inbox_floats(B, Hp), h->d_inbox_dirty));    // same launch as the zero fills
             GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
             h->ticket_next = 0;
         } else if (rs) {        // "not written yet" fill pattern of the dh partial inboxes

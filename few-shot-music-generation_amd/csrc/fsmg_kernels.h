@@ -53,6 +53,9 @@ int gemm_tile_m();   // rows of a block tile (128 or 256)
 // out[i] = sum_z slabs[z][i]  (fixed order -> deterministic split-K)
 hipError_t launch_reduce_slabs(hipStream_t s, const float* slabs, long long slab_stride, int nslab,
                                float* out, long long n);
+// two such sums in one launch (a split-K GEMM's C and its column sums); the second may be empty (n2 == 0)
+hipError_t launch_reduce_slabs2(hipStream_t s, const float* slabs, long long slab_stride, int nslab, float* out, long long n,
+                                const float* slabs2, long long slab_stride2, float* out2, long long n2);
 
 // ---------------------------------------------------------------- recurrent steps (lstm_step.hip)
 struct LstmFwdArgs {
@@ -198,7 +201,8 @@ hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);
 // ---------------------------------------------------------------- everything else (elementwise.hip)
 // up to FILL_MAX_RANGES 32-bit pattern fills in ONE launch (each p 16-byte aligned)
 constexpr int FILL_MAX_RANGES = 16;
-struct FillRanges { uint32_t* p[FILL_MAX_RANGES]; uint32_t word[FILL_MAX_RANGES]; long long n[FILL_MAX_RANGES]; int count; };
+// cond[k] != nullptr: range k is filled only when *cond[k] != 0 (read on the device when the launch runs)
+struct FillRanges { uint32_t* p[FILL_MAX_RANGES]; uint32_t word[FILL_MAX_RANGES]; long long n[FILL_MAX_RANGES]; const int* cond[FILL_MAX_RANGES]; int count; };
 hipError_t launch_fill_multi(hipStream_t s, const FillRanges& r);
 // out[r][0..T) = table[idx[r]][0..T) for r < n_rows (device-resident split table -> the token staging buffer)
 hipError_t launch_gather_rows(hipStream_t s, const int* table, const int* idx, int n_rows, int T, int n_songs, int* out, int* err_flag);

@@ -21,6 +21,7 @@
 // other LDS buffer afterwards, one barrier per K tile; blocks are numbered so that the 8 XCDs (block b -> XCD
 // b % 8 as observed on MI355X) each walk a contiguous range of tiles and share operand panels in their private L2.
 #include "fsmg_kernels.h"
+#include <algorithm>
 
 namespace fsmg {
 
@@ -1009,6 +1010,21 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, long long stride
     }
 }
 
+// blocks [0, nb1): range 1, the rest: range 2 -- the same per-element sum as k_reduce_slabs
+__global__ void k_reduce_slabs2(const float* __restrict__ slabs, long long stride, int nslab, float* __restrict__ out, long long n,
+                                int nb1, const float* __restrict__ slabs2, long long stride2, float* __restrict__ out2, long long n2) {
+    const bool second = (int)blockIdx.x >= nb1;
+    const float* sl = second ? slabs2 : slabs;
+    float* o = second ? out2 : out;
+    const long long st = second ? stride2 : stride, nn = second ? n2 : n;
+    const long long b = second ? (long long)blockIdx.x - nb1 : blockIdx.x, nb = second ? (long long)gridDim.x - nb1 : nb1;
+    for (long long i = b * blockDim.x + threadIdx.x; i < nn; i += nb * blockDim.x) {
+        float v = sl[i];
+        for (int z = 1; z < nslab; ++z) v += sl[z * st + i];
+        o[i] = v;
+    }
+}
+
 }  // namespace
 
 int gemm_block_slots() { return 256 * ((BK == 16 ? 4 : 2) * 256 / NTHREADS); }
@@ -1032,6 +1048,15 @@ hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, i
     if (amode == OP_XC && bmode == OP_XC) return launch_t<OP_XC, OP_XC>(s, g, lds_pad);
     if (amode == OP_KC && bmode == OP_KC) return launch_t<OP_KC, OP_KC>(s, g, lds_pad);
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_reduce_slabs2(hipStream_t s, const float* slabs, long long slab_stride, int nslab, float* out, long long n,
+                                const float* slabs2, long long slab_stride2, float* out2, long long n2) {
+    if (n2 <= 0) return launch_reduce_slabs(s, slabs, slab_stride, nslab, out, n);
+    if (n <= 0) return launch_reduce_slabs(s, slabs2, slab_stride2, nslab, out2, n2);
+    int nb1 = (int)std::min<long long>((n + 255) / 256, 2048), nb2 = (int)std::min<long long>((n2 + 255) / 256, 64);
+    hipLaunchKernelGGL(k_reduce_slabs2, dim3(nb1 + nb2), dim3(256), 0, s, slabs, slab_stride, nslab, out, n, nb1, slabs2, slab_stride2, out2, n2);
+    return hipGetLastError();
 }
 
 hipError_t launch_reduce_slabs(hipStream_t s, const float* slabs, long long slab_stride, int nslab,

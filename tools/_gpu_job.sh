@@ -1,5 +1,11 @@
 cd $GRAFT_REPO_ROOT
-( for o in "logits  Hout" "dhout   dlog" "dW      Hout" dKh zx edge; do for b in 2 3; do echo "== BX3=$b $o"; BX3=$b ONLY="$o" timeout 120 tools/gemm_bench.bin 10 4 1 | grep -v "verify.*ok"; done; done
-for o in "logits  Hout" "dhout   dlog" "dW      (no"; do echo "== PROF BX3=3 $o"; PROF=1 BX3=3 ONLY="$o" timeout 120 tools/gemm_bench.bin 3 4 0 | grep -A3 "S 1 \|S 4 \|S 8 " | grep -v "CUs seen"; done ) > gpurun_out/r03_gemm_prof11.log 2>&1
-grep -v edge gpurun_out/r03_gemm_prof11.log | grep "==\|S 1 \|S 3 \|S 4 \|S 5 \|S 8 \|PROF\|MISMATCH" | cut -c1-250
-grep -c MISMATCH gpurun_out/r03_gemm_prof11.log
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r03f_pytest_gpu.log 2>&1
+tail -4 gpurun_out/r03f_pytest_gpu.log
+timeout 600 python bench.py --steps 40 --warmup 8 --no-cpu-baseline > gpurun_out/r03f_bench.json 2> gpurun_out/r03f_bench.err; python - <<PY
+import json
+d=json.loads(open('gpurun_out/r03f_bench.json').read().strip().splitlines()[-1])
+print('cfg-B', round(d['value'],1), round(d['ms_per_step'],4), d['guard']['ok'])
+PY
+FSMG_CHAIN_SPIN_LIMIT=0 timeout 300 python - <<PY
+print('skip')
+PY
