@@ -15,6 +15,10 @@ for c in cfg-C cfg-E; do
   python $R/tools/rocpd_stats.py $(find /tmp/prof_$t -name "*.db" | head -1) > $O/${TAG}_${t}_bench_rocprofv3_kernel_stats.txt 2>&1
   python $R/tools/step_timeline.py $(find /tmp/prof_$t -name "*.db" | head -1) 30 > $O/${TAG}_${t}_step_timeline.txt 2>&1
 done
+# un-profiled bench lines of the diagnostic workloads
+for c in cfg-C cfg-E cfg-D cfg-Bx8; do
+  python $R/bench.py --config $c --steps 40 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_$c.json
+done
 # counters: separate passes (SQ block 8 slots; FETCH_SIZE and WRITE_SIZE do not fit one TCC pass), kernel-trace only
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   n=$(echo $set | cut -d' ' -f1)
