@@ -607,15 +607,11 @@ int run_graphed(fsmg_model* h, const std::string& key, F&& body) {
 
 // ------------------------------------------------------------------ the step pieces
 // host-side parameter writes (init / set_param / restore) leave the fragment-ordered weight copies stale
+int repack_recurrent_weights(fsmg_model* h, hipStream_t s);
 int ensure_khf(fsmg_model* h) {
     if (!h->khf_dirty) return FSMG_OK;
-    for (int l = 0; l < h->L; ++l)
-    {
-        HIPCK(h, launch_repack_kh(h->stream, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
-                                  h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
-        if (h->khx) HIPCK(h, launch_repack_kh_xcd(h->stream, h->P + h->off_kh[l], h->khx + (size_t)(2 * l) * h->Hp * h->G4,
-                                                  h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
-    }
+    const int rc = repack_recurrent_weights(h, h->stream);
+    if (rc != FSMG_OK) return rc;
     h->khf_dirty = false;
     return FSMG_OK;
 }
@@ -1095,6 +1091,30 @@ int backward(fsmg_model* h, int B, int part = 0) {
     return FSMG_OK;
 }
 
+// K_h of every layer into the layouts the recurrent kernels read: one launch (up to REPACK_MAX_LAYERS layers)
+int repack_recurrent_weights(fsmg_model* h, hipStream_t s) {
+    const bool x_ok = h->khx == nullptr || h->Hp == 512 || h->Hp == 1024;
+    if (h->L <= REPACK_MAX_LAYERS && x_ok) {
+        RepackAllArgs a{};
+        a.n = h->L; a.Hp = h->Hp;
+        for (int l = 0; l < h->L; ++l) {
+            a.Kh[l] = h->P + h->off_kh[l];
+            a.cf[l] = h->khf + (size_t)(2 * l) * h->Hp * h->G4; a.cb[l] = h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4;
+            a.xf[l] = h->khx ? h->khx + (size_t)(2 * l) * h->Hp * h->G4 : nullptr;
+            a.xb[l] = h->khx ? h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4 : nullptr;
+        }
+        HIPCK(h, launch_repack_kh_all(s, a));
+        return FSMG_OK;
+    }
+    for (int l = 0; l < h->L; ++l) {
+        HIPCK(h, launch_repack_kh(s, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
+                                  h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
+        if (h->khx) HIPCK(h, launch_repack_kh_xcd(s, h->P + h->off_kh[l], h->khx + (size_t)(2 * l) * h->Hp * h->G4,
+                                                  h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
+    }
+    return FSMG_OK;
+}
+
 int apply_update(fsmg_model* h, float grad_scale) {
     ScopedRange rng_("fsmg.clip+adam");
     hipStream_t s = h->stream;
@@ -1110,12 +1130,7 @@ int apply_update(fsmg_model* h, float grad_scale) {
     a.grad_scale = grad_scale; a.lr = h->cfg.lr; a.n_decay = h->cfg.n_decay; a.clip = h->cfg.max_grad_norm;
     a.step = h->d_step; a.gnorm_out = h->d_gnorm; a.err_flag = h->d_err;
     HIPCK(h, launch_adam_update(s, a));
-    for (int l = 0; l < h->L; ++l) {         // refresh the fragment-ordered recurrent weights
-        HIPCK(h, launch_repack_kh(s, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
-                                  h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
-        if (h->khx) HIPCK(h, launch_repack_kh_xcd(s, h->P + h->off_kh[l], h->khx + (size_t)(2 * l) * h->Hp * h->G4,
-                                                  h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
-    }
+    GEMMCK(repack_recurrent_weights(h, s));  // refresh the fragment-ordered recurrent weights
     HIPCK(h, launch_step_increment(s, h->d_step, h->G + h->n_flat + 1, grad_scale, h->d_ring, RING_CAP, h->d_err, h->d_counters, h->d_inbox_dirty));
     PHASE(7);
 #ifdef FSMG_PHASE_DEBUG

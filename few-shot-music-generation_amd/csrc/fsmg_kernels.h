@@ -195,6 +195,10 @@ long long lstm_xcd_inbox_floats(int B, int Hp = 512);
 long long lstm_xcd_weight_floats(int Hp = 512);   // floats per register image
 int lstm_xcd_packed_rows(int B);               // rows per XCD that leave whole XCDs free without adding row groups (hidden 512)
 hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp = 512);
+// all layers, both layouts, one launch: Kh[l] -> cf / cb (launch_repack_kh) and, where xf[l] != nullptr, xf / xb (launch_repack_kh_xcd)
+constexpr int REPACK_MAX_LAYERS = 4;
+struct RepackAllArgs { int n; int Hp; const float* Kh[REPACK_MAX_LAYERS]; float* cf[REPACK_MAX_LAYERS]; float* cb[REPACK_MAX_LAYERS]; float* xf[REPACK_MAX_LAYERS]; float* xb[REPACK_MAX_LAYERS]; };
+hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a);
 hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a);
 hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);
 

@@ -21,6 +21,7 @@
 // that produces them, next to the row-major copy the big GEMMs consume.
 #include "fsmg_kernels.h"
 #include "lstm_cell.h"
+#include "lstm_repack.h"
 
 namespace fsmg {
 
@@ -832,25 +833,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_bwd_rs(const LstmBwdRsArgs a) {
 //   fwd: B[k][n = packed col], block nb = 16 cols:  KhF_fwd[nb][g][lane=16q+n][s] = Kh[16g+4q+s][16nb+n]
 //   bwd: B[k = packed col][n = unit], block ug:      KhF_bwd[ug][g][lane=16q+n][s] = Kh[16ug+n][16g+4q+s]
 __global__ void k_repack_kh(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd, int Hp) {
-    const int G4 = 4 * Hp;
-    const long long total = (long long)Hp * G4 / 4;            // float4 slots per copy
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int lane = (int)(i & 63), q = lane >> 4, n = lane & 15;
-        {   // forward copy
-            const int ng = Hp >> 4;
-            const int g = (int)((i >> 6) % ng), nb = (int)((i >> 6) / ng);
-            float4 v;
-            const float* src = Kh + (long long)(16 * g + 4 * q) * G4 + 16 * nb + n;
-            v.x = src[0]; v.y = src[G4]; v.z = src[2LL * G4]; v.w = src[3LL * G4];
-            reinterpret_cast<float4*>(fwd)[i] = v;
-        }
-        {   // backward copy
-            const int ng = G4 >> 4;
-            const int g = (int)((i >> 6) % ng), ug = (int)((i >> 6) / ng);
-            reinterpret_cast<float4*>(bwd)[i] =
-                *reinterpret_cast<const float4*>(Kh + (long long)(16 * ug + n) * G4 + 16 * g + 4 * q);
-        }
-    }
+    repack_kh_chunked(Kh, fwd, bwd, Hp, blockIdx.x, gridDim.x);
 }
 
 }  // namespace

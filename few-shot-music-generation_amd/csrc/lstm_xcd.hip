@@ -49,7 +49,9 @@
 // column-split kernels: placement decides speed, never results.
 #include "fsmg_kernels.h"
 #include "lstm_cell.h"
+#include "lstm_repack.h"
 #include <type_traits>
+#include <algorithm>
 
 namespace fsmg {
 namespace {
@@ -451,9 +453,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd(const LstmBwdXcdArgs a)
 // Kh [512][2048] (packed gate columns) -> the register images of the two XCD-local kernels:
 //   fwd word i (= 16q + b), component e of (cu, w), lane l:  Kh[128w + 64q + 16(b/4) + 4(b%4) + e][64cu + l]
 //   bwd word i, component e' of (cu, w), lane l, r = 4i + e' = 64cg + k:  Kh[128w + 64cg + l][64cu + k]
-__global__ void k_repack_kh_xcd(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd) {
+__device__ __forceinline__ void repack_kh_xcd_body(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd, int b, int nb) {
     const int total = NCU * 4 * 32 * 64;            // f32x4 words per copy
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    for (int idx = b * blockDim.x + threadIdx.x; idx < total; idx += nb * blockDim.x) {
         const int l = idx & 63, i = (idx >> 6) & 31, w = (idx >> 11) & 3, cu = idx >> 13;
         {
             const int q = i >> 4, b = i & 15;
@@ -469,6 +471,9 @@ __global__ void k_repack_kh_xcd(const float* __restrict__ Kh, float* __restrict_
                 *reinterpret_cast<const float4*>(Kh + (size_t)(128 * w + 64 * cg + l) * XG4 + 64 * cu + k);
         }
     }
+}
+__global__ void k_repack_kh_xcd(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd) {
+    repack_kh_xcd_body(Kh, fwd, bwd, blockIdx.x, gridDim.x);
 }
 
 // ================================================================ XCD-PAIR-local recurrence, hidden size 1024 (cfg-C / cfg-E)
@@ -1214,9 +1219,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_pair_chains(const LstmBwdXc
 // Kh [1024][4096] (packed gate columns) -> the register images of the pair kernels (same convention as k_repack_kh_xcd):
 //   fwd word i (= 16q + b, q < 4), component e of (cu, w), lane l:  Kh[256w + 64q + 16(b/4) + 4(b%4) + e][64cu + l]
 //   bwd word i, component e' of (cu, w), lane l, r = 4i + e' = 64cg + k (cg < 4):  Kh[256w + 64cg + l][64cu + k]
-__global__ void k_repack_kh_pair(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd) {
+__device__ __forceinline__ void repack_kh_pair_body(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd, int b, int nb) {
     const int total = PCU * 4 * PNW * 64;           // f32x4 words per copy
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    for (int idx = b * blockDim.x + threadIdx.x; idx < total; idx += nb * blockDim.x) {
         const int l = idx & 63, i = (idx >> 6) & 63, w = (idx >> 12) & 3, cu = idx >> 14;
         {
             const int q = i >> 4, b = i & 15;
@@ -1233,8 +1238,32 @@ __global__ void k_repack_kh_pair(const float* __restrict__ Kh, float* __restrict
         }
     }
 }
+__global__ void k_repack_kh_pair(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd) {
+    repack_kh_pair_body(Kh, fwd, bwd, blockIdx.x, gridDim.x);
+}
+
+// every layer's K_h into every layout the recurrent kernels read, ONE launch (blockIdx.y = 2 * layer + {0: the column-split
+// kernels' fragment order, 1: the XCD / XCD-pair register image}): the four repacks of a two-layer model were 56 us of a
+// 2.85 ms cfg-C step as separate launches
+__global__ void k_repack_kh_all(const RepackAllArgs a) {
+    const int l = blockIdx.y >> 1, kind = blockIdx.y & 1;
+    if (kind == 0) { repack_kh_chunked(a.Kh[l], a.cf[l], a.cb[l], a.Hp, blockIdx.x, gridDim.x); return; }
+    if (a.xf[l] == nullptr) return;
+    if (a.Hp == PH) repack_kh_pair_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
+    else repack_kh_xcd_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
+}
 
 }  // namespace
+
+hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a) {
+    if (a.n <= 0) return hipSuccess;
+    if (a.n > REPACK_MAX_LAYERS) return hipErrorInvalidValue;
+    for (int l = 0; l < a.n; ++l) if (a.xf[l] != nullptr && !(a.Hp == XH || a.Hp == PH)) return hipErrorInvalidValue;
+    const long long total = (long long)a.Hp * 4 * a.Hp / 4;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_repack_kh_all, dim3(blocks, 2 * a.n), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 // row groups of 4 rows per weight copy: hidden 512 -> 8 copies (one per XCD), 3 is padded to 4 (the lane mapping of
 // k_lstm_bwd_xcd needs a divisor of 4); hidden 1024 -> 4 copies (one per XCD pair), 1 .. 4
