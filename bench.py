@@ -16,7 +16,9 @@ torchrun environment starts its own N ranks (re-executes itself under torch.dist
 and prints rank 0's line; under torchrun (RANK / WORLD_SIZE set) it is one rank of the job.  For N > 1 the timed loop runs
 once per exchange schedule IN THE SAME RUN (`schedules`): "graph_end" (one graph per backward pass, the three gradient
 buckets reduced on the communication stream when it ends), "split_bucket0" (two graphs: bucket 0 = softmax gradients, 56 %
-of the bytes, is released behind the projection-gradient GEMMs and travels under BPTT) and "one_collective" (a single
+of the bytes, is released behind the projection-gradient GEMMs and travels under BPTT), "split_after_chain" (the same with
+the cut behind the last recurrent chain: an XCD-local chain needs every CU, so a collective started in front of it only
+delays it; behind it bucket 0 travels beside the weight- / input-gradient GEMMs) and "one_collective" (a single
 all-reduce on the compute stream); `value` is the fastest, `comm.exposed_ms` what each one adds to the same loop without
 any exchange.  FSMG_BENCH_LIBRARY_RCCL=1 adds "library_rccl": the collectives issued by libfsmg itself (fsmg_comm_init).
 
@@ -324,7 +326,8 @@ def main():
     if world == 1:
         plans = [('single_gpu_one_graph', {})]
     else:
-        plans = [('graph_end', {}), ('split_bucket0', {'dp_split_backward': True}), ('one_collective', {'bucketed': False})]
+        plans = [('graph_end', {}), ('split_bucket0', {'dp_split_backward': True}), ('split_after_chain', {'dp_split_backward': 2}),
+                 ('one_collective', {'bucketed': False})]
         if os.environ.get('FSMG_BENCH_LIBRARY_RCCL', '0') == '1' and not same_gpu:
             # opt-in: the exchange issued by libfsmg itself (fsmg_comm_*; tested with one rank on the GPU box, never yet with
             # N > 1 -- kept out of the default plans so that a first multi-GPU run cannot be lost to it)

@@ -105,7 +105,7 @@ struct fsmg_model {
     // the h hand-off buffer, the dh-partial inboxes and the per-launch ticket counters
     bool xcd = true;                    // FSMG_XCD=0: keep the column-split persistent kernels
     int xcd_max_rows = 128;             // FSMG_XCD_MAX_ROWS: largest sequence count that takes the XCD-local kernels
-    bool dp_split = false;              // FSMG_DP_SPLIT=1: fsmg_forward_backward replays TWO graphs (forward + projection gradients | BPTT + the rest) and
+    int dp_split = 0;                   // FSMG_DP_SPLIT=1 / 2: fsmg_forward_backward replays TWO graphs (forward + projection gradients | BPTT + the rest) and
                                         // records bucket 0's readiness between them, so its all-reduce runs under the second one
     int pair_mode = 2;                  // hidden size 1024 (one copy of K_h per XCD pair): 0 = column-split kernels, 1 = pair kernel forward only
                                         // (6.4 against 7.0 us per step; the backward pair kernel ties with the column-split one), 2 = both directions
@@ -942,6 +942,10 @@ int backward(fsmg_model* h, int B, int part = 0) {
     const int rpx = xov ? lstm_xcd_packed_rows(B) : 0;
     const bool cut = !ov && !xov;           // the order that can be cut behind the projection gradients
     if (part == 2 && !cut) return FSMG_OK;
+    // dp_split == 2: the cut sits behind the LAST recurrent chain instead -- an XCD-local chain needs every CU of the chip, so
+    // a collective kernel started in front of it only delays it; behind it the exchange of bucket 0 runs beside the
+    // weight- / input-gradient GEMMs of the bottom layer, the embedding gradient and the norm
+    const bool cut_late = cut && h->dp_split == 2 && part != 0;
     PHASE(3);
     FillBatch fills(h);                     // embedding-gradient zero + the top layer's BPTT buffers: one launch
     if (part != 2) GEMMCK(fills.add(h->G + h->off_emb, 0u, (long long)h->V1 * h->Ep));
@@ -975,9 +979,12 @@ int backward(fsmg_model* h, int B, int part = 0) {
         GEMMCK(dhout_chunk(h, mainl, B, 0, T));
         GEMMCK(dw_gemm(h, mainl, B));
     }
-    if (part == 1 && cut) return fills.flush();
+    if (part == 1 && cut && !cut_late) return fills.flush();
     for (int l = h->L - 1; l >= 0; --l) {
         const bool top = l == h->L - 1;
+        if (part == 2 && cut_late && l > 0) continue;                       // done in part 1
+        const bool skip_chain = part == 2 && cut_late;                      // layer 0: its chain ran in part 1
+        if (!skip_chain) {
         GEMMCK(fills.add(h->dC, 0u, (long long)B * Hp));
         if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[nch - 1], 0));
         PHASE(4);
@@ -1053,6 +1060,8 @@ int backward(fsmg_model* h, int B, int part = 0) {
             HIPCK(h, hipEventRecord(h->ev_bucket[0], s));
             h->bucket0_recorded = true;
         }
+        }   // !skip_chain
+        if (part == 1 && cut_late && l == 0) return FSMG_OK;                // bucket 0 travels beside what follows
         const int in_p = h->in_dim[l];
         PHASE(5);
         {
@@ -1464,7 +1473,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (cfg->recurrence == FSMG_RECURRENCE_PER_STEP) h->persist = false;
         if (cfg->recurrence == FSMG_RECURRENCE_COLUMN_SPLIT) h->xcd = false;
         if (cfg->recurrence == FSMG_RECURRENCE_XCD_LOCAL) h->pair_mode = 2;
-        if (cfg->dp_split_backward) h->dp_split = true;
+        if (cfg->dp_split_backward) h->dp_split = cfg->dp_split_backward == 2 ? 2 : 1;
         const char* env = std::getenv("FSMG_OVERLAP");
         if (env) { h->overlap = env[0] != '0'; h->overlap_forced = true; }
         if (const char* e = std::getenv("FSMG_GEMM")) h->bx3 = std::strcmp(e, "f32") != 0;
@@ -1478,7 +1487,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_FALLBACK_STEPS")) h->fallback_steps = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("FSMG_BWD_RS")) h->bwd_rs = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XCD")) h->xcd = (e[0] != '0');
-        if (const char* e = std::getenv("FSMG_DP_SPLIT")) h->dp_split = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_DP_SPLIT")) h->dp_split = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_XCD_VARIANT")) h->xcd_variant = std::atoi(e);
         if (const char* e = std::getenv("FSMG_XCD_PAIR")) h->pair_mode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_XCD_MAX_ROWS")) h->xcd_max_rows = std::max(1, std::min(128, std::atoi(e)));

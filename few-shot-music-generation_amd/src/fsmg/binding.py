@@ -148,7 +148,7 @@ class FsmgModel(object):
         schedule = schedule or config.get('schedule', 'auto')
         recurrence = recurrence or config.get('recurrence', 'auto')
         if dp_split_backward is None:
-            dp_split_backward = bool(config.get('dp_split_backward', False))
+            dp_split_backward = config.get('dp_split_backward', False)
         self.cfg = FsmgConfig(
             input_size=int(config['input_size']), max_len=int(config['max_len']),
             embedding_size=int(config['embedding_size']), hidden_size=int(config['hidden_size']),
@@ -157,7 +157,7 @@ class FsmgModel(object):
             clip_norm_mode=CLIP_MODES[clip_norm_mode], device=int(device), max_sequences=int(max_sequences),
             use_graph=int(bool(use_graph)), stream=stream, state_arena=state_arena,
             state_arena_bytes=int(state_arena_bytes), config_version=FSMG_CONFIG_VERSION, gemm=GEMM_KINDS[gemm],
-            schedule=SCHEDULES[schedule], recurrence=RECURRENCES[recurrence], dp_split_backward=int(bool(dp_split_backward)))
+            schedule=SCHEDULES[schedule], recurrence=RECURRENCES[recurrence], dp_split_backward=(2 if dp_split_backward == 2 and dp_split_backward is not True else int(bool(dp_split_backward))))
         self.max_len = int(config['max_len'])
         handle = _P()
         rc = self._lib.fsmg_create(C.byref(self.cfg), C.byref(handle))

@@ -89,7 +89,9 @@ typedef struct fsmg_config {
     int32_t schedule;           /* FSMG_SCHEDULE_*                                                                           */
     int32_t recurrence;         /* FSMG_RECURRENCE_*                                                                         */
     int32_t dp_split_backward;  /* 1: fsmg_forward_backward replays two graphs and bucket 0 of the gradient exchange
-                                   (softmax gradients) is final behind the first one (fsmg_stream_wait_bucket)               */
+                                   (softmax gradients) is final behind the first one (fsmg_stream_wait_bucket), which ends
+                                   behind the projection gradients; 2: the first graph ends behind the last recurrent
+                                   chain instead (a collective started before a chain that needs every CU only delays it)   */
     int32_t reserved[7];        /* zero                                                                                       */
 } fsmg_config;
 

@@ -39,7 +39,7 @@ def test_bench_starts_its_own_ranks_and_reports_every_schedule():
     assert out['world']['size'] == 2 and out['world']['launcher'] == 'bench.py self-launch'
     assert out['world']['backend'] == 'gloo' and out['world']['same_gpu_dry_run'] is True
     assert [d['rank'] for d in out['world']['devices']] == [0, 1]
-    assert set(out['schedules']) == {'graph_end', 'split_bucket0', 'one_collective'}
+    assert set(out['schedules']) == {'graph_end', 'split_bucket0', 'split_after_chain', 'one_collective'} and not out['schedules_failed']
     assert out['schedule_used'] in out['schedules']
     best = min(v['ms_per_step'] for k, v in out['schedules'].items() if v['guard_ok'] or not any(s['guard_ok'] for s in out['schedules'].values()))
     assert abs(out['ms_per_step'] - best) < 1e-9

@@ -898,3 +898,29 @@ def test_library_owned_exchange_with_one_rank_equals_the_fused_step():
     assert lib.step == plain.step == 5
     lib.comm_release()
     assert lib.train_step(*eps[5]) == plain.train_step(*eps[5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('layers,hidden', [(1, 512), (2, 64)])
+def test_split_backward_cut_points_give_the_same_gradients_and_updates(layers, hidden):
+    """fsmg_config.dp_split_backward (include/fsmg.h): the backward pass of the episode-parallel order replayed as two graphs,
+    cut behind the projection gradients (1) or behind the last recurrent chain (2), so that bucket 0 of the gradient exchange
+    can travel beside the second graph.  Where the cut sits changes when kernels are enqueued, never what they compute: every
+    gradient tensor, three updates and the losses are bit-identical to the one-graph pass (0)."""
+    cfg = small_config(hidden_size=hidden, embedding_size=24, input_size=300, max_len=9, max_grad_norm=0.5, n_layers=layers)
+    eps = O.synthetic_episodes(3, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=17, realistic=True)
+    ref = new_model(cfg)
+    want_g, want_l = [], []
+    for s_, q_ in eps:
+        ref.forward_backward(s_, q_)
+        want_g.append({k: ref.get_grad(k).copy() for k in ref.param_shapes})
+        want_l.append(ref.apply_update(1.0))
+    for mode in (1, 2):
+        m = new_model(cfg, dp_split_backward=mode)
+        for i, (s_, q_) in enumerate(eps):
+            m.forward_backward(s_, q_)
+            for k in m.param_shapes:
+                np.testing.assert_array_equal(m.get_grad(k), want_g[i][k], err_msg='cut %d, step %d, %s' % (mode, i, k))
+            assert m.apply_update(1.0) == want_l[i]
+        for k in ref.param_shapes:
+            np.testing.assert_array_equal(m.get_param(k), ref.get_param(k))
