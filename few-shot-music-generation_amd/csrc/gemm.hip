@@ -655,7 +655,7 @@ struct BxStager {
                 const unsigned s0 = __builtin_amdgcn_readfirstlane(so), ldb = (unsigned)ld_ * 4;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo[0], s0 + i * ldb, 0));
-                so += sstep; p[0] += step;
+                so += sstep;                // (p stays at the K range's start: fetch_partial adds `so`)
                 return;
             }
 #pragma unroll
@@ -669,7 +669,6 @@ struct BxStager {
                 for (int i = 0; i < 2; ++i) {
                     const u4_ q = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[i], s0, 0);
                     v[4 * i] = __uint_as_float(q.x); v[4 * i + 1] = __uint_as_float(q.y); v[4 * i + 2] = __uint_as_float(q.z); v[4 * i + 3] = __uint_as_float(q.w);
-                    p[i] += step;
                 }
                 so += sstep;
                 return;
@@ -684,6 +683,7 @@ struct BxStager {
     }
     // last tile of a K range: k0 = first k of the tile, zeros from kend on
     __device__ __forceinline__ void fetch_partial(int k0, int kend, int tid) {
+        const long long adv = use_buf ? (long long)(so >> 2) : 0;      // buffer-load path: the pointers never moved
         so += sstep;
         if (MODE == OP_XC) {
             const int kh = tid / XW;
@@ -693,16 +693,18 @@ struct BxStager {
                 advance_ids();
                 return;
             }
+            const float* q = p[0] + adv;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (k0 + 8 * kh + i < kend) ? p[0][i * ld_] : 0.0f;
-            p[0] += step;
+            for (int i = 0; i < 8; ++i) v[i] = (k0 + 8 * kh + i < kend) ? q[i * ld_] : 0.0f;
+            if (!use_buf) p[0] += step;
         } else {
             const int kq = tid & 3;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                const float* q = p[i] + adv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * i + e] = (k0 + 4 * kq + e < kend) ? p[i][e] : 0.0f;
-                p[i] += step;
+                for (int e = 0; e < 4; ++e) v[4 * i + e] = (k0 + 4 * kq + e < kend) ? q[e] : 0.0f;
+                if (!use_buf) p[i] += step;
             }
         }
     }

@@ -1,9 +1,11 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r03j_pytest_gpu.log 2>&1
-grep -n "passed\|failed" gpurun_out/r03j_pytest_gpu.log | tail -3
-for c in cfg-C cfg-E cfg-D; do for m in 0 1; do FSMG_GEMM_BUF=$m timeout 600 python bench.py --config $c --steps 30 --warmup 6 --no-cpu-baseline > gpurun_out/r03j_${c}_buf$m.json 2>/dev/null; python - <<PY
+( for o in "logits  Hout" "dhout   dlog" "dW      Hout" dKh zx edge "logits/8"; do for b in 1 2; do echo "== BX3=$b $o"; BX3=$b ONLY="$o" timeout 120 tools/gemm_bench.bin 10 4 1 | grep -v "verify.*ok" | grep "MISMATCH\|S 1 \|S 4 \|S 8 "; done; done ) > gpurun_out/r03_gemm_buf4.log 2>&1
+grep -c MISMATCH gpurun_out/r03_gemm_buf4.log; grep -v edge gpurun_out/r03_gemm_buf4.log | grep "==\|S 1 .*logits\|S 1 .*zx\|S 4 \|S 8 " | cut -c1-200 | tail -40
+for m in 1 1; do timeout 600 python bench.py --steps 40 --warmup 8 --no-cpu-baseline > gpurun_out/r03k_bench.json 2> gpurun_out/r03k_bench.err; python - <<PY
 import json
-d=json.loads(open('gpurun_out/r03j_${c}_buf$m.json').read().strip().splitlines()[-1])
-print('$c BUF=$m', round(d['value'],1), round(d['ms_per_step'],4), d['guard']['ok'])
+d=json.loads(open('gpurun_out/r03k_bench.json').read().strip().splitlines()[-1])
+ks=d.get('kernels') or {}
+print('cfg-B', round(d['value'],1), round(d['ms_per_step'],4), d['guard']['ok'], {k: round(v['ms_per_step'],4) for k,v in ks.items() if k.startswith('gemm')})
 PY
-done; done
+done
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | grep "passed\|failed" | tail -2
