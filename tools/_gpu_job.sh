@@ -1,3 +1,8 @@
 cd $GRAFT_REPO_ROOT
-( for bin in gemm_bench gemm_bench_pk gemm_bench gemm_bench_pk; do for o in "logits  Hout" "dhout   dlog" "dW      Hout" dKh edge; do for b in 1 2; do echo "== $bin BX3=$b $o"; BX3=$b ONLY="$o" timeout 120 tools/$bin.bin 10 4 1 | grep -v "verify.*ok" | grep "MISMATCH\|S 1 \|S 4 \|S 8 "; done; done; done ) > gpurun_out/r03_gemm_pk1.log 2>&1
-grep -c MISMATCH gpurun_out/r03_gemm_pk1.log; grep -v edge gpurun_out/r03_gemm_pk1.log | grep "==\|S 1 .*logits\|S 4 \|S 8 " | cut -c1-190
+bash tools/refresh_profiles.sh r03 > gpurun_out/r03_refresh.log 2>&1
+python - <<PY
+import json
+for f in ['r03_bench.json','r03_bench_under_rocprofv3.json','r03_bench_cfg-C.json','r03_bench_cfg-E.json','r03_bench_cfg-D.json','r03_bench_cfg-Bx8.json']:
+    d=json.loads(open('gpurun_out/'+f).read().strip().splitlines()[-1])
+    print(f, round(d['value'],1), round(d['ms_per_step'],4), d.get('roofline',{}).get('frac'), d['guard']['ok'], (d.get('roofline_gemm') or {}).get('frac'))
+PY
