@@ -39,7 +39,9 @@
 // dependent chain -- is paid per phase, i.e. twice: 2.65 / 2.85, and still 2.32 / 2.71 with all waits and all slow traffic
 // compiled out); the cell update spread over all 256 threads, one gate per lane with DPP row shifts (more instructions per
 // wave than two cell waves doing whole cells: 2.48-2.52 / 2.80-2.90); a leaner tanh without the small-|x| polynomial
-// (no change).  The step is now ~2176 ticks of MFMA + ~330 LDS/barrier + ~800 cell + ~1300 from hand-off store to
+// (no change); v_rcp_f32 instead of the correctly rounded reciprocal in the five nonlinearities of a cell update (45 fewer
+// dependent VALU instructions per step: no change either -- 2.14-2.17 / 2.35-2.43, profiles/r03_xcd_probe7_rcp.log -- and one
+// Adam-step comparison moves to 1.002e-4 against its 1e-4 bound, so the exact one stays).  The step is now ~2176 ticks of MFMA + ~330 LDS/barrier + ~800 cell + ~1300 from hand-off store to
 // the consumers' first successful poll (646 between idle CUs + poll granularity + skew of 32 CUs), and the last term is
 // what a one-chain-per-XCD design cannot hide.
 //
