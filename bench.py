@@ -389,6 +389,7 @@ def main():
 
     world_info = None
     without_exchange_ms = None
+    extras_failed = {}                         # optional legs that raised: reported, never fatal
     if world > 1:
         props = torch.cuda.get_device_properties(local)
         mine = {'rank': rank, 'local_device': local, 'name': props.name, 'uuid': str(getattr(props, 'uuid', '')),
@@ -400,43 +401,62 @@ def main():
                       'launcher': 'bench.py self-launch' if os.environ.get('FSMG_BENCH_SELF_LAUNCHED') == '1' else 'torchrun',
                       'same_gpu_dry_run': same_gpu}
         # the same loop with NO exchange (replicas diverge: timing only, on its own model) -> what each schedule's exchange adds
-        m0, p0 = make({})
-        p0.exchange = False
-        el0, _ = timed(p0, m0.engine, 'no_exchange')
-        per0 = [None] * world
-        dist.all_gather_object(per0, el0)
-        without_exchange_ms = 1e3 * max(per0) / max(args.steps, 1)
-        del m0, p0
+        try:
+            m0, p0 = make({})
+            p0.exchange = False
+            el0, _ = timed(p0, m0.engine, 'no_exchange')
+            per0 = [None] * world
+            dist.all_gather_object(per0, el0)
+            without_exchange_ms = 1e3 * max(per0) / max(args.steps, 1)
+            del m0, p0
+        except Exception as e:                 # noqa: BLE001 -- an extra leg must not cost the result line
+            log('no_exchange leg failed: %r' % (e,))
+            extras_failed['no_exchange'] = repr(e)
     # ---- roofline leg: the same K steps again with HIP events around every launch of the fused-cell kernels on the library's
     # stream, in the schedule of the timed region (event timing replaces the hipGraph replay by the same launches, eagerly)
     cell = {}
     if not maml:
-        for cls in CELL_CLASSES:
-            eng.timing_select(cls)
-            eng.timing_enable(True)
-            eng.timing_reset()
-            for i in range(args.steps):
-                step(args.warmup + args.steps + i)
-            cell[cls] = eng.timing_read(cls)
-            eng.timing_enable(False)
+        try:
+            for cls in CELL_CLASSES:
+                eng.timing_select(cls)
+                eng.timing_enable(True)
+                eng.timing_reset()
+                for i in range(args.steps):
+                    step(args.warmup + args.steps + i)
+                cell[cls] = eng.timing_read(cls)
+                eng.timing_enable(False)
+        except Exception as e:                 # noqa: BLE001
+            log('roofline leg failed: %r' % (e,))
+            extras_failed['roofline'] = repr(e)
+            cell = {}
+            try:
+                eng.timing_enable(False)
+            except Exception:                  # noqa: BLE001
+                pass
     # communication (N > 1): the all-reduce of the flat gradient buffer alone on the library's stream, and per schedule what the
     # exchange adds to the same timed loop without any exchange (= the exposed, un-overlapped part)
     comm = None
     if world > 1:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with model.stream_context():
-            dist.all_reduce(model.grad_tensor, op=dist.ReduceOp.SUM)
-            ev0.record()
-            for _ in range(5):
+        ar_ms, nbytes = None, None
+        try:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with model.stream_context():
                 dist.all_reduce(model.grad_tensor, op=dist.ReduceOp.SUM)
-            ev1.record()
-        torch.cuda.synchronize()
-        nbytes = int(model.grad_tensor.numel() * 4)
-        ar_ms = ev0.elapsed_time(ev1) / 5
+                ev0.record()
+                for _ in range(5):
+                    dist.all_reduce(model.grad_tensor, op=dist.ReduceOp.SUM)
+                ev1.record()
+            torch.cuda.synchronize()
+            nbytes = int(model.grad_tensor.numel() * 4)
+            ar_ms = ev0.elapsed_time(ev1) / 5
+        except Exception as e:                 # noqa: BLE001
+            log('standalone all-reduce leg failed: %r' % (e,))
+            extras_failed['allreduce_standalone'] = repr(e)
         comm = {'allreduce_ms_standalone': ar_ms, 'bytes': nbytes,
-                'allreduce_busbw_GBps': 2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9 if ar_ms > 0 else None,
+                'allreduce_busbw_GBps': 2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9 if ar_ms else None,
                 'ms_per_step_without_exchange': without_exchange_ms,
-                'exposed_ms': {n: schedules[n]['ms_per_step'] - without_exchange_ms for n in schedules},
+                'exposed_ms': ({n: schedules[n]['ms_per_step'] - without_exchange_ms for n in schedules}
+                               if without_exchange_ms is not None else None),
                 'note': 'exposed_ms = ms_per_step of the schedule minus the same K-step loop with the exchange switched off (timing only)'}
     losses = eng.read_losses(min(args.steps, 1024)) if args.steps > 0 else np.zeros(1)
 
@@ -490,76 +510,88 @@ def main():
                 'note': 'algorithmic 2*B*H*4H FLOP per time step (SURVEY.md 8d, recurrent-only) over the HIP-event time of the launches in the timed '
                         'schedule; latency-bound chain: us_per_time_step is the figure to watch (0.60 us at the MFMA peak)'}
     if rank == 0 and not maml:
-        # the other half of BASELINE.json's metric: the validation path (query-only forward, batched 16 episodes
-        # per call like train.evaluate does); inputs resident in HBM, NLLs read back per call
-        n_ev, reps = 16, 5
-        qptr = d_qry.data_ptr()
-        eng.eval_batch(qptr, shape=(n_ev, N_WAY, Q_QUERY))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for r in range(reps):
-            nll = eng.eval_batch(qptr + r * n_ev * qry_stride, shape=(n_ev, N_WAY, Q_QUERY))
-        torch.cuda.synchronize()
-        out['eval'] = {'episodes_per_s': n_ev * reps / (time.perf_counter() - t0), 'batch_episodes': n_ev,
-                       'mean_val_nll': float(np.mean(nll)), 'unit': 'eval episodes/s (query-only forward, %d sequences/episode)' % (N_WAY * Q_QUERY)}
+        try:
+            # the other half of BASELINE.json's metric: the validation path (query-only forward, batched 16 episodes
+            # per call like train.evaluate does); inputs resident in HBM, NLLs read back per call
+            n_ev, reps = 16, 5
+            qptr = d_qry.data_ptr()
+            eng.eval_batch(qptr, shape=(n_ev, N_WAY, Q_QUERY))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for r in range(reps):
+                nll = eng.eval_batch(qptr + r * n_ev * qry_stride, shape=(n_ev, N_WAY, Q_QUERY))
+            torch.cuda.synchronize()
+            out['eval'] = {'episodes_per_s': n_ev * reps / (time.perf_counter() - t0), 'batch_episodes': n_ev,
+                           'mean_val_nll': float(np.mean(nll)), 'unit': 'eval episodes/s (query-only forward, %d sequences/episode)' % (N_WAY * Q_QUERY)}
+        except Exception as e:                 # noqa: BLE001 -- an extra leg must not cost the result line
+            log('eval leg failed: %r' % (e,))
+            extras_failed['eval'] = repr(e)
     if rank == 0 and world == 1 and not maml:
-        # the reference's calling convention: host numpy episodes in, the loss read back every step (one 23 KB H2D
-        # token copy + one synchronising 4-byte D2H per step) -- PCIe-inclusive, never the headline value
-        n_h = min(args.steps, 30)
-        t0 = time.perf_counter()
-        for i in range(n_h):
-            eng.train_step(*pool_host[i % POOL], want_loss=True)
-        out['host_synchronous'] = {'episodes_per_s': n_h / (time.perf_counter() - t0),
-                                   'note': 'host token buffers + per-step loss readback (reference train() semantics)'}
-        # what train.train does here: the split's token table resident in HBM, an episode = 45 row indices from the host
-        # sampler (180 B H2D), losses read from the device ring once per log line
-        table = np.concatenate([np.concatenate([s.reshape(-1, cfg['max_len']), q.reshape(-1, cfg['max_len'])]) for s, q in pool_host[:32]])
-        eng.upload_table(0, table)
-        rng = np.random.RandomState(7)
-        idx = [(rng.randint(0, table.shape[0], size=(N_WAY, K_SHOT)), rng.randint(0, table.shape[0], size=(N_WAY, Q_QUERY))) for _ in range(64)]
-        n_i = max(args.steps, 30)
-        for i in range(3):
-            eng.train_step_indexed(0, *idx[i], want_loss=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n_i):
-            eng.train_step_indexed(0, *idx[i % 64], want_loss=False)
-        _ = eng.read_losses(min(n_i, 1024))
-        out['host_indexed_deferred'] = {'episodes_per_s': n_i / (time.perf_counter() - t0),
-                                        'note': 'host sampler indices into the device-resident table, losses read once per window (train.train fast path)'}
+        try:
+            # the reference's calling convention: host numpy episodes in, the loss read back every step (one 23 KB H2D
+            # token copy + one synchronising 4-byte D2H per step) -- PCIe-inclusive, never the headline value
+            n_h = min(args.steps, 30)
+            t0 = time.perf_counter()
+            for i in range(n_h):
+                eng.train_step(*pool_host[i % POOL], want_loss=True)
+            out['host_synchronous'] = {'episodes_per_s': n_h / (time.perf_counter() - t0),
+                                       'note': 'host token buffers + per-step loss readback (reference train() semantics)'}
+            # what train.train does here: the split's token table resident in HBM, an episode = 45 row indices from the host
+            # sampler (180 B H2D), losses read from the device ring once per log line
+            table = np.concatenate([np.concatenate([s.reshape(-1, cfg['max_len']), q.reshape(-1, cfg['max_len'])]) for s, q in pool_host[:32]])
+            eng.upload_table(0, table)
+            rng = np.random.RandomState(7)
+            idx = [(rng.randint(0, table.shape[0], size=(N_WAY, K_SHOT)), rng.randint(0, table.shape[0], size=(N_WAY, Q_QUERY))) for _ in range(64)]
+            n_i = max(args.steps, 30)
+            for i in range(3):
+                eng.train_step_indexed(0, *idx[i], want_loss=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_i):
+                eng.train_step_indexed(0, *idx[i % 64], want_loss=False)
+            _ = eng.read_losses(min(n_i, 1024))
+            out['host_indexed_deferred'] = {'episodes_per_s': n_i / (time.perf_counter() - t0),
+                                            'note': 'host sampler indices into the device-resident table, losses read once per window (train.train fast path)'}
+        except Exception as e:                 # noqa: BLE001 -- an extra leg must not cost the result line
+            log('host_paths leg failed: %r' % (e,))
+            extras_failed['host_paths'] = repr(e)
     if rank == 0 and world == 1 and not args.no_breakdown and not maml:
-        # second, fully instrumented pass: every kernel class bracketed by HIP events (extra information)
-        eng.timing_select(None)
-        eng.timing_enable(True)
-        eng.timing_reset()
-        nb = min(args.steps, 10)
-        for i in range(nb):
-            step(i)
-        torch.cuda.synchronize()
-        gf = algorithmic_gflop(cfg, B)
-        kernels = {}
-        for c in CLASSES:
-            ms, n = eng.timing_read(c)
-            if n:
-                per_step = ms / nb
-                kernels[c] = {'ms_per_step': per_step}
-                if c in gf:
-                    kernels[c]['tflops'] = gf[c] / per_step
-                    kernels[c]['frac_mfma_peak'] = gf[c] / per_step / PEAK_F32_MFMA_TFLOPS      # of the fp32-MFMA peak
-                    if c.startswith('gemm_') and os.environ.get('FSMG_GEMM', 'bx3') != 'f32':
-                        kernels[c]['frac_bx3_bound'] = gf[c] / per_step / PEAK_BX3_TFLOPS          # of bf16 peak / 6
-        eng.timing_enable(False)
-        out['kernels'] = kernels
-        # the GEMMs as one family (63 % of the step): fp32-equivalent TFLOP/s over the instrumented pass against their own bound
-        gemm = [c for c in kernels if c.startswith('gemm_')]
-        g_ms = sum(kernels[c]['ms_per_step'] for c in gemm)
-        g_gf = sum(gf[c] for c in gemm)
-        bx3 = os.environ.get('FSMG_GEMM', 'bx3') != 'f32'
-        out['roofline_gemm'] = {'bound': 'mfma', 'kernel': 'k_gemm_bx3 (all seven dense contractions of the step)' if bx3 else 'k_gemm (fp32 MFMA)',
-                                'achieved': g_gf / g_ms, 'peak': PEAK_BX3_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s (fp32-equivalent)',
-                                'frac': g_gf / g_ms / (PEAK_BX3_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS), 'ms_per_step': g_ms,
-                                'note': 'peak = dense bf16 MFMA peak / 6 products per fp32 product at the 2.4 GHz spec clock; the chip sustains 1.92 GHz beside this kernel'}
-        log('breakdown done')
+        try:
+            # second, fully instrumented pass: every kernel class bracketed by HIP events (extra information)
+            eng.timing_select(None)
+            eng.timing_enable(True)
+            eng.timing_reset()
+            nb = min(args.steps, 10)
+            for i in range(nb):
+                step(i)
+            torch.cuda.synchronize()
+            gf = algorithmic_gflop(cfg, B)
+            kernels = {}
+            for c in CLASSES:
+                ms, n = eng.timing_read(c)
+                if n:
+                    per_step = ms / nb
+                    kernels[c] = {'ms_per_step': per_step}
+                    if c in gf:
+                        kernels[c]['tflops'] = gf[c] / per_step
+                        kernels[c]['frac_mfma_peak'] = gf[c] / per_step / PEAK_F32_MFMA_TFLOPS      # of the fp32-MFMA peak
+                        if c.startswith('gemm_') and os.environ.get('FSMG_GEMM', 'bx3') != 'f32':
+                            kernels[c]['frac_bx3_bound'] = gf[c] / per_step / PEAK_BX3_TFLOPS          # of bf16 peak / 6
+            eng.timing_enable(False)
+            out['kernels'] = kernels
+            # the GEMMs as one family (63 % of the step): fp32-equivalent TFLOP/s over the instrumented pass against their own bound
+            gemm = [c for c in kernels if c.startswith('gemm_')]
+            g_ms = sum(kernels[c]['ms_per_step'] for c in gemm)
+            g_gf = sum(gf[c] for c in gemm)
+            bx3 = os.environ.get('FSMG_GEMM', 'bx3') != 'f32'
+            out['roofline_gemm'] = {'bound': 'mfma', 'kernel': 'k_gemm_bx3 (all seven dense contractions of the step)' if bx3 else 'k_gemm (fp32 MFMA)',
+                                    'achieved': g_gf / g_ms, 'peak': PEAK_BX3_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s (fp32-equivalent)',
+                                    'frac': g_gf / g_ms / (PEAK_BX3_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS), 'ms_per_step': g_ms,
+                                    'note': 'peak = dense bf16 MFMA peak / 6 products per fp32 product at the 2.4 GHz spec clock; the chip sustains 1.92 GHz beside this kernel'}
+            log('breakdown done')
+        except Exception as e:                 # noqa: BLE001 -- an extra leg must not cost the result line
+            log('breakdown leg failed: %r' % (e,))
+            extras_failed['breakdown'] = repr(e)
     if rank == 0 and world == 1 and not args.no_breakdown and not maml and os.environ.get('FSMG_GEMM', 'bx3') != 'f32':
         # the same timed loop with every GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32): what the bf16-split GEMMs buy
         try:
@@ -584,8 +616,9 @@ def main():
                                         'advanced_by': alt.engine.step - a0, 'final_loss': float(l_alt[-1]),
                                         'note': 'same workload and schedule, every GEMM on v_mfma_f32_32x32x2_f32 (fsmg_config.gemm = FSMG_GEMM_F32)'}
             del alt, par_alt
-        finally:
-            pass
+        except Exception as e:                 # noqa: BLE001
+            log('fp32-MFMA GEMM leg failed: %r' % (e,))
+            extras_failed['alt_gemm_f32_mfma'] = repr(e)
         log('fp32-MFMA GEMM leg done')
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not maml:
         out['cpu_baseline'] = cpu_baseline(base, pool_host, shape)
@@ -604,6 +637,7 @@ def main():
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:
+        out['extras_failed'] = extras_failed
         sys.stdout.flush()
         print(json.dumps(out))
     if world > 1:
