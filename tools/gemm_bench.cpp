@@ -139,6 +139,9 @@ int main(int argc, char** argv) {
         {"dW      (no colsum) <XC,XC>", OP_XC, OP_XC, H, V, TB, 0, false},
         {"dKh     Hprev^T*dZ  <XC,XC>", OP_XC, OP_XC, H, 4 * H, TB, 0, true},
         {"zx      X*Kx        <KC,XC>", OP_KC, OP_XC, TB, 4 * H, E, 1, false},
+        // the two weight gradients with the activations handed over TRANSPOSED (k = rows contiguous): 16-byte loads for A
+        {"dWt     HoutT*dlog  <KC,XC>", OP_KC, OP_XC, H, V, TB, 0, true},
+        {"dKht    HprevT*dZ   <KC,XC>", OP_KC, OP_XC, H, 4 * H, TB, 0, true},
         // one of the 8 time chunks of the two-stream schedule (16 steps x 45 sequences)
         {"logits/8 chunk      <KC,XC>", OP_KC, OP_XC, TB / 8, V, H, 1, false},
         {"dhout/8  chunk      <KC,KC>", OP_KC, OP_KC, TB / 8, H, V, 0, false},
