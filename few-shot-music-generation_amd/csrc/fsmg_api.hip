@@ -375,13 +375,13 @@ int download_tensor(fsmg_model* h, const float* flat, const char* name, float* h
 // idle; splitting K multiplies the block count.  Cost model: MFMA time at ~100 TF/s divided by the
 // slot efficiency of tiles*S blocks over the resident-block slots, plus S slabs of C written and read back.
 constexpr int MAX_SPLIT = 16;
-int pick_split(int64_t M, int64_t N, int64_t K, int64_t slots = 0, bool bx3 = false) {
+int pick_split(int64_t M, int64_t N, int64_t K, int64_t slots = 0, bool bx3 = false, int tile_mn = 0) {
     static const int max_split_env = std::getenv("FSMG_MAX_SPLIT") ? std::max(1, std::atoi(std::getenv("FSMG_MAX_SPLIT"))) : MAX_SPLIT;   // debugging knob
     if (max_split_env <= 1) return 1;
     if (slots <= 0) slots = gemm_block_slots();
-    if (bx3) slots = slots * 3 / 4;                     // k_gemm_bx3: three resident blocks per CU where k_gemm has four
-    const int64_t tm = gemm_tile_m();
-    const int64_t tiles = ((M + tm - 1) / tm) * ((N + 127) / 128);
+    if (bx3 && tile_mn == 0) slots = slots * 3 / 4;     // k_gemm_bx3: three resident blocks per CU where k_gemm has four
+    const int64_t tm = tile_mn ? tile_mn : gemm_tile_m(), tn = tile_mn ? tile_mn : 128;   // tile_mn = 256: k_gemm_bx3h, `slots` as given
+    const int64_t tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
     const double t_mfma = 2.0 * M * N * K / (bx3 ? 170e12 : 100e12);
     const double t_slab = 2.0 * M * N * 4.0 / 4e12;
     int best = 1; double best_t = 1e30;
@@ -547,15 +547,33 @@ bool use_ws_gemm(fsmg_model* h, int amode, int bmode, const GemmArgs& g, const L
     return g.K <= 4096;                                                                     // KC x KC: dx yes, dH no
 }
 
+// The 256 x 256-tile kernel k_gemm_bx3h (one 8-wave block per CU; half the loads, split work and fragment reads per MFMA; same
+// bits for the same K split): where the output has enough 256-tiles x K slabs to fill the 256 CUs about once.
+// FSMG_GEMM_H=0 / 2: never / wherever it can run (A/B runs).
+bool use_h_gemm(fsmg_model* h, int amode, int bmode, const GemmArgs& g, const Lane& ln) {
+    static const int mode = std::getenv("FSMG_GEMM_H") ? std::atoi(std::getenv("FSMG_GEMM_H")) : 1;
+    if (!h->bx3 || mode == 0 || ln.lds_pad != 0 || g.xcd_first != 0 || g.ce_part != nullptr) return false;
+    if (amode == OP_XC && g.gather != nullptr) return false;
+    if (mode == 2) return true;
+    // measured in the cfg-B step (profiles/r03p_bench_h*.json, ms per launch incl. the slab sums, without / with): dH 0.349 /
+    // 0.296, dW 0.375 / 0.316, projection 0.318 / 0.310, dKh + dKx 0.154 / 0.147; zx 0.047 / 0.051, dx 0.050 / 0.057
+    const int64_t tiles = ((g.M + 255) / 256) * (int64_t)((g.N + 255) / 256);
+    if (amode == OP_KC && bmode == OP_KC) return g.K >= 4096 && tiles >= 32;               // dH, not dx
+    if (amode == OP_XC && bmode == OP_XC) return g.K >= 2048 && tiles >= 16;               // dW, dKh
+    return g.K >= 384 && tiles >= 512;                                                      // the projection, not zx
+}
+
 int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g) {
     hipStream_t s = ln.s;
     g.bx3 = h->bx3;
-    int slots = ln.slots;
-    if (use_ws_gemm(h, amode, bmode, g, ln)) {
+    int slots = ln.slots, tile_mn = 0;
+    if (use_h_gemm(h, amode, bmode, g, ln)) {
+        g.bx3 = 3; slots = 256; tile_mn = 256;
+    } else if (use_ws_gemm(h, amode, bmode, g, ln)) {
         g.bx3 = 2; slots = 512 * 4 / 3;             // pick_split takes 3/4 of `slots` for the bf16-split kernels: 512 here
         if (amode == OP_KC && bmode == OP_XC) g.group_m = 4;
     }
-    const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K, slots, g.bx3 != 0) : 1;
+    const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K, slots, g.bx3 != 0, tile_mn) : 1;
     if (S <= 1 || (int64_t)S * g.M * g.N > h->slab_cap) {
         g.ksplit = 1;
         HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));

@@ -129,14 +129,13 @@ template <int XW> struct Loader<OP_XC, XW> : XcLoader<XW> {
 // lane holds single floats of 16 rows.  Each wave transposes its 64x64 sub-tile through its own slice of the (now
 // idle) pipeline LDS, 32 rows at a time, and stores 16-byte row segments: 16 store instructions per lane
 // instead of 64 (the store tail of a short-K GEMM is issue bound).
-__device__ __forceinline__ void store_tile(const GemmArgs& g, f32x16 (&acc)[2][2], float* smem, int z, int m0, int n0,
-                                           int tn, int tilesN, int wave, int lane) {
-    const int wm = wave >> 1, wn = wave & 1;
+// the 64 x 64 sub-tile whose first row / column is mrow0 / ncol0, staged through the wave-private slice `ep` (32 x 68 floats);
+// wn = which 64-column half of its 128-column tile tn this is (the forward-only cross entropy's partials are per half)
+__device__ __forceinline__ void store_tile_at(const GemmArgs& g, f32x16 (&acc)[2][2], float* ep, int z, int mrow0, int ncol0,
+                                              int tn, int tilesN, int wn, int lane) {
     const int l31 = lane & 31, khalf = lane >> 5;
     float* C = g.C + (long long)z * g.c_slab;
     constexpr int EP_LD = 68;                                  // 64 + 4: rows stay 16-byte aligned
-    float* ep = smem + wave * (32 * EP_LD);                    // one 8.5 KiB slice per wave
-    const int ncol0 = n0 + wn * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -148,7 +147,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, f32x16 (&acc)[2][2
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int rl = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-            const int row = m0 + wm * 64 + i * 32 + rl, col = ncol0 + c4;
+            const int row = mrow0 + i * 32 + rl, col = ncol0 + c4;
             float4 v = *reinterpret_cast<const float4*>(ep + rl * EP_LD + c4);
             if (g.ce_part != nullptr) {
                 // forward-only cross entropy: softmax statistics of this row over the wave's 64 columns; the 16
@@ -190,6 +189,12 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, f32x16 (&acc)[2][2
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                    // reads done before the slice is overwritten
     }
+}
+
+__device__ __forceinline__ void store_tile(const GemmArgs& g, f32x16 (&acc)[2][2], float* smem, int z, int m0, int n0,
+                                           int tn, int tilesN, int wave, int lane) {
+    const int wm = wave >> 1, wn = wave & 1;
+    store_tile_at(g, acc, smem + wave * (32 * 68), z, m0 + wm * 64, n0 + wn * 64, tn, tilesN, wn, lane);   // one 8.5 KiB slice per wave
 }
 
 // XCD-aware tile numbering (bijective for any tile count): block b runs on XCD b % 8; each XCD walks a contiguous
@@ -1003,6 +1008,139 @@ __global__ __launch_bounds__(256 * (MT + 1), MT == 1 ? 2 : 1) void k_gemm_bx3w(c
         o[7] = ((unsigned long long)xcc << 32) | hw;
     }
 }
+
+// ---- 256 x 256 block tile, eight waves of 128 x 64 (GemmArgs::bx3 == 3) -------------------------------------------------------
+// Per MFMA this tile needs half of everything the 128 x 128 kernels need beside the matrix pipe: 32 KiB of operands, 16 values
+// to split per thread and 18 fragment reads per 48 MFMAs of a wave (2.6 issued instructions per MFMA instead of 5.0, 10.7
+// instead of 21 bytes per cycle and CU at the pipe's full rate).  One block per CU, two waves per SIMD -- waves w and w + 4 --
+// and those two run the k tile in OPPOSITE order so that they do not both want the matrix pipe right behind the barrier:
+// waves 0-3 read their fragments, multiply, then split and write their share of the next tile; waves 4-7 split and write
+// first (their loads were issued a whole iteration earlier), then read and multiply.  Same LDS image per 128 rows / columns,
+// k order and term order as k_gemm_bx3: the same bits for the same K split.
+template <int AMODE, int BMODE, bool PROF = false, int BUFM = 0>
+__global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
+    constexpr int XT = 256;
+    constexpr int PLANE = 2 * XT * 16, OPER = 3 * PLANE, STAGE = 2 * OPER;            // 8 KiB, 24 KiB, 48 KiB
+    constexpr int EPI = 8 * 32 * 68 * 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[(2 * STAGE > EPI) ? 2 * STAGE : EPI];
+    __shared__ float s_cs[256];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 2) & 1, wn = wave & 3;      // wave tile: rows 128 wm ..., columns 64 wn ...
+    const bool late = wave >= 4;                          // order of the k tile, see above
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int tilesM = (g.M + XT - 1) / XT, tilesN = (g.N + XT - 1) / XT;
+    const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
+    int tm, tn; tile_coords(bid, tilesM, tilesN, g.group_m, tm, tn);
+    const int z = blockIdx.y;
+    const int m0 = tm * XT, n0 = tn * XT;
+    unsigned long long pacc[5] = {0, 0, 0, 0, 0}, plast = 0, p_entry = 0, p_loop = 0;
+    if (PROF) { p_entry = plast = __builtin_amdgcn_s_memtime(); }
+
+    int kb = 0, ke = g.K;
+    if (g.ksplit > 1) {
+        const int per = ((g.K + g.ksplit - 1) / g.ksplit + 15) / 16 * 16;
+        kb = z * per;
+        ke = min(g.K, kb + per);
+    }
+    const int nk = (ke > kb) ? (ke - kb + 15) / 16 : 0;
+    const int nfull = (ke > kb) ? (ke - kb) / 16 : 0;
+
+    BxStager<AMODE, XT, 512, (BUFM >= 2)> sa;             // 512 threads cover 256 rows / columns, 8 values each
+    BxStager<BMODE, XT, 512, (BUFM >= 1)> sb;
+    sa.init(g.A, g.lda, g.M, m0, g.gather, kb, tid, g.K);
+    sb.init(g.B, g.ldb, g.N, n0, nullptr, kb, tid, g.K);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // column sums of op(B): thread = (x = tid % 256, k half = tid / 256) of the XC stager
+    const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0;
+    float csum = 0.0f;
+#define BXH_FETCH(T)                                                                                           \
+    if ((T) < nfull) { sa.fetch(); sb.fetch(); }                                                               \
+    else { sa.fetch_partial(kb + (T) * 16, ke, tid); sb.fetch_partial(kb + (T) * 16, ke, tid); }
+#define BXH_COMMIT(ST)                                                                                         \
+    if (do_colsum) csum += sb.sum8();                                                                          \
+    sa.commit(smem + (ST) * STAGE);                                                                            \
+    sb.commit(smem + (ST) * STAGE + OPER);
+
+    if (nk > 0) {
+        BXH_FETCH(0)
+        BXH_COMMIT(0)
+        if (nk > 1) { BXH_FETCH(1) }                      // every fetch sits right behind a commit (the VALU half of an iteration)
+    }
+    bx_barrier();
+    const int fa = khalf * (XT * 16) + (wm * 128 + l31) * 16, fb = khalf * (XT * 16) + (wn * 64 + l31) * 16;
+    if (PROF) { p_loop = plast = __builtin_amdgcn_s_memtime(); }
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        // fragments first for every wave, so that the late waves' reads land while they split (and while their partner
+        // multiplies) -- except with two x-contiguous operands, whose stagers leave no registers for that (10 spilled)
+        constexpr bool READS_FIRST = !(AMODE == OP_XC && BMODE == OP_XC);
+        const unsigned char* at = smem + (kt & 1) * STAGE;
+        const unsigned char* bt = at + OPER;
+        bf16x8_t a[3][4], b[3][2];
+#define BXH_READ_FRAGS                                                                                         \
+        _Pragma("unroll") for (int pl = 2; pl >= 0; --pl) {                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) a[pl][i] = *reinterpret_cast<const bf16x8_t*>(at + pl * PLANE + fa + i * 512);        \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) b[2 - pl][j] = *reinterpret_cast<const bf16x8_t*>(bt + (2 - pl) * PLANE + fb + j * 512); \
+        }
+        if (READS_FIRST) { BXH_READ_FRAGS __builtin_amdgcn_sched_barrier(0); }
+        if (late && more) {
+            BXH_COMMIT((kt + 1) & 1)
+            if (kt + 2 < nk) { BXH_FETCH(kt + 2) }
+        }
+        if (READS_FIRST) __builtin_amdgcn_sched_barrier(0);
+        BX_STAMP(3)
+        if (!READS_FIRST) { BXH_READ_FRAGS }
+#undef BXH_READ_FRAGS
+#define BXH_TERM(PA, PB)                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][i], b[PB][j], acc[i][j], 0, 0, 0);
+        BXH_TERM(2, 0) BXH_TERM(0, 2) BXH_TERM(1, 1) BXH_TERM(1, 0) BXH_TERM(0, 1) BXH_TERM(0, 0)
+#undef BXH_TERM
+        BX_STAMP(2)
+        if (!late && more) {
+            BXH_COMMIT((kt + 1) & 1)
+            if (kt + 2 < nk) { BXH_FETCH(kt + 2) }
+        }
+        BX_STAMP(3)
+        bx_barrier();
+        BX_STAMP(4)
+    }
+#undef BXH_FETCH
+#undef BXH_COMMIT
+    const unsigned long long p_exit_loop = PROF ? __builtin_amdgcn_s_memtime() : 0;
+
+    if (do_colsum) {                    // the two k halves of a column live in threads tid and tid + 256
+        if (tid >= 256) s_cs[tid - 256] = csum;
+        bx_barrier();
+        if (tid < 256 && n0 + tid < g.N) g.colsum[(long long)z * g.colsum_slab + n0 + tid] = csum + s_cs[tid];
+    }
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {    // the wave's 128 x 64 tile as two 64 x 64 halves
+        f32x16 (&sub)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * h2][0]);
+        store_tile_at(g, sub, ep, z, m0 + wm * 128 + h2 * 64, n0 + wn * 64, (n0 + wn * 64) / 128, (g.N + 127) / 128, wn & 1, lane);
+    }
+    if (PROF && g.prof != nullptr && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long p_end = __builtin_amdgcn_s_memtime();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* o = g.prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+        o[0] = p_entry; o[1] = p_loop; o[2] = pacc[2]; o[3] = pacc[3]; o[4] = pacc[4]; o[5] = p_exit_loop; o[6] = p_end;
+        o[7] = ((unsigned long long)xcc << 32) | hw;
+    }
+}
 #undef BX_STAMP
 
 template <int AMODE, int BMODE>
@@ -1025,6 +1163,14 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     static const bool buf_off = std::getenv("FSMG_GEMM_BUF") && std::atoi(std::getenv("FSMG_GEMM_BUF")) == 0;      // A/B runs
     const int bufm = (buf_off && g.prof == nullptr) ? 0 : (a_buf && b_buf) ? 2 : (b_buf ? 1 : 0);
     if (g.prof != nullptr && bufm != 2) return hipErrorInvalidValue;     // the stamped instantiations exist for bufm == 2 only
+    if (g.bx3 == 3) {        // 256 x 256 tile
+        dim3 grid3(((g.M + 255) / 256) * ((g.N + 255) / 256), g.ksplit > 1 ? g.ksplit : 1);
+        if (g.prof != nullptr) hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, true, 2>), grid3, dim3(512), lds_pad, s, g);
+        else if (bufm == 2) hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 2>), grid3, dim3(512), lds_pad, s, g);
+        else if (bufm == 1) hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 1>), grid3, dim3(512), lds_pad, s, g);
+        else hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE>), grid3, dim3(512), lds_pad, s, g);
+        return hipGetLastError();
+    }
     if (g.bx3 == 2) {        // wave-specialised variant
         if (g.prof != nullptr) hipLaunchKernelGGL((k_gemm_bx3w<AMODE, BMODE, 1, true, 2>), grid, dim3(512), lds_pad, s, g);
         else if (bufm == 2) hipLaunchKernelGGL((k_gemm_bx3w<AMODE, BMODE, 1, false, 2>), grid, dim3(512), lds_pad, s, g);

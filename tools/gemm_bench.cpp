@@ -71,7 +71,7 @@ static float* dev_random(size_t n, unsigned seed) {
 // PROF=1 (with BX3=1): one more launch of the shape through the stamped instantiation of k_gemm_bx3; prints where a wave's
 // cycles go per k tile, the prologue / epilogue share of a block's life and how many blocks a CU had in their k loop over time
 static void profile_launch(hipStream_t s, int amode, int bmode, GemmArgs g, int pad, int blocks, float ms_plain) {
-    const int NW = g.bx3 == 2 ? 8 : 4;                  // waves per block (bx3 == 2: 4 multipliers + 4 loaders)
+    const int NW = g.bx3 >= 2 ? 8 : 4;                  // waves per block (bx3 == 2: 4 multipliers + 4 loaders; 3: 8 of 128 x 64)
     unsigned long long* d; const size_t n = (size_t)blocks * NW * 8;
     CK(hipMalloc(&d, n * 8)); CK(hipMemset(d, 0, n * 8));
     g.prof = d;
@@ -88,17 +88,17 @@ static void profile_launch(hipStream_t s, int amode, int bmode, GemmArgs g, int 
     unsigned long long base[16]; for (auto& v : base) v = ~0ull;
     for (size_t w = 0; w < (size_t)blocks * NW; ++w) { const unsigned long long* o = &h[w * 8]; if (o[6]) { auto& m = base[(o[7] >> 32) & 15]; m = std::min(m, o[0]); } }
     double span = 0;
-    for (int role = 0; role < (NW > 4 ? 2 : 1); ++role) {
+    for (int role = 0; role < (g.bx3 == 2 ? 2 : 1); ++role) {
         double mf = 0, cm = 0, bar = 0, pro = 0, epi = 0, life = 0, loop = 0; size_t cnt = 0;
         for (size_t w = 0; w < (size_t)blocks * NW; ++w) {
-            if (NW > 4 && (int)((w % NW) >= (size_t)(NW / 2)) != role) continue;
+            if (g.bx3 == 2 && (int)((w % NW) >= (size_t)(NW / 2)) != role) continue;
             const unsigned long long* o = &h[w * 8];
             if (o[6] == 0) continue;
             mf += o[2]; cm += o[3]; bar += o[4]; pro += o[1] - o[0]; epi += o[6] - o[5]; life += o[6] - o[0]; loop += o[5] - o[1]; ++cnt;
             span = std::max(span, (double)(o[6] - base[(o[7] >> 32) & 15]));
         }
         printf("    PROF %s: per wave and k tile (ticks): reads+MFMA issue %.0f  loads wait+split+LDS write %.0f  drain+barrier %.0f  (sum %.0f) | per block: prologue %.0f  loop %.0f  epilogue %.0f  -> pro+epi %.1f %% of its life\n",
-               NW > 4 ? (role ? "loaders    " : "multipliers") : "", mf / cnt / nk, cm / cnt / nk, bar / cnt / nk, (mf + cm + bar) / cnt / nk, pro / cnt, loop / cnt, epi / cnt, 100.0 * (pro + epi) / life);
+               g.bx3 == 2 ? (role ? "loaders    " : "multipliers") : "", mf / cnt / nk, cm / cnt / nk, bar / cnt / nk, (mf + cm + bar) / cnt / nk, pro / cnt, loop / cnt, epi / cnt, 100.0 * (pro + epi) / life);
     }
     printf("    PROF: stamped launch %.3f ms (plain %.3f); span %.0f ticks -> %.0f MHz; %.0f k tiles per block; MFMA pipe floor 768 ticks per k tile and wave\n", ms, ms_plain, span, span / (ms * 1e3), nk);
     // blocks resident / in their k loop per CU over time (wave 0 of every block)
@@ -207,7 +207,7 @@ int main(int argc, char** argv) {
                 if (r >= 0) { ms_k += a; ms_t += b; }
             }
             ms_k /= reps; ms_t /= reps;
-            const int tiles = ((sh.M + gemm_tile_m() - 1) / gemm_tile_m()) * ((sh.N + 127) / 128);
+            const int tiles = bx3 == 3 ? ((sh.M + 255) / 256) * ((sh.N + 255) / 256) : ((sh.M + gemm_tile_m() - 1) / gemm_tile_m()) * ((sh.N + 127) / 128);
             if (verify) {
                 CK(hipStreamSynchronize(s));
                 const double e = max_rel(C, Cref, cn), ec = sh.colsum ? max_rel(cs, csref, sh.N) : 0.0;
