@@ -1,6 +1,7 @@
 """The bf16-split GEMM has several implementations of the same arithmetic (csrc/gemm.hip): k_gemm_bx3 (128 x 128 tiles), its
 wave-specialised variant k_gemm_bx3w and the 256 x 256-tile k_gemm_bx3h (chosen per shape by use_ws_gemm / use_h_gemm,
-csrc/fsmg_api.hip) and, in all of them, operand loads as buffer loads or through 64-bit lane addresses.  DESIGN.md claims they produce THE SAME BITS for the same K split -- same LDS image, k order and term order --
+csrc/fsmg_api.hip) and, in all of them, operand loads as buffer loads or through 64-bit lane addresses (k_gemm_bx3h: two
+x-contiguous operands through LDS-DMA as well, FSMG_GEMM_DMA).  DESIGN.md claims they produce THE SAME BITS for the same K split -- same LDS image, k order and term order --
 which is what lets the choice be made per shape by measured speed alone.  ("For the same K split": the variants keep a different
 number of blocks per CU, so the split policy may cut K differently for them and the slabs are then summed in a different
 association; FSMG_MAX_SPLIT=1 takes that out of the comparison.)  The knobs are read once per process, so every variant
@@ -50,6 +51,6 @@ def test_every_bf16_split_gemm_variant_gives_the_same_bits():
     assert all(x == x and x > 0 for x in base['losses'])
     for over in (dict(FSMG_GEMM_WS='2', FSMG_GEMM_H='0', FSMG_GEMM_BUF='0'), dict(FSMG_GEMM_WS='0', FSMG_GEMM_H='0', FSMG_GEMM_BUF='1'),
                  dict(FSMG_GEMM_WS='2', FSMG_GEMM_H='0', FSMG_GEMM_BUF='1'), dict(FSMG_GEMM_H='2', FSMG_GEMM_BUF='0'),
-                 dict(FSMG_GEMM_H='2', FSMG_GEMM_BUF='1'), dict()):
+                 dict(FSMG_GEMM_H='2', FSMG_GEMM_BUF='1'), dict(FSMG_GEMM_H='2', FSMG_GEMM_DMA='0'), dict()):
         got = _run(**over)
         assert got == base, (over, got, base)

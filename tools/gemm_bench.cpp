@@ -78,8 +78,8 @@ static void profile_launch(hipStream_t s, int amode, int bmode, GemmArgs g, int 
     g.dbg = getenv("DBG") ? atoi(getenv("DBG")) : 0;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     CK(launch_gemm(s, amode, bmode, g, pad));             // warm the instantiation
-    CK(hipEventRecord(a, s)); CK(launch_gemm(s, amode, bmode, g, pad)); CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b));
-    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipEventRecord(a, s)); for (int i = 0; i < 10; ++i) CK(launch_gemm(s, amode, bmode, g, pad)); CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 10;     // (the stamps kept are the last launch's)
     std::vector<unsigned long long> h(n);
     CK(hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost));
     const int per = g.ksplit > 1 ? ((g.K + g.ksplit - 1) / g.ksplit + 15) / 16 * 16 : g.K;
