@@ -277,7 +277,7 @@ def main():
         schedule, recurrence, dp_split_backward) plus `bucketed` for the exchange"""
         over = dict(over)
         bucketed = over.pop('bucketed', None)
-        m = Model(dict(cfg, **over))
+        m = Model(dict(cfg, max_sequences=N_WAY * (K_SHOT + Q_QUERY), **over))
         m.recover_or_init('')
         return m, EpisodeParallel(m, bucketed=bucketed)
 
@@ -496,10 +496,21 @@ def main():
             gflop = sum(gf[c] for c in cell) * args.steps                 # both directions, every launch of the repeat
             ach = gflop / tot_ms if tot_ms > 0 else 0.0
             steps_per_launch = {c: (T * cfg['n_layers'] * args.steps) / max(n, 1) for c, (ms, n) in cell.items()}
+            try:
+                cell_bx3 = bool(eng.debug_read('xcd_bx3', 1)[0])
+            except Exception:                  # noqa: BLE001
+                cell_bx3 = False
+            if cell_bx3:      # hidden 512, > 64 rows: the recurrent product as six bf16 products per fp32 product (csrc/lstm_xcd.hip)
+                cell_kernel = ('k_lstm_fwd_xcd16 + k_lstm_bwd_xcd16 (recurrent [B x H] x [H x 4H] contraction as an exact three-way bf16 split on '
+                               'v_mfma_f32_16x16x32_bf16, fp32 accumulation')
+            elif cfg['hidden_size'] > 512:
+                cell_kernel = 'k_lstm_fwd_pair* + k_lstm_bwd_pair* (recurrent [B x H] x [H x 4H] contraction on v_mfma_f32_4x4x1_16B_f32, K_h in the registers of an XCD pair'
+            else:
+                cell_kernel = 'k_lstm_fwd_xcd + k_lstm_bwd_xcd (recurrent [B x H] x [H x 4H] contraction on v_mfma_f32_4x4x1_16B_f32'
             out['roofline'] = {
                 'bound': 'mfma',
-                'kernel': 'fused LSTM cell: k_lstm_fwd_xcd + k_lstm_bwd_xcd (recurrent [B x H] x [H x 4H] contraction on v_mfma_f32_4x4x1_16B_f32 '
-                          '+ gate nonlinearities / gate gradients + state update, %d dependent time steps per launch)' % int(steps_per_launch['lstm_fwd']),
+                'kernel': 'fused LSTM cell: %s + gate nonlinearities / gate gradients + state update, %d dependent time steps per launch)'
+                          % (cell_kernel, int(steps_per_launch['lstm_fwd'])),
                 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
                 'traffic': hbm_traffic()[0], 'traffic_source': hbm_traffic()[1], 'launches': tot_n, 'avg_launch_ms': tot_ms / max(tot_n, 1),
                 'algorithmic_gflop_per_launch': gf['lstm_fwd'] / max(cell['lstm_fwd'][1] / max(args.steps, 1), 1),
@@ -508,7 +519,11 @@ def main():
                 'backward': {'avg_launch_ms': cell['lstm_bwd'][0] / max(cell['lstm_bwd'][1], 1), 'us_per_time_step': 1e3 * cell['lstm_bwd'][0] / (T * cfg['n_layers'] * args.steps),
                              'frac': gf['lstm_bwd'] * args.steps / cell['lstm_bwd'][0] / PEAK_F32_MFMA_TFLOPS},
                 'note': 'algorithmic 2*B*H*4H FLOP per time step (SURVEY.md 8d, recurrent-only) over the HIP-event time of the launches in the timed '
-                        'schedule; latency-bound chain: us_per_time_step is the figure to watch (0.60 us at the MFMA peak)'}
+                        'schedule; latency-bound chain: us_per_time_step is the figure to watch (0.60 us at the MFMA peak)'
+                        + ('; peak = the fp32 MFMA peak the other kernel family is priced against -- this family runs on the bf16 pipe, whose '
+                           'bound for fp32-equivalent work is %.0f TFLOP/s (frac_bf16_split)' % PEAK_BX3_TFLOPS if cell_bx3 else '')}
+            if cell_bx3:
+                out['roofline']['frac_bf16_split'] = ach / PEAK_BX3_TFLOPS
     if rank == 0 and not maml:
         try:
             # the other half of BASELINE.json's metric: the validation path (query-only forward, batched 16 episodes
@@ -584,7 +599,7 @@ def main():
             g_ms = sum(kernels[c]['ms_per_step'] for c in gemm)
             g_gf = sum(gf[c] for c in gemm)
             bx3 = os.environ.get('FSMG_GEMM', 'bx3') != 'f32'
-            out['roofline_gemm'] = {'bound': 'mfma', 'kernel': 'k_gemm_bx3 (all seven dense contractions of the step)' if bx3 else 'k_gemm (fp32 MFMA)',
+            out['roofline_gemm'] = {'bound': 'mfma', 'kernel': 'k_gemm_bx3h / k_gemm_bx3w / k_gemm_bx3 (all seven dense contractions of the step; 256 x 256 tiles for the three large ones)' if bx3 else 'k_gemm (fp32 MFMA)',
                                     'achieved': g_gf / g_ms, 'peak': PEAK_BX3_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s (fp32-equivalent)',
                                     'frac': g_gf / g_ms / (PEAK_BX3_TFLOPS if bx3 else PEAK_F32_MFMA_TFLOPS), 'ms_per_step': g_ms,
                                     'note': 'peak = dense bf16 MFMA peak / 6 products per fp32 product at the 2.4 GHz spec clock; the chip sustains 1.92 GHz beside this kernel'}

@@ -111,6 +111,7 @@ struct fsmg_model {
                                         // (6.4 against 7.0 us per step; the backward pair kernel ties with the column-split one), 2 = both directions
     int xcd_variant = -1;               // FSMG_XCD_VARIANT: XCD_* bits for both directions (-1: lstm_xcd_default_variant)
     float* khx = nullptr;
+    bool xcd_bx3 = false;               // hidden 512: the XCD-local recurrence on the bf16 matrix pipe (k_lstm_*_xcd16); one format per handle
     float* HX = nullptr; int64_t hx_floats = 0;
     float* inboxX = nullptr; int64_t inboxx_floats = 0;
     int* d_inbox_dirty = nullptr;       // device word: != 0 -> the next BPTT pass refills the inboxes first (set at creation, when the scratch moves,
@@ -434,7 +435,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     const int64_t o_inbox = place(want_inbox ? 4 * n_inbox : 256);
     // XCD-local kernels: sized for the largest row count they take (not for B, same reason)
     const int xrows = (h->persist && h->xcd && lstm_xcd_max_rows((int)Hp) > 0 && (Hp == 512 || h->pair_mode >= 1)) ? std::min(h->xcd_max_rows, lstm_xcd_max_rows((int)Hp)) : 0;
-    const int64_t n_hx = xrows ? lstm_xcd_hx_floats(xrows, (int)T, (int)Hp) : 0;
+    const int64_t n_hx = xrows ? lstm_xcd_hx_floats(xrows, (int)T, (int)Hp, h->xcd_bx3) : 0;
     const int64_t n_inx = (xrows && (Hp == 512 || h->pair_mode >= 2)) ? lstm_xcd_inbox_floats(xrows, (int)Hp) : 0;
     const int64_t o_hx = place(xrows ? 4 * n_hx : 256), o_inx = place(n_inx ? 4 * n_inx : 256);
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
@@ -707,7 +708,7 @@ struct FillBatch {
 inline bool use_xcd(const fsmg_model* h, int B, bool backward = false) {
     if (h->Hp != 512 && h->pair_mode < (backward ? 2 : 1)) return false;
     return h->persist && h->xcd && h->khx != nullptr && h->HX != nullptr && B <= h->xcd_max_rows && lstm_xcd_supported(B, h->Hp) &&
-           lstm_xcd_hx_floats(B, h->T, h->Hp) <= h->hx_floats &&
+           lstm_xcd_hx_floats(B, h->T, h->Hp, h->xcd_bx3) <= h->hx_floats &&
            ((h->Hp != 512 && !backward) || lstm_xcd_inbox_floats(B, h->Hp) <= h->inboxx_floats);
 }
 // Two-stream (eager) or single-stream (hipGraph replay) order for a pass over B sequences.  The XCD-local recurrent kernels
@@ -830,7 +831,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
         if (xcd) {       // the same for the XCD-local hand-off buffer, and fresh ticket counters for this layer's launches
             GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
             h->ticket_next = 0;
-            const long long step_f = lstm_xcd_hx_floats(B, 0, Hp);
+            const long long step_f = lstm_xcd_hx_floats(B, 0, Hp, h->xcd_bx3);
             GEMMCK(fills.add(h->HX, 0u, step_f));
             GEMMCK(fills.add(h->HX + step_f, 0xFFFFFFFFu, step_f * T));
             if (xov && top) GEMMCK(fills.add(h->xov_ctl, 0u, 4 + gemm_items(ghead)));
@@ -844,8 +845,8 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             if (xcd) {
                 ScopedTimer tm(h, "lstm_fwd");
                 LstmFwdXcdArgs a{};
-                a.rpx = rpx; a.Hp = Hp; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, true, Hp);
-                a.KhX = h->khx + (size_t)(2 * l) * Hp * G4; a.HX = h->HX; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
+                a.rpx = rpx; a.Hp = Hp; a.bx3 = h->xcd_bx3 ? 1 : 0; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, true, Hp);
+                a.KhX = h->khx + (size_t)(2 * l) * lstm_xcd_weight_floats((int)Hp, h->xcd_bx3); a.HX = h->HX; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
                 a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_fwd_xcd(s, a));
                 ++h->n_xcd_launches;
@@ -1026,8 +1027,8 @@ int backward(fsmg_model* h, int B, int part = 0) {
             ScopedTimer tm(h, "lstm_bwd");
             if (xcd) {
                 LstmBwdXcdArgs a{};
-                a.rpx = rpx; a.Hp = Hp; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, false, Hp);
-                a.KhXb = h->khx + (size_t)(2 * l + 1) * Hp * G4; a.inbox = h->inboxX; a.Z = h->Z[l]; a.Cs = h->Cs[l];
+                a.rpx = rpx; a.Hp = Hp; a.bx3 = h->xcd_bx3 ? 1 : 0; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, false, Hp);
+                a.KhXb = h->khx + (size_t)(2 * l + 1) * lstm_xcd_weight_floats((int)Hp, h->xcd_bx3); a.inbox = h->inboxX; a.Z = h->Z[l]; a.Cs = h->Cs[l];
                 a.dc = h->dC; a.dH = h->dH; a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_bwd_xcd(s, a));
                 ++h->n_xcd_launches;
@@ -1123,12 +1124,12 @@ int repack_recurrent_weights(fsmg_model* h, hipStream_t s) {
     const bool x_ok = h->khx == nullptr || h->Hp == 512 || h->Hp == 1024;
     if (h->L <= REPACK_MAX_LAYERS && x_ok) {
         RepackAllArgs a{};
-        a.n = h->L; a.Hp = h->Hp;
+        a.n = h->L; a.Hp = h->Hp; a.bx3 = h->xcd_bx3 ? 1 : 0;
         for (int l = 0; l < h->L; ++l) {
             a.Kh[l] = h->P + h->off_kh[l];
             a.cf[l] = h->khf + (size_t)(2 * l) * h->Hp * h->G4; a.cb[l] = h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4;
-            a.xf[l] = h->khx ? h->khx + (size_t)(2 * l) * h->Hp * h->G4 : nullptr;
-            a.xb[l] = h->khx ? h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4 : nullptr;
+            a.xf[l] = h->khx ? h->khx + (size_t)(2 * l) * lstm_xcd_weight_floats((int)h->Hp, h->xcd_bx3) : nullptr;
+            a.xb[l] = h->khx ? h->khx + (size_t)(2 * l + 1) * lstm_xcd_weight_floats((int)h->Hp, h->xcd_bx3) : nullptr;
         }
         HIPCK(h, launch_repack_kh_all(s, a));
         return FSMG_OK;
@@ -1136,8 +1137,8 @@ int repack_recurrent_weights(fsmg_model* h, hipStream_t s) {
     for (int l = 0; l < h->L; ++l) {
         HIPCK(h, launch_repack_kh(s, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
                                   h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
-        if (h->khx) HIPCK(h, launch_repack_kh_xcd(s, h->P + h->off_kh[l], h->khx + (size_t)(2 * l) * h->Hp * h->G4,
-                                                  h->khx + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
+        if (h->khx) HIPCK(h, launch_repack_kh_xcd(s, h->P + h->off_kh[l], h->khx + (size_t)(2 * l) * lstm_xcd_weight_floats((int)h->Hp, h->xcd_bx3),
+                                                  h->khx + (size_t)(2 * l + 1) * lstm_xcd_weight_floats((int)h->Hp, h->xcd_bx3), h->Hp, h->xcd_bx3));
     }
     return FSMG_OK;
 }
@@ -1570,7 +1571,11 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     if (hipMalloc((void**)&h->khf, sizeof(float) * (size_t)h->L * 2 * h->Hp * h->G4) != hipSuccess)
         return bail(FSMG_ERR_NOMEM, "hipMalloc(fragment weights) failed");
     if (h->persist && h->xcd && lstm_xcd_supported(1, h->Hp)) {
-        if (hipMalloc((void**)&h->khx, sizeof(float) * (size_t)h->L * 2 * lstm_xcd_weight_floats(h->Hp)) != hipSuccess)
+        // bf16-split XCD-local kernels where the episode the handle is created for has the rows that make them the faster ones
+        // (cfg-D: 100 sequences); FSMG_XCD_BX3=0/1 forces.  One format per handle: weight images and hand-off buffer follow it.
+        h->xcd_bx3 = lstm_xcd_bx3_pays(cfg->max_sequences > 0 ? cfg->max_sequences : 45, h->Hp) && (cfg->max_sequences <= h->xcd_max_rows);
+        if (const char* e = std::getenv("FSMG_XCD_BX3")) h->xcd_bx3 = std::atoi(e) != 0 && h->Hp == 512;
+        if (hipMalloc((void**)&h->khx, sizeof(float) * (size_t)h->L * 2 * lstm_xcd_weight_floats(h->Hp, h->xcd_bx3)) != hipSuccess)
             return bail(FSMG_ERR_NOMEM, "hipMalloc(XCD-local weight images) failed");
     }
     const int b0 = cfg->max_sequences > 0 ? cfg->max_sequences : 45;
@@ -2057,6 +2062,7 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
         return (l >= 0 && l < h->L && std::strlen(what) > n) ? l : -1;
     };
     int l;
+    if (!std::strcmp(what, "xcd_bx3")) { host[0] = h->xcd_bx3 ? 1.0f : 0.0f; return FSMG_OK; }      // a host-side fact: which XCD-local kernel family this handle runs
     if (!std::strcmp(what, "logits")) { src = h->logits; cap = rows * h->V1p; }
     else if (!std::strcmp(what, "dlogits")) { src = h->dlogits; cap = rows * h->V1p; }
     else if (!std::strcmp(what, "lse")) { src = h->lse; cap = rows; }

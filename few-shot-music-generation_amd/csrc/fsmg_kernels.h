@@ -171,6 +171,7 @@ struct LstmFwdXcdArgs {
     int rpx;                    // rows per XCD; 0 = ceil(B / 8).  lstm_xcd_packed_rows(B) packs the batch on the first XCDs
     int variant;                // XCD_* bits; lstm_xcd_default_variant(B, forward) has the measured choice
     int Hp;                     // 512 (0 = 512): one copy of K_h per XCD; 1024: one copy per XCD PAIR (k_lstm_fwd_pair)
+    int bx3;                    // hidden 512: KhX / HX are in the bf16-split format, run k_lstm_fwd_xcd16
 };
 struct LstmBwdXcdArgs {
     const float* KhXb;    // backward register image of K_h
@@ -187,17 +188,20 @@ struct LstmBwdXcdArgs {
     int rpx;              // as LstmFwdXcdArgs
     int variant;          // as LstmFwdXcdArgs
     int Hp;               // as LstmFwdXcdArgs
+    int bx3;              // as LstmFwdXcdArgs (KhXb in the bf16-split format, k_lstm_bwd_xcd16)
 };
 bool lstm_xcd_supported(int B, int Hp);        // Hp 512: up to 128 rows; Hp 1024 (one copy of K_h per XCD pair): up to 64 rows
 int lstm_xcd_max_rows(int Hp);                 // 128 / 64 / 0
-long long lstm_xcd_hx_floats(int B, int T, int Hp = 512);
+long long lstm_xcd_hx_floats(int B, int T, int Hp = 512, bool bx3 = false);   // bx3: for the bf16-split kernels (hidden 512)
 long long lstm_xcd_inbox_floats(int B, int Hp = 512);
-long long lstm_xcd_weight_floats(int Hp = 512);   // floats per register image
+long long lstm_xcd_weight_floats(int Hp = 512, bool bx3 = false);   // floats per register image
+bool lstm_xcd_bx3_pays(int B, int Hp);         // the bf16-split kernels are the faster ones at this row count
 int lstm_xcd_packed_rows(int B);               // rows per XCD that leave whole XCDs free without adding row groups (hidden 512)
-hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp = 512);
+hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp = 512, bool bx3 = false);
 // all layers, both layouts, one launch: Kh[l] -> cf / cb (launch_repack_kh) and, where xf[l] != nullptr, xf / xb (launch_repack_kh_xcd)
 constexpr int REPACK_MAX_LAYERS = 4;
-struct RepackAllArgs { int n; int Hp; const float* Kh[REPACK_MAX_LAYERS]; float* cf[REPACK_MAX_LAYERS]; float* cb[REPACK_MAX_LAYERS]; float* xf[REPACK_MAX_LAYERS]; float* xb[REPACK_MAX_LAYERS]; };
+struct RepackAllArgs { int n; int Hp; const float* Kh[REPACK_MAX_LAYERS]; float* cf[REPACK_MAX_LAYERS]; float* cb[REPACK_MAX_LAYERS]; float* xf[REPACK_MAX_LAYERS]; float* xb[REPACK_MAX_LAYERS];
+                       int bx3; /* hidden 512: the XCD images as three bf16 planes (k_lstm_*_xcd16) */ };
 hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a);
 hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a);
 hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);

@@ -53,6 +53,7 @@
 #include "lstm_cell.h"
 #include "lstm_repack.h"
 #include <type_traits>
+#include <cstdlib>
 #include <algorithm>
 
 namespace fsmg {
@@ -476,6 +477,473 @@ __device__ __forceinline__ void repack_kh_xcd_body(const float* __restrict__ Kh,
 }
 __global__ void k_repack_kh_xcd(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd) {
     repack_kh_xcd_body(Kh, fwd, bwd, blockIdx.x, gridDim.x);
+}
+
+// ================================================================ hidden size 512 on the bf16 matrix pipe (round 3)
+// The recurrent product of the kernels above runs at the fp32 MFMA rate and pays for 4-row groups: a 6-row slice (B = 45) costs
+// 2 x 128 `4x4x1` MFMAs = 2048 cycles per step and wave, 13 rows (B = 100) cost 4096.  The dense GEMMs of the step already
+// compute fp32 products from an exact three-way bf16 split on the bf16 pipe (gemm.hip: six products per term, 16x the fp32
+// rate per instruction); the same arithmetic here: K_h sits in the registers as THREE bf16 planes (192 VGPRs per lane instead
+// of 128), h_t travels as three bf16 planes (split once, by the cell thread that produced it), and a step's product is
+// 96 `v_mfma_f32_16x16x32_bf16` per wave = 1536 cycles for ANY number of rows up to 16 per XCD.
+//   forward : wave w = K range 128 w ... (four k steps of 32) x the CU's 64 gate columns (four 16-column tiles, tile nt = unit
+//             block nt: column 16 nt + 4 g + e).  A operand = rows of h: lane (row = l % 16, k group = l / 16) holds 8 bf16 of
+//             one plane; only the lanes of real rows load anything, the others stay zero.
+//   HX16    : [T+1][8 xcd][4 w][3 planes][4 k steps][4 RG rows][4 k groups] 16-byte words = 8 units of one row and plane: the
+//             rows a load instruction fetches are contiguous (6 rows = 384 bytes; with the row outermost every poll round
+//             was 6 scattered 64-byte pieces per instruction, 9000 requests per XCD, and the forward step 3.1 us).
+//             Eight cell lanes pack their units' bf16 with DPP moves and one of them stores the word; the consumers' readiness
+//             test is per 16-bit half (fill 0xFFFF is a bf16 NaN, no h or residual is).
+//   backward: dz slice (rows x the CU's 64 gate columns) as A, split by the cell threads into LDS; wave w holds K_h^T for
+//             destination units 128 w ... (eight 16-unit tiles = eight destination CUs) x 64 columns (two k steps); the D
+//             registers of tile nt ARE the inbox words of destination 8 w + nt (lane = (row group, unit), 4 rows per lane).
+// Term order and split are those of gemm.hip (smallest products first, fp32 accumulation).
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 xbf16x8;
+typedef unsigned short xu16x2 __attribute__((ext_vector_type(2)));
+constexpr int HXW16 = 4 * 3 * 4 * 4;          // 16-byte words per row of one XCD and time index
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {          // low half = bf16(x), round to nearest even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ void split3(float x, unsigned (&p)[3]) {
+    p[0] = bf16_rne(x);
+    const float r1 = x - __uint_as_float(p[0] << 16);
+    p[1] = bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(p[1] << 16);
+    p[2] = bf16_rne(r2);
+}
+template <int OFS>
+__device__ __forceinline__ f32x4 load_sc1_ofs(const f32x4* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=&v"(v) : "v"(p), "n"(OFS) : "memory");
+    return v;
+}
+template <int OFS>
+__device__ __forceinline__ void store_l2_ofs(f32x4* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" : : "v"(p), "v"(v), "n"(OFS) : "memory");
+}
+// Eight consecutive lanes (units 8 h ... 8 h + 7 of one row: cell lane = 16 i + 4 bb + e) each hold one bf16 in the low half
+// of `p`; the lane with bb even, e = 0 gets the 16-byte hand-off word of the eight.  (Three 2-byte stores per lane instead cost
+// 860 cycles per step in the store queue and delayed the consumers by as much, profiles/r03_xcd16_probe1.log.)
+__device__ __forceinline__ f32x4 pack8_bf16(unsigned p) {
+    const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p, 0xB1, 0xF, 0xF, true);             // lane ^ 1
+    const unsigned d = __builtin_amdgcn_perm(nb, p, 0x05040100u);                                          // {own, neighbour}
+    const unsigned q1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d, 0xAA, 0xF, 0xF, true);            // lane 2 of the quad
+    const unsigned n0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d, 0x104, 0xF, 0xF, true);           // row_shl:4 = next quad
+    const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)q1, 0x104, 0xF, 0xF, true);
+    return f32x4{__uint_as_float(d), __uint_as_float(q1), __uint_as_float(n0), __uint_as_float(n1)};
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// no 16-bit half of the twelve fragments shows the fill pattern
+__device__ __forceinline__ bool frags16_ready(const f32x4 (&av)[12]) {
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = pk_max_u16(m, __float_as_uint(av[j][e]));
+    return (m & 0xffffu) != 0xffffu && (m >> 16) != 0xffffu;
+}
+__device__ __forceinline__ xbf16x8 as_bf16x8(const f32x4& v) { return *reinterpret_cast<const xbf16x8*>(&v); }
+
+#define XCD_STAMP(i) if (PROF) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc[i] += n_ - plast; plast = n_; }
+#define X16_TERMS(DO) DO(2, 0) DO(0, 2) DO(1, 1) DO(1, 0) DO(0, 1) DO(0, 0)
+template <int RG, bool PROF>
+__global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd16(const LstmFwdXcdArgs a) {
+    constexpr int HXR = 4 * RG;                  // rows per XCD the hand-off buffer is laid out for
+    __shared__ __attribute__((aligned(16))) float red[2][4][16 * 16 * 4];   // [step parity][wave][row][unit][gate]
+    __shared__ int s_role[2];
+    __shared__ int s_fail;
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_fail = 0;
+    Role role;
+    if (!take_role(a.tickets, a.err_flag, s_role, role)) return;
+    const int xcd = role.xcd, cu = role.cu;
+    const int B = a.B;
+    const int rpx = a.rpx > 0 ? a.rpx : (B + NXCD - 1) / NXCD, row0 = xcd * rpx;
+    if (row0 >= B) return;
+    const int rgc = min((rpx + 3) >> 2, RG);     // waves with cell threads: wave rg owns rows 4 rg ... 4 rg + 3
+
+    xbf16x8 W[3][4][4];                          // [plane][k step][column tile]
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.KhX) + ((size_t)(cu * 4 + wave) * 48) * 64 + lane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x4 wv = wp[((pl * 4 + ks) * 4 + nt) * 64];
+                    asm volatile("" : "+a"(wv));          // the weights live in the accumulation half of the register file: the
+                    W[pl][ks][nt] = as_bf16x8(wv);        // arch half is for the fragments in flight, the cell update and the addresses
+                }
+    }
+    const int ci = lane >> 4, cbb = (lane >> 2) & 3, ce = lane & 3;
+    const int lrow = 4 * wave + ci, row = row0 + lrow, unit = 16 * cu + 4 * cbb + ce;
+    const bool cellw = wave < rgc;
+    const bool act = cellw && lrow < rpx && row < B;
+    const bool pub = cellw && lrow < rpx;         // rows past B on the last XCD publish zeros: the readers load every row < rpx
+    float cp = act ? a.Cs[((size_t)a.t0 * B + row) * XH + unit] : 0.0f;
+    const int arow = lane & 15, akg = lane >> 4;
+    const bool ldl = arow < rpx;                  // lanes of pad rows never load: their A registers stay zero
+    const size_t hx_step = (size_t)HXR * NXCD * HXW16;                      // 16-byte words per time index
+    const f32x4* hx_in = reinterpret_cast<const f32x4*>(a.HX) + (((size_t)xcd * 4 + wave) * 12) * (HXR * 4) + arow * 4 + akg;
+    // unit u = 16 cu + 4 cbb + ce -> w = u / 128, k step = u % 128 / 32, k group = u % 32 / 8, position u % 8
+    f32x4* hx_out = reinterpret_cast<f32x4*>(a.HX) +
+        ((((size_t)xcd * 4 + (cu >> 3)) * 12 + ((cu & 7) >> 1)) * (HXR * 4) + lrow * 4 + 2 * (cu & 1) + (cbb >> 1));
+    const bool stl = pub && ce == 0 && (cbb & 1) == 0;      // the lane that stores the eight units 8 (cbb / 2) ... of its row
+    unsigned long long pacc[5] = {0, 0, 0, 0, 0}, plast = PROF ? __builtin_amdgcn_s_memtime() : 0;
+    float zq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float o_c = 0.f, o_hh = 0.f, o_g[4] = {0.f, 0.f, 0.f, 0.f};
+    bool o_have = false;
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (a.t0 + k < a.t1) {
+                const float* zn = a.Z + ((size_t)(a.t0 + k) * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) zq[k][g] = zn[4 * g];
+            }
+    }
+    f32x4 av[12];                                 // [plane][k step]
+#pragma unroll
+    for (int j = 0; j < 12; ++j) av[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = a.t0; t < a.t1; ++t) {
+        XCD_STAMP(4)
+        {
+            bool fail = false;
+            const f32x4* af = hx_in + (size_t)t * hx_step;
+            for (int spins = 0;; ++spins) {
+                if (ldl) {
+#define X16_LD(J) av[J] = load_sc1_ofs<((J) & 3) * HXR * 64>(af + ((J) >> 2) * (4 * HXR * 4));      /* (plane, k step) stride: HXR x 64 bytes */
+                    X16_LD(0) X16_LD(1) X16_LD(2) X16_LD(3) X16_LD(4) X16_LD(5) X16_LD(6) X16_LD(7) X16_LD(8) X16_LD(9) X16_LD(10) X16_LD(11)
+#undef X16_LD
+                    drain_vmem();
+                }
+#pragma unroll
+                for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(av[j]));
+                const bool ok = !ldl || frags16_ready(av);
+                if (__all(ok)) break;
+                if (!(a.variant & XCD_NO_POLL_SLEEP)) __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
+                if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+            }
+            if (fail && lane == 0) {
+                __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_fail = 1;
+            }
+        }
+        if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {
+            a.Cs[((size_t)t * B + row) * XH + unit] = o_c;
+            a.Hs[((size_t)t * B + row) * XH + unit] = o_hh;
+            float* zo = a.Z + ((size_t)(t - 1) * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
+            zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+        }
+        float zin[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { zin[g] = zq[0][g]; zq[0][g] = zq[1][g]; zq[1][g] = 0.0f; }
+        float* zp = a.Z + ((size_t)t * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
+        if (act && t + 2 < a.t1) {
+            const float* zn = zp + 2 * (size_t)B * XG4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) zq[1][g] = zn[4 * g];
+        }
+        XCD_STAMP(0)
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#define X16_FWD(PA, PB)                                                                                         \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                    \
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(av[(PA) * 4 + ks]), W[PB][ks][nt], acc[nt], 0, 0, 0);
+            X16_TERMS(X16_FWD)
+#undef X16_FWD
+        }
+        if (PROF) { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); acc[0][0] += 0.0f; }
+        XCD_STAMP(1)
+        if (akg < rgc) {                           // D: lane = (column 4 g + e of the tile, rows 4 akg ... + 3)
+            float* rp = &red[t & 1][wave][0] + ((4 * akg) * 16 + (lane & 3)) * 4 + ((lane >> 2) & 3);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rp[(r * 16 + 4 * nt) * 4] = acc[nt][r];
+        }
+        __syncthreads();
+        if (s_fail) return;
+        XCD_STAMP(2)
+
+        if (cellw) {
+            float hn = 0.0f, g_si = 0.f, g_tj = 0.f, g_sf = 0.f, g_so = 0.f;
+            if (act) {
+                const f32x4* rsrc = reinterpret_cast<const f32x4*>(&red[t & 1][0][0]) + lrow * 16 + 4 * cbb + ce;
+                const f32x4 r0 = rsrc[0], r1 = rsrc[256], r2 = rsrc[512], r3 = rsrc[768];
+                float zg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float zs = 0.0f;
+                    zs += r0[g]; zs += r1[g]; zs += r2[g]; zs += r3[g];
+                    zg[g] = zin[g] + zs;
+                }
+                const CellOut co = cell_forward(zg, cp);
+                hn = co.h; cp = co.c;
+                g_si = co.si; g_tj = co.tj; g_sf = co.sf; g_so = co.so;
+            }
+            {
+                unsigned hp[3];
+                split3(hn, hp);                    // (every lane of a cell wave: the packing below crosses lanes)
+                const f32x4 w0 = pack8_bf16(hp[0]), w1 = pack8_bf16(hp[1]), w2 = pack8_bf16(hp[2]);
+                if (stl) {
+                    f32x4* o = hx_out + (size_t)(t + 1) * hx_step;
+                    store_l2_ofs<0>(o, w0); store_l2_ofs<0>(o + 4 * HXR * 4, w1); store_l2_ofs<0>(o + 8 * HXR * 4, w2);
+                }
+            }
+            XCD_STAMP(3)
+            if (a.variant & XCD_DEFER_OUTPUTS) {
+                o_c = cp; o_hh = hn; o_g[0] = g_si; o_g[1] = g_tj; o_g[2] = g_sf; o_g[3] = g_so; o_have = true;
+            } else if (act) {
+                a.Cs[((size_t)(t + 1) * B + row) * XH + unit] = cp;
+                a.Hs[((size_t)(t + 1) * B + row) * XH + unit] = hn;
+                zp[0] = g_si; zp[4] = g_tj; zp[8] = g_sf; zp[12] = g_so;
+            }
+        }
+    }
+    if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {
+        a.Cs[((size_t)a.t1 * B + row) * XH + unit] = o_c;
+        a.Hs[((size_t)a.t1 * B + row) * XH + unit] = o_hh;
+        float* zo = a.Z + ((size_t)(a.t1 - 1) * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
+        zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+    }
+    if (PROF && lane == 0 && a.prof) {
+        XCD_STAMP(4)
+        for (int i = 0; i < 5; ++i) a.prof[((size_t)(xcd * NCU + cu) * 4 + wave) * 8 + i] = pacc[i];
+    }
+}
+
+// inbox as in k_lstm_bwd_xcd: [2 slots][8 xcd][32 dest][32 producer][RG][16 units][4 rows]
+template <int RG, bool PROF>
+__global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd16(const LstmBwdXcdArgs a) {
+    constexpr int NG = 4 / RG;
+    constexpr int LPW = 2 * RG;
+    __shared__ __attribute__((aligned(16))) float psum[4 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char dzA[3][2][64][16];      // [plane][k step][lane = (k group, row)][8 bf16]
+    __shared__ int s_role[2];
+    __shared__ int s_fail;
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_fail = 0;
+    for (int i = tid; i < 3 * 2 * 64 * 4; i += 256) reinterpret_cast<unsigned*>(&dzA[0][0][0][0])[i] = 0u;     // rows >= 4 RG stay zero
+    Role role;
+    if (!take_role(a.tickets, a.err_flag, s_role, role)) return;
+    const int xcd = role.xcd, cu = role.cu;
+    const int B = a.B;
+    const int rpx = a.rpx > 0 ? a.rpx : (B + NXCD - 1) / NXCD, row0 = xcd * rpx;
+    if (row0 >= B) return;
+
+    xbf16x8 W[3][2][8];                           // [plane][k step][destination tile]: Kh[128 w + 16 nt + l % 16][64 cu + 32 ks + 8 (l / 16) + j]
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.KhXb) + ((size_t)(cu * 4 + wave) * 48) * 64 + lane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    f32x4 wv = wp[((pl * 2 + ks) * 8 + nt) * 64];
+                    asm volatile("" : "+a"(wv));
+                    W[pl][ks][nt] = as_bf16x8(wv);
+                }
+    }
+    const int ci = lane >> 4, cbb = (lane >> 2) & 3, ce = lane & 3;
+    const int lrow = 4 * wave + ci, row = row0 + lrow, unit = 16 * cu + 4 * cbb + ce;
+    const bool cellw = wave < RG;
+    const bool act = cellw && lrow < rpx && row < B;
+    const size_t hi = (size_t)row * XH + unit;
+    float dcv = act ? a.dc[hi] : 0.0f;
+    const size_t slot_w = (size_t)NXCD * NCU * NCU * RG * 16;
+    f32x4* const inbox = reinterpret_cast<f32x4*>(a.inbox);
+    const size_t in_base = (((size_t)xcd * NCU + cu) * NCU + 8 * wave) * RG * 16 + lane;
+    // producer side: tile nt of wave w -> destination 8 w + nt, word (dest, producer = cu, row group l / 16, unit l % 16)
+    const size_t out_ofs = ((((size_t)xcd * NCU + 8 * wave) * NCU + cu) * RG + (lane >> 4)) * 16 + (lane & 15);
+    const bool outl = (lane >> 4) < RG;
+    const f32x4 fill = f32x4{__uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu)};
+    unsigned long long pacc[5] = {0, 0, 0, 0, 0}, plast = PROF ? __builtin_amdgcn_s_memtime() : 0;
+    // dz of gate g, local column k = 16 cbb + 4 g + ce: k step cbb / 2, k group 2 (cbb % 2) + g / 2, position 4 (g % 2) + ce
+    unsigned short* const dz_out = reinterpret_cast<unsigned short*>(&dzA[0][cbb >> 1][(2 * (cbb & 1)) * 16 + lrow][0]) + ce;
+
+    float n_si = 0.f, n_tj = 0.f, n_sf = 0.f, n_so = 0.f, n_ct = 0.f, n_cp = 0.f, n_dh = 0.f;
+    if (act && a.t1 > a.t0) {
+        const int t = a.t1 - 1;
+        const float* gp = a.Z + ((size_t)t * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
+        n_si = gp[0]; n_tj = gp[4]; n_sf = gp[8]; n_so = gp[12];
+        n_ct = a.Cs[(size_t)(t + 1) * B * XH + hi]; n_cp = a.Cs[(size_t)t * B * XH + hi];
+        n_dh = a.dH[(size_t)t * B * XH + hi];
+    }
+
+    for (int t = a.t1 - 1; t >= a.t0; --t) {
+        XCD_STAMP(4)
+        const float si = n_si, tj = n_tj, sf = n_sf, so = n_so, ct = n_ct, cpv = n_cp, dht = n_dh;
+        float* gp = a.Z + ((size_t)t * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
+        // ---- A: consume
+        f32x4 wsum = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < a.T) {
+            f32x4* in = inbox + (size_t)((t + 1) & 1) * slot_w + in_base;
+            f32x4 v[LPW];
+            bool fail = false;
+            for (int spins = 0;; ++spins) {
+#pragma unroll
+                for (int k = 0; k < LPW; ++k) v[k] = load_sc1(in + k * 64);
+                drain_vmem();
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < LPW; ++k) { asm volatile("" : "+v"(v[k])); ok &= frag_ready(v[k]); }
+                if (__all(ok)) break;
+                if (!(a.variant & XCD_NO_POLL_SLEEP)) __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
+                if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+            }
+            if (fail && lane == 0) {
+                __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_fail = 1;
+            }
+#pragma unroll
+            for (int k = 0; k < LPW; ++k) {
+                store_l2(in + k * 64, fill);
+                wsum = (k == 0) ? v[0] : wsum + v[k];
+            }
+        }
+        XCD_STAMP(0)
+        *reinterpret_cast<f32x4*>(&psum[(wave * 64 + lane) * 4]) = wsum;
+        __syncthreads();
+        if (s_fail) return;
+        XCD_STAMP(1)
+
+        // ---- B: gate gradients
+        float di = 0.f, dj = 0.f, df = 0.f, dg = 0.f;
+        if (cellw) {
+            if (act) {
+                float dh_rec = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int grp = 0; grp < NG; ++grp)
+                        dh_rec += psum[(w * 64 + (grp * RG + wave) * 16 + 4 * cbb + ce) * 4 + ci];
+                const CellGrad cg = cell_backward(si, tj, sf, so, ct, cpv, dcv, dht + dh_rec);
+                di = cg.di; dj = cg.dj; df = cg.df; dg = cg.dg;
+                if (!(a.variant & XCD_DEFER_OUTPUTS)) { gp[0] = di; gp[4] = dj; gp[8] = df; gp[12] = dg; }
+                dcv = cg.dc_out;
+            }
+            const float dzv[4] = {di, dj, df, dg};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned p3[3];
+                split3(dzv[g], p3);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)        // plane stride 2 * 64 * 8 halves, k group stride 16 * 8
+                    dz_out[pl * (2 * 64 * 8) + (g >> 1) * (16 * 8) + 4 * (g & 1)] = (unsigned short)p3[pl];
+            }
+        }
+        __syncthreads();
+        XCD_STAMP(2)
+        drain_vmem();
+        if ((a.variant & XCD_DEFER_OUTPUTS) && act) { gp[0] = di; gp[4] = dj; gp[8] = df; gp[12] = dg; }
+        if (act && t > a.t0) {
+            const float* gn = a.Z + ((size_t)(t - 1) * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
+            n_si = gn[0]; n_tj = gn[4]; n_sf = gn[8]; n_so = gn[12];
+            n_ct = cpv; n_cp = a.Cs[(size_t)(t - 1) * B * XH + hi];
+            n_dh = a.dH[(size_t)(t - 1) * B * XH + hi];
+        }
+
+        // ---- C: produce the partials of dh_{t-1}
+        if (t > 0) {
+            xbf16x8 av[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) av[pl][ks] = *reinterpret_cast<const xbf16x8*>(&dzA[pl][ks][lane][0]);
+            f32x4 acc[8];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#define X16_BWD(PA, PB)                                                                                         \
+                _Pragma("unroll") for (int nt = 0; nt < 8; ++nt)                                                \
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[PA][ks], W[PB][ks][nt], acc[nt], 0, 0, 0);
+                X16_TERMS(X16_BWD)
+#undef X16_BWD
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            XCD_STAMP(3)
+            if (outl) {
+                f32x4* out = inbox + (size_t)(t & 1) * slot_w + out_ofs;
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) store_l2(out + (size_t)nt * NCU * RG * 16, acc[nt]);
+            }
+        }
+    }
+    if (act) a.dc[hi] = dcv;
+    if (PROF && lane == 0 && a.prof) {
+        XCD_STAMP(4)
+        for (int i = 0; i < 5; ++i) a.prof[((size_t)(xcd * NCU + cu) * 4 + wave) * 8 + i] = pacc[i];
+    }
+}
+#undef X16_TERMS
+#undef XCD_STAMP
+
+// Kh [512][2048] (packed gate columns) -> the three-plane bf16 register images of the two kernels above, 16-byte words
+// [cu][w][48][64 lanes]:
+//   fwd word (pl * 4 + ks) * 4 + nt, lane l, position j: plane pl of Kh[128 w + 32 ks + 8 (l / 16) + j][64 cu + 16 nt + l % 16]
+//   bwd word (pl * 2 + ks) * 8 + nt, lane l, position j: plane pl of Kh[128 w + 16 nt + l % 16][64 cu + 32 ks + 8 (l / 16) + j]
+__device__ __forceinline__ void repack_kh_xcd16_body(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd, int b, int nb) {
+    const int total = NCU * 4 * 16 * 64;            // (cu, w, 16 operand slots, lane) per image
+    uint4* const fo = reinterpret_cast<uint4*>(fwd);
+    uint4* const bo = reinterpret_cast<uint4*>(bwd);
+    for (int idx = b * blockDim.x + threadIdx.x; idx < total; idx += nb * blockDim.x) {
+        const int l = idx & 63, slot = (idx >> 6) & 15, w = (idx >> 10) & 3, cu = idx >> 12;
+        float x[8];
+        unsigned pk[3][4];
+        {
+            const int ks = slot >> 2, nt = slot & 3;
+            const float* src = Kh + (size_t)(128 * w + 32 * ks + 8 * (l >> 4)) * XG4 + 64 * cu + 16 * nt + (l & 15);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = src[(size_t)j * XG4];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                unsigned p0[3], p1[3];
+                split3(x[j], p0); split3(x[j + 1], p1);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) pk[pl][j >> 1] = (p0[pl] & 0xffffu) | (p1[pl] << 16);
+            }
+            const size_t base = ((size_t)(cu * 4 + w) * 48) * 64 + l;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fo[base + (size_t)((pl * 4 + ks) * 4 + nt) * 64] = make_uint4(pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]);
+        }
+        {
+            const int ks = slot >> 3, nt = slot & 7;
+            const float* src = Kh + (size_t)(128 * w + 16 * nt + (l & 15)) * XG4 + 64 * cu + 32 * ks + 8 * (l >> 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = src[j];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                unsigned p0[3], p1[3];
+                split3(x[j], p0); split3(x[j + 1], p1);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) pk[pl][j >> 1] = (p0[pl] & 0xffffu) | (p1[pl] << 16);
+            }
+            const size_t base = ((size_t)(cu * 4 + w) * 48) * 64 + l;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bo[base + (size_t)((pl * 2 + ks) * 8 + nt) * 64] = make_uint4(pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]);
+        }
+    }
+}
+__global__ void k_repack_kh_xcd16(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd) {
+    repack_kh_xcd16_body(Kh, fwd, bwd, blockIdx.x, gridDim.x);
 }
 
 // ================================================================ XCD-PAIR-local recurrence, hidden size 1024 (cfg-C / cfg-E)
@@ -1252,6 +1720,7 @@ __global__ void k_repack_kh_all(const RepackAllArgs a) {
     if (kind == 0) { repack_kh_chunked(a.Kh[l], a.cf[l], a.cb[l], a.Hp, blockIdx.x, gridDim.x); return; }
     if (a.xf[l] == nullptr) return;
     if (a.Hp == PH) repack_kh_pair_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
+    else if (a.bx3) repack_kh_xcd16_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
     else repack_kh_xcd_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
 }
 
@@ -1263,6 +1732,7 @@ hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a) {
     for (int l = 0; l < a.n; ++l) if (a.xf[l] != nullptr && !(a.Hp == XH || a.Hp == PH)) return hipErrorInvalidValue;
     const long long total = (long long)a.Hp * 4 * a.Hp / 4;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
+    if (a.bx3 && a.Hp != XH) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_repack_kh_all, dim3(blocks, 2 * a.n), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -1279,20 +1749,26 @@ static int xcd_row_groups(int B, int Hp = XH) {
 bool lstm_xcd_supported(int B, int Hp) { return (Hp == XH || Hp == PH) && B >= 1 && xcd_row_groups(B, Hp) <= 4; }
 int lstm_xcd_max_rows(int Hp) { return Hp == PH ? 16 * PGRP : (Hp == XH ? 16 * NXCD : 0); }
 
-long long lstm_xcd_hx_floats(int B, int T, int Hp) {
+long long lstm_xcd_hx_floats(int B, int T, int Hp, bool bx3) {
     if (Hp == PH) return (long long)(T + 1) * PGRP * 4 * xcd_row_groups(B, Hp) * PNQ * 64 * 4;
+    if (bx3) return (long long)(T + 1) * (4 * xcd_row_groups(B)) * NXCD * HXW16 * 4;      // rows x XCDs x 3 KiB, see k_lstm_fwd_xcd16
     return (long long)(T + 1) * NXCD * 4 * xcd_row_groups(B) * 2 * 64 * 4;
 }
 long long lstm_xcd_inbox_floats(int B, int Hp) {
     if (Hp == PH) return 2LL * PGRP * PCU * xcd_row_groups(B, Hp) * PCU * 16 * 4;
     return 2LL * NXCD * NCU * NCU * xcd_row_groups(B) * 16 * 4;
 }
-long long lstm_xcd_weight_floats(int Hp) { return (long long)Hp * 4 * Hp; }
+long long lstm_xcd_weight_floats(int Hp, bool bx3) { return (bx3 && Hp == XH) ? (long long)Hp * 4 * Hp * 3 / 2 : (long long)Hp * 4 * Hp; }   // three bf16 planes
+// The bf16-split kernels pay 1536 MFMA cycles per step for any row count, the fp32 ones 1024 per row group, and the bf16 hand-off
+// is 1.5x the bytes in 3x the load instructions: measured (profiles/r03_xcd16_probe3.log, us per step forward / backward)
+// B = 20: 2.68 / 2.17 against 1.81 / 1.64, B = 45: 2.57 / 2.35 against 2.17 / 2.38, B = 100: 2.98 / 3.22 against 3.86 / 4.35.
+bool lstm_xcd_bx3_pays(int B, int Hp) { return Hp == XH && xcd_row_groups(B) >= 3; }
 // Rows per XCD that fill the row groups the 8-way split already pays for: the batch then sits on the first
 // ceil(B / rows) XCDs and the others are free for another stream's GEMMs (B = 45: 8 rows on 6 XCDs instead of 6 on 8).
 int lstm_xcd_packed_rows(int B) { return 4 * xcd_row_groups(B); }
-hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp) {
+hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp, bool bx3) {
     if (Hp == PH) hipLaunchKernelGGL(k_repack_kh_pair, dim3(2048), dim3(256), 0, s, Kh, fwd, bwd);
+    else if (bx3) hipLaunchKernelGGL(k_repack_kh_xcd16, dim3(512), dim3(256), 0, s, Kh, fwd, bwd);
     else hipLaunchKernelGGL(k_repack_kh_xcd, dim3(1024), dim3(256), 0, s, Kh, fwd, bwd);
     return hipGetLastError();
 }
@@ -1337,6 +1813,20 @@ hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {
         }
         return hipGetLastError();
     }
+    if (a.bx3) {
+        if (a.prof) {
+            if (xcd_row_groups(a.B) != 2) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((k_lstm_fwd_xcd16<2, true>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+        switch (xcd_row_groups(a.B)) {              // = the row count lstm_xcd_hx_floats sized (and the caller filled) the buffer for
+            case 1: hipLaunchKernelGGL((k_lstm_fwd_xcd16<1, false>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((k_lstm_fwd_xcd16<2, false>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((k_lstm_fwd_xcd16<4, false>), grid, block, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (a.prof) {
         if (xcd_row_groups(a.B) != 2) return hipErrorInvalidValue;
         hipLaunchKernelGGL((k_lstm_fwd_xcd<2, true>), grid, block, 0, s, a);
@@ -1370,6 +1860,20 @@ hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a) {
             case 2: hipLaunchKernelGGL((k_lstm_bwd_pair<2>), grid, block, 0, s, a); break;
             case 3: hipLaunchKernelGGL((k_lstm_bwd_pair<3>), grid, block, 0, s, a); break;
             case 4: hipLaunchKernelGGL((k_lstm_bwd_pair<4>), grid, block, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    if (a.bx3) {
+        if (a.prof) {
+            if (xcd_row_groups(a.B) != 2) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((k_lstm_bwd_xcd16<2, true>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+        switch (xcd_row_groups(a.B)) {
+            case 1: hipLaunchKernelGGL((k_lstm_bwd_xcd16<1, false>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((k_lstm_bwd_xcd16<2, false>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((k_lstm_bwd_xcd16<4, false>), grid, block, 0, s, a); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

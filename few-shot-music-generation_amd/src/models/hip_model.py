@@ -41,9 +41,14 @@ class HIPModel(BaseModel):
         # a dedicated (non-default) torch stream: its handle is a real hipStream_t the library can launch
         # on, and collectives issued under `stream_context()` are ordered with the library's kernels
         self._stream = torch.cuda.Stream(device=self._device)
+        # sequences per training episode, when the merged YAMLs say (N-way x (K + Q)): sizes the activations up front and
+        # picks the recurrent kernels built for that row count (fsmg_config.max_sequences)
+        max_sequences = int(config.get('max_sequences', 0))
+        if max_sequences == 0 and all(k in config for k in ('batch_size', 'support_size', 'query_size')):
+            max_sequences = int(config['batch_size']) * (int(config['support_size']) + int(config['query_size']))
         self._model = FsmgModel(config, device=self._device, stream=self._stream.cuda_stream,
                                 state_arena=base + pad, state_arena_bytes=nbytes,
-                                max_sequences=int(config.get('max_sequences', 0)),
+                                max_sequences=max_sequences,
                                 clip_norm_mode=config.get('clip_norm_mode', 'tf1_slices'),
                                 use_graph=bool(config.get('use_graph', True)))
         gptr, gcount = self._model.grad_buffer()

@@ -76,7 +76,9 @@ typedef struct fsmg_config {
     float n_decay;           /* config['n_decay'] (lr halves every n_decay steps, continuous) */
     int32_t clip_norm_mode;  /* FSMG_CLIP_TF1_SLICES (reference behaviour) or FSMG_CLIP_DENSE */
     int32_t device;          /* HIP device ordinal                                            */
-    int32_t max_sequences;   /* initial activation capacity in sequences (N*(K+Q)); grows on demand */
+    int32_t max_sequences;   /* sequences per training episode (N*(K+Q)): initial activation capacity (grows on demand)
+                                and the row count the recurrent kernel family is chosen for (hidden 512, > 64 rows: the
+                                bf16-split XCD-local kernels); 0 = 45 */
     int32_t use_graph;       /* 1: replay the per-timestep launch chains as hipGraphs         */
     void* stream;            /* optional caller hipStream_t; NULL = the library creates one   */
     void* state_arena;       /* optional caller-owned DEVICE memory for params+grads+Adam state
@@ -244,7 +246,8 @@ int fsmg_get_stats(fsmg_handle h, fsmg_stats* out);
 /* copy an internal activation buffer of the last forward to the host, float32:
  *   "h<l>" [T+1,B,Hp] (index 0 = zero state), "c<l>" [T+1,B,Hp], "gates<l>" [T,B,4Hp] (packed
  *   gate order, holds dz after a backward), "logits" [T*B,V1p], "lse" [T*B], "ce" [T*B];
- *   rows are TIME-major (row = t*B + b).  count = elements to copy (<= buffer size). */
+ *   rows are TIME-major (row = t*B + b).  count = elements to copy (<= buffer size).
+ *   "xcd_bx3" [1]: 1.0 when the handle runs the bf16-split XCD-local recurrent kernels (hidden 512, created for > 64 rows) */
 int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count);
 /* padded sizes: writes Ep, Hp, V1p, last B, T */
 int fsmg_debug_dims(fsmg_handle h, int32_t dims[5]);

@@ -65,7 +65,10 @@ def _episode(cfg, N, K, Q, seed=0, realistic=True):
 def test_forward_backward_every_tensor(over, N, K, Q, gemm_kind):
     cfg = small_config(**over)
     sup, qry = _episode(cfg, N, K, Q, seed=3)
-    model = new_model(cfg)
+    model = new_model(cfg, max_sequences=N * (K + Q))          # as the plugin does from the task YAML: picks the kernel family
+    # hidden 512 with > 64 rows runs the bf16-split XCD-local recurrence (k_lstm_*_xcd16), every other shape the fp32 one
+    forced = os.environ.get('FSMG_XCD_BX3')
+    assert bool(model.debug_read('xcd_bx3', 1)[0]) == (cfg['hidden_size'] == 512 and (N * (K + Q) > 64 if forced is None else forced == '1'))
     params = f64_params(model)
     loss, cache, grads, aux = cached_oracle_step(('shape', repr(sorted(over.items())), N, K, Q), params, sup, qry, cfg)
     B, T = N * (K + Q), cfg['max_len']
@@ -588,7 +591,7 @@ def test_full_size_properties(name):
     over, N, K, Q = FULL[name]
     cfg = small_config(**over)
     (sup, qry), (sup2, qry2) = O.synthetic_episodes(2, N, K, Q, cfg['max_len'], cfg['input_size'], seed=21)
-    model = new_model(cfg)
+    model = new_model(cfg, max_sequences=N * (K + Q))
     nll0 = model.eval_step(qry)
     assert abs(nll0 - np.log(cfg['input_size'] + 1)) < 0.02
     want = O.eval_step(f64_params(model), qry, cfg)
@@ -753,7 +756,7 @@ def test_full_size_gradients_match_oracle(name, gemm_kind):
     over, N, K, Q = FULL[name]
     cfg = small_config(**over)
     (sup, qry), = O.synthetic_episodes(1, N, K, Q, cfg['max_len'], cfg['input_size'], seed=8, realistic=True)
-    model = new_model(cfg)
+    model = new_model(cfg, max_sequences=N * (K + Q))          # cfg-D (100 rows): the bf16-split XCD-local recurrence
     params = f64_params(model)
     loss, cache, grads, aux = cached_oracle_step(('full', name), params, sup, qry, cfg)
     params = {k: v.copy() for k, v in params.items()}
