@@ -553,7 +553,7 @@ bool use_ws_gemm(fsmg_model* h, int amode, int bmode, const GemmArgs& g, const L
 // FSMG_GEMM_H=0 / 2: never / wherever it can run (A/B runs).
 bool use_h_gemm(fsmg_model* h, int amode, int bmode, const GemmArgs& g, const Lane& ln) {
     static const int mode = std::getenv("FSMG_GEMM_H") ? std::atoi(std::getenv("FSMG_GEMM_H")) : 1;
-    if (!h->bx3 || mode == 0 || ln.lds_pad != 0 || g.xcd_first != 0 || g.ce_part != nullptr) return false;
+    if (!h->bx3 || mode == 0 || ln.lds_pad != 0 || g.xcd_first != 0) return false;
     if (amode == OP_XC && g.gather != nullptr) return false;
     if (mode == 2) return true;
     // measured in the cfg-B step (profiles/r03p_bench_h*.json, ms per launch incl. the slab sums, without / with): dH 0.349 /
@@ -777,7 +777,8 @@ int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t 
         ScopedTimer tm(h, "gemm_logits");
         g.ce_part = h->ce_part + (size_t)r0 * h->ce_nparts; g.ce_tgt = h->Y + r0; g.ce_tgt_logit = h->tgt_logit + r0;
         g.ce_nvocab = h->V1; g.bx3 = h->bx3;
-        if (use_ws_gemm(h, OP_KC, OP_XC, g, ln)) { g.bx3 = 2; g.group_m = 4; }
+        if (use_h_gemm(h, OP_KC, OP_XC, g, ln)) g.bx3 = 3;                  // (the softmax partials are per 64-column half of a 128-column tile in every kernel)
+        else if (use_ws_gemm(h, OP_KC, OP_XC, g, ln)) { g.bx3 = 2; g.group_m = 4; }
         HIPCK(h, launch_gemm(ln.s, OP_KC, OP_XC, g, ln.lds_pad));          // K = Hp: never split
         HIPCK(h, launch_ce_combine(ln.s, h->ce_part + (size_t)r0 * h->ce_nparts, h->ce_nparts,
                                    h->tgt_logit + r0, (int)m, h->ce + r0));

@@ -1224,6 +1224,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     } else
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {    // the wave's 128 x 64 tile as two 64 x 64 halves
+        // a 256-column tile may reach past the last 128-column tile of N: nothing to store there, and the forward-only cross
+        // entropy has no partial slot for it (a write would land in the next row's slots)
+        if ((n0 + wn * 64) / 128 >= (g.N + 127) / 128) break;
         f32x16 (&sub)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * h2][0]);
         store_tile_at(g, sub, ep, z, m0 + wm * 128 + h2 * 64, n0 + wn * 64, (n0 + wn * 64) / 128, (g.N + 127) / 128, wn & 1, lane);
     }
