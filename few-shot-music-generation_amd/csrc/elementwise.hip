@@ -4,6 +4,7 @@
 // __shfl_xor over 64 lanes.
 #include <algorithm>
 #include "fsmg_kernels.h"
+#include <cstdlib>
 
 namespace fsmg {
 namespace {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ logit
 // exp() is evaluated once per element, and the gradient is written from registers -- the three-pass kernel above
 // re-reads 40 KB rows that have long left the L2 when thousands of rows are in flight (0.141 -> see DESIGN.md).
 // softmax = exp(x - max) / sum instead of exp(x - lse): the same value to ~1 ulp.
-template <int NV>
+template <int NV, bool NT>
 __global__ __launch_bounds__(256) void k_ce_rows_reg(const float* __restrict__ logits, int ld, int n_vocab,
                                                      const int* __restrict__ tgt, float* __restrict__ lse,
                                                      float* __restrict__ ce, float* __restrict__ dlogits, float inv_n) {
@@ -211,8 +212,12 @@ __global__ __launch_bounds__(256) void k_ce_rows_reg(const float* __restrict__ l
             d.y = x[i].y * scale - (v + 1 == t ? inv_n : 0.0f);
             d.z = x[i].z * scale - (v + 2 == t ? inv_n : 0.0f);
             d.w = x[i].w * scale - (v + 3 == t ? inv_n : 0.0f);
-            __builtin_nontemporal_store(d.x, drow + v); __builtin_nontemporal_store(d.y, drow + v + 1);
-            __builtin_nontemporal_store(d.z, drow + v + 2); __builtin_nontemporal_store(d.w, drow + v + 3);
+            if (NT) {
+                __builtin_nontemporal_store(d.x, drow + v); __builtin_nontemporal_store(d.y, drow + v + 1);
+                __builtin_nontemporal_store(d.z, drow + v + 2); __builtin_nontemporal_store(d.w, drow + v + 3);
+            } else {
+                *reinterpret_cast<float4*>(drow + v) = d;
+            }
         }
     }
 }
@@ -532,8 +537,14 @@ hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, c
 hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt,
                           float* lse, float* ce, float* dlogits, float inv_n) {
     if (rows <= 0) return hipSuccess;
-    if (ld <= 6 * 1024) hipLaunchKernelGGL(k_ce_rows_reg<6>, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
-    else if (ld <= 12 * 1024) hipLaunchKernelGGL(k_ce_rows_reg<12>, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+    static const int nt = std::getenv("FSMG_DLOGITS_NT") ? std::atoi(std::getenv("FSMG_DLOGITS_NT")) : 1;      // A/B: non-temporal dlogits stores
+    if (ld <= 6 * 1024) {
+        if (nt) hipLaunchKernelGGL((k_ce_rows_reg<6, true>), dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+        else hipLaunchKernelGGL((k_ce_rows_reg<6, false>), dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+    } else if (ld <= 12 * 1024) {
+        if (nt) hipLaunchKernelGGL((k_ce_rows_reg<12, true>), dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+        else hipLaunchKernelGGL((k_ce_rows_reg<12, false>), dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+    }
     else hipLaunchKernelGGL(k_ce_rows, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
     return hipGetLastError();
 }

@@ -757,7 +757,8 @@ GemmArgs logits_args(fsmg_model* h, int B, int t0, int t1) {
     g.A = h->Hs[h->L - 1] + (size_t)B * Hp + (size_t)r0 * Hp; g.lda = Hp;
     g.B = h->P + h->off_w; g.ldb = h->V1p;
     g.C = h->logits + (size_t)r0 * h->V1p; g.ldc = h->V1p; g.M = (int)m; g.N = h->V1p; g.K = Hp;
-    g.bias = h->P + h->off_d; g.ksplit = 1; g.nt_store = 1;
+    static const int nt = std::getenv("FSMG_LOGITS_NT") ? std::atoi(std::getenv("FSMG_LOGITS_NT")) : 1;         // A/B: non-temporal logits stores
+    g.bias = h->P + h->off_d; g.ksplit = 1; g.nt_store = nt;
     return g;
 }
 int ce_rows(fsmg_model* h, hipStream_t s, int B, int t0, int t1, int64_t rows_total) {

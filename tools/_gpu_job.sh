@@ -1,3 +1,12 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r03s_pytest_full.log 2>&1; grep -n "passed\|failed\|Error\|assert" gpurun_out/r03s_pytest_full.log | head -8
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp
+for c in "1 1" "1 0" "0 0"; do
+  set -- $c
+  rm -rf /tmp/p_$1$2; FSMG_LOGITS_NT=$1 FSMG_DLOGITS_NT=$2 rocprofv3 --kernel-trace --stats -d /tmp/p_$1$2 -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > $GRAFT_REPO_ROOT/gpurun_out/r03t_ntp_$1$2.json
+  python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/p_$1$2 -name "*.db" | head -1) > $GRAFT_REPO_ROOT/gpurun_out/r03t_ntp_$1$2_stats.txt 2>&1
+  echo "== logits_nt=$1 dlogits_nt=$2"; grep "k_ce_rows_reg\|k_gemm_bx3h" $GRAFT_REPO_ROOT/gpurun_out/r03t_ntp_$1$2_stats.txt | cut -c1-60,100-160
+  python - <<PY
+import json
+d=json.load(open('$GRAFT_REPO_ROOT/gpurun_out/r03t_ntp_$1$2.json')); print(round(d['value'],1))
+PY
+done
