@@ -1739,7 +1739,16 @@ hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a) {
 
 // row groups of 4 rows per weight copy: hidden 512 -> 8 copies (one per XCD), 3 is padded to 4 (the lane mapping of
 // k_lstm_bwd_xcd needs a divisor of 4); hidden 1024 -> 4 copies (one per XCD pair), 1 .. 4
-static int xcd_row_groups(int B, int Hp = XH) {
+// row groups of a launch whose rows are packed `rpx` per XCD (0: spread over all eight): the bf16-split kernels take up to 16
+// rows per XCD at the same MFMA cost, so a batch may sit on fewer XCDs than the 8-way split would use
+static int xcd_row_groups(int B, int Hp = 512);
+static int xcd_row_groups_packed(int B, int rpx) {
+    const int rg = xcd_row_groups(B, XH);
+    if (rpx <= 0) return rg;
+    const int need = (rpx + 3) / 4;
+    return std::max(rg, need == 3 ? 4 : need);
+}
+static int xcd_row_groups(int B, int Hp) {
     if (Hp == PH) return ((B + PGRP - 1) / PGRP + 3) / 4;
     const int rpx = (B + NXCD - 1) / NXCD;
     const int rg = (rpx + 3) / 4;
@@ -1819,7 +1828,7 @@ hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {
             hipLaunchKernelGGL((k_lstm_fwd_xcd16<2, true>), grid, block, 0, s, a);
             return hipGetLastError();
         }
-        switch (xcd_row_groups(a.B)) {              // = the row count lstm_xcd_hx_floats sized (and the caller filled) the buffer for
+        switch (xcd_row_groups_packed(a.B, a.rpx)) {     // = the row count lstm_xcd_hx_floats sized (and the caller filled) the buffer for
             case 1: hipLaunchKernelGGL((k_lstm_fwd_xcd16<1, false>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((k_lstm_fwd_xcd16<2, false>), grid, block, 0, s, a); break;
             case 4: hipLaunchKernelGGL((k_lstm_fwd_xcd16<4, false>), grid, block, 0, s, a); break;
@@ -1870,7 +1879,7 @@ hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a) {
             hipLaunchKernelGGL((k_lstm_bwd_xcd16<2, true>), grid, block, 0, s, a);
             return hipGetLastError();
         }
-        switch (xcd_row_groups(a.B)) {
+        switch (xcd_row_groups_packed(a.B, a.rpx)) {
             case 1: hipLaunchKernelGGL((k_lstm_bwd_xcd16<1, false>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((k_lstm_bwd_xcd16<2, false>), grid, block, 0, s, a); break;
             case 4: hipLaunchKernelGGL((k_lstm_bwd_xcd16<4, false>), grid, block, 0, s, a); break;

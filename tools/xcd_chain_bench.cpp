@@ -243,6 +243,7 @@ struct Dev {
 
 static int g_variant = 0;
 static bool g_bx3 = false;
+static int g_rpx = 0;          // RPX=n: rows per XCD (packs the batch on the first ceil(B / n) XCDs); buffers sized for 128 rows then
 static int run_case(int B, int Tcheck, int Ttime, int H) {
     const int G4 = 4 * H;
     Problem p; p.B = B; p.T = Tcheck; p.H = H; p.G4 = G4;
@@ -261,7 +262,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
     Dev d;
     const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
     CK(hipMalloc(&d.Kh, 4ull * H * G4)); CK(hipMalloc(&d.KhXf, 4ull * lstm_xcd_weight_floats(H, g_bx3 && H == 512))); CK(hipMalloc(&d.KhXb, 4ull * lstm_xcd_weight_floats(H, g_bx3 && H == 512))); CK(hipMalloc(&d.KhF, 8ull * H * G4));
-    CK(hipMalloc(&d.HX, 4ull * lstm_xcd_hx_floats(B, Tmax, H, g_bx3 && H == 512))); CK(hipMalloc(&d.inboxX, 4ull * lstm_xcd_inbox_floats(B, H)));
+    CK(hipMalloc(&d.HX, 4ull * lstm_xcd_hx_floats((g_rpx && H == 512) ? 128 : B, Tmax, H, g_bx3 && H == 512))); CK(hipMalloc(&d.inboxX, 4ull * lstm_xcd_inbox_floats((g_rpx && H == 512) ? 128 : B, H)));
     CK(hipMalloc(&d.Z, 4ull * Tmax * B * G4)); CK(hipMalloc(&d.Zsave, 4ull * Tmax * B * G4));
     CK(hipMalloc(&d.Cs, 4ull * (Tmax + 1) * B * H)); CK(hipMalloc(&d.Hs, 4ull * (Tmax + 1) * B * H));
     CK(hipMalloc(&d.dC, 4ull * B * H)); CK(hipMalloc(&d.dH, 4ull * Tmax * B * H));
@@ -280,25 +281,25 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
     auto fwd_xcd = [&](int T, int nchunk) {
         CK(hipMemcpyAsync(d.Z, Zin.data(), 4ull * T * B * G4, hipMemcpyHostToDevice, s));
         CK(hipMemsetAsync(d.Cs, 0, 4ull * B * H, s)); CK(hipMemsetAsync(d.Hs, 0, 4ull * B * H, s));
-        const size_t step_f = (size_t)lstm_xcd_hx_floats(B, 0, H, g_bx3 && H == 512);
+        const size_t step_f = (size_t)lstm_xcd_hx_floats((g_rpx && H == 512) ? 128 : B, 0, H, g_bx3 && H == 512);
         CK(hipMemsetAsync(d.HX, 0, 4 * step_f, s));
         CK(hipMemsetAsync(d.HX + step_f, 0xFF, 4 * step_f * T, s));
         CK(hipMemsetAsync(d.tickets, 0, 64 * 4, s));
         for (int c = 0; c < nchunk; ++c) {
             LstmFwdXcdArgs a{};
             a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0;
+            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
             CK(launch_lstm_fwd_xcd(s, a));
         }
     };
     auto bwd_xcd = [&](int T, int nchunk) {
         CK(hipMemsetAsync(d.dC, 0, 4ull * B * H, s));
-        CK(hipMemsetAsync(d.inboxX, 0xFF, 4ull * lstm_xcd_inbox_floats(B, H), s));
+        CK(hipMemsetAsync(d.inboxX, 0xFF, 4ull * lstm_xcd_inbox_floats((g_rpx && H == 512) ? 128 : B, H), s));
         CK(hipMemsetAsync(d.tickets, 0, 64 * 4, s));
         for (int c = nchunk - 1; c >= 0; --c) {
             LstmBwdXcdArgs a{};
             a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0;
+            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
             CK(launch_lstm_bwd_xcd(s, a));
         }
     };
@@ -340,7 +341,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                 for (int c = 0; c < nchunk; ++c) {
                     LstmFwdXcdArgs a{};
                     a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0;
+                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     CK(launch_lstm_fwd_xcd(s, a));
                 }
                 CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
@@ -350,7 +351,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                 for (int c = nchunk - 1; c >= 0; --c) {
                     LstmBwdXcdArgs a{};
                     a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0;
+                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     CK(launch_lstm_bwd_xcd(s, a));
                 }
                 CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
@@ -370,13 +371,13 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                     fwd_xcd(T, 0);
                     CK(hipEventRecord(e0, s));
                     { LstmFwdXcdArgs a{}; a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; CK(launch_lstm_fwd_xcd(s, a)); }
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0; CK(launch_lstm_fwd_xcd(s, a)); }
                     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best_f = std::min(best_f, ms);
                     bwd_xcd(T, 0);
                     CK(hipEventRecord(e0, s));
                     { LstmBwdXcdArgs a{}; a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; CK(launch_lstm_bwd_xcd(s, a)); }
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0; CK(launch_lstm_bwd_xcd(s, a)); }
                     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                     CK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
                 }
@@ -393,12 +394,12 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                 if (dir == 0) {
                     fwd_xcd(T, 0);
                     LstmFwdXcdArgs a{}; a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = 96; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = 96; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     if (launch_lstm_fwd_xcd(s, a) != hipSuccess) continue;
                 } else {
                     bwd_xcd(T, 0);
                     LstmBwdXcdArgs a{}; a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = 96; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = 96; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     if (launch_lstm_bwd_xcd(s, a) != hipSuccess) continue;
                 }
                 CK(hipStreamSynchronize(s));
@@ -418,13 +419,13 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                     fwd_xcd(T, 0);
                     LstmFwdXcdArgs a{};
                     a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     CK(launch_lstm_fwd_xcd(s, a));
                 } else {
                     bwd_xcd(T, 0);
                     LstmBwdXcdArgs a{};
                     a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     CK(launch_lstm_bwd_xcd(s, a));
                 }
                 CK(hipStreamSynchronize(s));
@@ -484,7 +485,9 @@ int main(int argc, char** argv) {
     if (rc) { printf("MFMA layout assumption wrong: kernels not run\n"); return 1; }
     const int only_pipe = getenv("PIPE") ? atoi(getenv("PIPE")) : -1;
     g_variant = getenv("VARIANT") ? atoi(getenv("VARIANT")) : 0;
-    g_bx3 = getenv("BX3") && atoi(getenv("BX3")) != 0;      // hidden 512: the bf16-split kernels (k_lstm_*_xcd16)
+    g_bx3 = getenv("BX3") && atoi(getenv("BX3")) != 0;
+    g_rpx = getenv("RPX") ? atoi(getenv("RPX")) : 0;
+    if (g_rpx && (!g_bx3 || g_rpx < 13 || g_rpx > 16)) { printf("RPX needs BX3=1 and 13..16 rows per XCD (the buffers are laid out for four row groups then)\n"); return 2; }      // hidden 512: the bf16-split kernels (k_lstm_*_xcd16)
     (void)only_pipe;
     const int only_h = getenv("HID") ? atoi(getenv("HID")) : 0;
     if (only_h != 1024) {
