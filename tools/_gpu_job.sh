@@ -1,7 +1,9 @@
+# scratch job script for `gpurun -- 'bash tools/_gpu_job.sh'` (overwritten per experiment): the round-end checks
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03_xcd16_probe5.log; : > $O
-for r in 15 12 8; do
-echo "=== BX3=1 RPX=$r" >> $O
-BX3=1 RPX=$r HID=512 timeout 200 tools/xcd_chain_bench.bin >> $O 2>&1; echo "rc $?" >> $O
-done
-grep "===\|vs CPU\|1 launch\|rc " $O | grep -v "column-split" | cut -c1-230
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r03s_pytest_final.log 2>&1; grep -n "passed\|failed\|Error\|assert" gpurun_out/r03s_pytest_final.log | head -8
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+python bench.py --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > gpurun_out/r03s_bench_final.json
+python - <<PY
+import json
+d=json.load(open('gpurun_out/r03s_bench_final.json')); print('bench', round(d['value'],1), round(d['ms_per_step'],4), d['guard'], round(d['roofline']['frac'],4))
+PY
