@@ -23,6 +23,18 @@ from models.base_model import BaseModel
 MAX_TO_KEEP = 10
 
 
+def episode_sequences(config):
+    """Sequences per training episode for fsmg_config.max_sequences: the explicit `max_sequences` key, else N x (K + Q) from the
+    merged YAMLs (model: batch_size = N artists per episode, task: support_size = K, query_size = Q; reference
+    src/data/episode.py:36-60 draws exactly that many songs), else 0 = the library's default (45)."""
+    explicit = int(config.get('max_sequences', 0) or 0)
+    if explicit > 0:
+        return explicit
+    if all(k in config for k in ('batch_size', 'support_size', 'query_size')):
+        return int(config['batch_size']) * (int(config['support_size']) + int(config['query_size']))
+    return 0
+
+
 class HIPModel(BaseModel):
     def __init__(self, config):
         super(HIPModel, self).__init__(config)
@@ -43,9 +55,7 @@ class HIPModel(BaseModel):
         self._stream = torch.cuda.Stream(device=self._device)
         # sequences per training episode, when the merged YAMLs say (N-way x (K + Q)): sizes the activations up front and
         # picks the recurrent kernels built for that row count (fsmg_config.max_sequences)
-        max_sequences = int(config.get('max_sequences', 0))
-        if max_sequences == 0 and all(k in config for k in ('batch_size', 'support_size', 'query_size')):
-            max_sequences = int(config['batch_size']) * (int(config['support_size']) + int(config['query_size']))
+        max_sequences = episode_sequences(config)
         self._model = FsmgModel(config, device=self._device, stream=self._stream.cuda_stream,
                                 state_arena=base + pad, state_arena_bytes=nbytes,
                                 max_sequences=max_sequences,
