@@ -1090,7 +1090,10 @@ __global__ __launch_bounds__(256 * (MT + 1), MT == 1 ? 2 : 1) void k_gemm_bx3w(c
 // waves 0-3 read their fragments, multiply, then split and write their share of the next tile; waves 4-7 split and write
 // first (their loads were issued a whole iteration earlier), then read and multiply.  Same LDS image per 128 rows / columns,
 // k order and term order as k_gemm_bx3: the same bits for the same K split.
-template <int AMODE, int BMODE, bool PROF = false, int BUFM = 0>
+// QUEUE (GemmArgs::xcd_first != 0): the tile comes from the work queue of k_gemm_queue instead of blockIdx -- a restricted launch
+// (xcd_first > 0) lets only blocks on XCDs >= xcd_first draw, only items below work_limit and only while *stop == 0; the clean-up
+// launch (xcd_first < 0) takes what nobody claimed.  Which block computes an item never changes the item.
+template <int AMODE, int BMODE, bool PROF = false, int BUFM = 0, bool QUEUE = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     constexpr int XT = 256;
     constexpr int PLANE = 2 * XT * 16, OPER = 3 * PLANE, STAGE = 2 * OPER;            // 8 KiB, 24 KiB, 48 KiB
@@ -1105,9 +1108,35 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     const bool late = wave >= 4;                          // order of the k tile, see above
     const int l31 = lane & 31, khalf = lane >> 5;
     const int tilesM = (g.M + XT - 1) / XT, tilesN = (g.N + XT - 1) / XT;
-    const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
-    int tm, tn; tile_coords(bid, tilesM, tilesN, g.group_m, tm, tn);
-    const int z = blockIdx.y;
+    int tm, tn, z;
+    if (QUEUE) {
+        __shared__ int s_item;
+        const int total = tilesM * tilesN * (g.ksplit > 1 ? g.ksplit : 1);
+        if (g.xcd_first > 0) {
+            int xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            if ((xcc & 7) < g.xcd_first) return;
+        }
+        if (tid == 0) {
+            int item = -1;
+            if (g.xcd_first < 0) {
+                const int j = atomicAdd(g.work + 1, 1);
+                if (j < total && atomicCAS(g.claim + j, 0, 1) == 0) item = j;
+            } else if (__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+                const int j = atomicAdd(g.work, 1);
+                if (j < min(g.work_limit, total) && atomicCAS(g.claim + j, 0, 1) == 0) item = j;
+            }
+            s_item = item;
+        }
+        __syncthreads();
+        const int item = s_item;
+        if (item < 0) return;
+        tm = (item / tilesN) % tilesM; tn = item % tilesN; z = item / (tilesM * tilesN);
+    } else {
+        const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
+        tile_coords(bid, tilesM, tilesN, g.group_m, tm, tn);
+        z = blockIdx.y;
+    }
     const int m0 = tm * XT, n0 = tn * XT;
     unsigned long long pacc[5] = {0, 0, 0, 0, 0}, plast = 0, p_entry = 0, p_loop = 0;
     if (PROF && (g.dbg & 16) && blockIdx.x < 256 && blockIdx.y == 0) {      // experiment: first-round blocks start staggered
@@ -1246,6 +1275,21 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
 template <int AMODE, int BMODE>
 hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    if (g.xcd_first != 0 && g.bx3 == 3) {      // work-queue launch of the 256 x 256-tile kernel (one block per CU)
+        if (g.work == nullptr || g.claim == nullptr || (g.xcd_first > 0 && g.stop == nullptr) || g.gather != nullptr || g.prof != nullptr) return hipErrorInvalidValue;
+        const long long a_b = 4LL * g.lda * (AMODE == OP_KC ? g.M : g.K), b_b = 4LL * g.ldb * (BMODE == OP_KC ? g.N : g.K);
+        if (a_b >= 0xfffff000LL || b_b >= 0xfffff000LL) return hipErrorInvalidValue;
+        const int total = ((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.ksplit > 1 ? g.ksplit : 1);
+        const int lim = g.work_limit < total ? g.work_limit : total;
+        const int blocks = g.xcd_first > 0 ? (int)(((long long)lim * 8 + 7 - g.xcd_first) / (8 - g.xcd_first)) + 64 : total;
+        const bool a_dma = AMODE != OP_XC || (g.lda % 4 == 0 && g.M % 4 == 0 && ((uintptr_t)g.A & 15) == 0);
+        const bool b_dma = BMODE != OP_XC || (g.ldb % 4 == 0 && g.N % 4 == 0 && ((uintptr_t)g.B & 15) == 0);
+        if constexpr (AMODE == OP_XC && BMODE == OP_XC) {
+            if (a_dma && b_dma) { hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 3, true>), dim3(blocks), dim3(512), 0, s, g); return hipGetLastError(); }
+        }
+        hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 2, true>), dim3(blocks), dim3(512), 0, s, g);
+        return hipGetLastError();
+    }
     if (g.xcd_first != 0) {             // work-queue launch: one resident set of blocks (4 per CU), see k_gemm_queue
         if (g.work == nullptr || g.claim == nullptr || (g.xcd_first > 0 && g.stop == nullptr) || (AMODE == OP_XC && g.gather != nullptr)) return hipErrorInvalidValue;
         const int total = tilesM * tilesN * (g.ksplit > 1 ? g.ksplit : 1);
