@@ -8,8 +8,8 @@ python $R/bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
 rm -rf /tmp/prof_st; rocprofv3 --kernel-trace --stats -d /tmp/prof_st -o st -- python $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprofv3.json
 python $R/tools/rocpd_stats.py $(find /tmp/prof_st -name "*.db" | head -1) > $O/${TAG}_bench_rocprofv3_kernel_stats.txt 2>&1
 python $R/tools/step_timeline.py $(find /tmp/prof_st -name "*.db" | head -1) 30 > $O/${TAG}_step_timeline.txt 2>&1
-# the hidden-1024 configurations (BASELINE.json configs[2], configs[4]): bench line, per-kernel statistics, device timeline
-for c in cfg-C cfg-E; do
+# the hidden-1024 configurations (BASELINE.json configs[2], configs[4]) and cfg-D (100 rows: the bf16-split XCD-local recurrence): bench line, per-kernel statistics, device timeline
+for c in cfg-C cfg-E cfg-D; do
   t=$(echo $c | tr -d '-')
   rm -rf /tmp/prof_$t; rocprofv3 --kernel-trace --stats -d /tmp/prof_$t -o st -- python $R/bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_${t}_bench_under_rocprofv3.json
   python $R/tools/rocpd_stats.py $(find /tmp/prof_$t -name "*.db" | head -1) > $O/${TAG}_${t}_bench_rocprofv3_kernel_stats.txt 2>&1
