@@ -7,7 +7,7 @@
 //      per step at T = 128 next to the column-split persistent kernels of lstm_step.hip; VARIANT=<XCD_* bits> selects the
 //      variant the correctness / timing / profile legs run (the variant sweep line always covers 16 / 32 / 48)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ifew-shot-music-generation_amd/csrc -Iinclude -c tools/xcd_chain_bench.cpp -o /tmp/xcb.o
-//        hipcc --offload-arch=gfx950 /tmp/xcb.o few-shot-music-generation_amd/build/lstm_xcd.o few-shot-music-generation_amd/build/lstm_step.o -o tools/xcd_chain_bench.bin
+//        hipcc --offload-arch=gfx950 /tmp/xcb.o few-shot-music-generation_amd/build/lstm_xcd.o few-shot-music-generation_amd/build/lstm_step.o few-shot-music-generation_amd/build/gemm.o -o tools/xcd_chain_bench.bin
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -16,6 +16,7 @@
 #include <cstring>
 #include <random>
 #include <vector>
+#include <chrono>
 #include "fsmg_kernels.h"
 
 using namespace fsmg;
@@ -362,6 +363,50 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                    B, H, nchunk, T, best_f, best_f * 1e3 / T, mflop * T / best_f / 1e6, mflop * T / best_f / 1e6 / 157.3 * 100, best_b, best_b * 1e3 / T,
                    mflop * T / best_b / 1e6, mflop * T / best_b / 1e6 / 157.3 * 100, e);
             CK(hipMemset(d.err, 0, 4));
+        }
+        if (getenv("CONC") && atoi(getenv("CONC")) && g_bx3 && g_rpx && H == 512 && B == 45) {
+            // CONC=1 (with BX3=1 RPX=15): the backward chain on XCDs 0-2 BESIDE cfg-B's dW GEMM (256 x 256-tile queue kernel,
+            // K split 6) confined to XCDs 3-7 on a second stream -- what the packed schedule of DESIGN.md section 4 would run
+            const int M = 512, N = 10016, K = 5760, S = 6;
+            float *A, *Bm, *slabs; int* ctl;
+            CK(hipMalloc(&A, 4ull * K * M)); CK(hipMalloc(&Bm, 4ull * K * N)); CK(hipMalloc(&slabs, 4ull * S * M * N)); CK(hipMalloc(&ctl, 4 * 65536));
+            CK(hipMemset(A, 0, 4ull * K * M)); CK(hipMemset(Bm, 0, 4ull * K * N));
+            hipStream_t s2; CK(hipStreamCreate(&s2));
+            hipEvent_t g0, g1, c0, c1; CK(hipEventCreate(&g0)); CK(hipEventCreate(&g1)); CK(hipEventCreate(&c0)); CK(hipEventCreate(&c1));
+            GemmArgs g{};
+            g.A = A; g.lda = M; g.B = Bm; g.ldb = N; g.C = slabs; g.ldc = N; g.M = M; g.N = N; g.K = K; g.ksplit = S; g.c_slab = (long long)M * N; g.bx3 = 3;
+            g.work = ctl; g.stop = ctl + 2; g.claim = ctl + 4; g.work_limit = 1 << 30;
+            auto chain = [&]() {
+                LstmBwdXcdArgs a{};
+                a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
+                a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = 32; a.Hp = H; a.bx3 = 1; a.rpx = g_rpx;
+                CK(launch_lstm_bwd_xcd(s, a));
+            };
+            for (int mode = 0; mode < 3; ++mode) {      // 0: chain alone, 1: confined GEMM alone, 2: both
+                float best_c = 1e9f, best_g = 1e9f, best_w = 1e9f;
+                for (int rep = 0; rep < 4; ++rep) {
+                    fwd_xcd(T, 1); bwd_xcd(T, 0);      // fresh forward state and resets
+                    CK(hipMemsetAsync(ctl, 0, 4 * 65536, s)); CK(hipStreamSynchronize(s));
+                    const auto w0 = std::chrono::steady_clock::now();
+                    if (mode != 1) { CK(hipEventRecord(c0, s)); chain(); CK(hipEventRecord(c1, s)); }
+                    if (mode != 0) {
+                        GemmArgs r1 = g; r1.xcd_first = 3;
+                        CK(hipEventRecord(g0, s2)); CK(launch_gemm(s2, OP_XC, OP_XC, r1, 0)); CK(hipEventRecord(g1, s2));
+                    }
+                    CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
+                    const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                    float ms;
+                    if (mode != 1) { CK(hipEventElapsedTime(&ms, c0, c1)); best_c = std::min(best_c, ms); }
+                    if (mode != 0) { CK(hipEventElapsedTime(&ms, g0, g1)); best_g = std::min(best_g, ms); }
+                    best_w = std::min(best_w, wall);
+                }
+                int claimed = 0; { std::vector<int> hc(65536); CK(hipMemcpy(hc.data(), ctl, 4 * 65536, hipMemcpyDeviceToHost)); for (int i = 4; i < 4 + 80 * S; ++i) claimed += hc[i] != 0; }
+                printf("[5] CONC mode %d (%s): chain %.3f ms (%.2f us/step)  confined dW (K split %d, %d of %d items) %.3f ms  wall %.3f ms  err_flag %d\n", mode,
+                       mode == 0 ? "chain alone" : mode == 1 ? "GEMM alone on XCDs 3-7" : "both", mode != 1 ? best_c : 0.f, mode != 1 ? best_c * 1e3 / T : 0.f, S, claimed, 80 * S,
+                       mode != 0 ? best_g : 0.f, best_w, read_err());
+                CK(hipMemset(d.err, 0, 4));
+            }
+            hipFree(A); hipFree(Bm); hipFree(slabs); hipFree(ctl);
         }
         {                    // variants (same results): 16 = XCD_DEFER_OUTPUTS, 32 = XCD_NO_POLL_SLEEP
             for (int dbg : {16, 32, 48, 96}) {
