@@ -369,7 +369,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
             // K split 6) confined to XCDs 3-7 on a second stream -- what the packed schedule of DESIGN.md section 4 would run
             const int M = 512, N = 10016, K = 5760, S = 6;
             float *A, *Bm, *slabs; int* ctl;
-            CK(hipMalloc(&A, 4ull * K * M)); CK(hipMalloc(&Bm, 4ull * K * N)); CK(hipMalloc(&slabs, 4ull * S * M * N)); CK(hipMalloc(&ctl, 4 * 65536));
+            CK(hipMalloc(&A, 4ull * K * M)); CK(hipMalloc(&Bm, 4ull * K * N)); CK(hipMalloc(&slabs, 4ull * std::max<size_t>((size_t)S * M * N, (size_t)5760 * N) /* dW's slabs, or the projection's output */)); CK(hipMalloc(&ctl, 4 * 65536));
             CK(hipMemset(A, 0, 4ull * K * M)); CK(hipMemset(Bm, 0, 4ull * K * N));
             hipStream_t s2; CK(hipStreamCreate(&s2));
             hipEvent_t g0, g1, c0, c1; CK(hipEventCreate(&g0)); CK(hipEventCreate(&g1)); CK(hipEventCreate(&c0)); CK(hipEventCreate(&c1));
@@ -405,6 +405,41 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                        mode == 0 ? "chain alone" : mode == 1 ? "GEMM alone on XCDs 3-7" : "both", mode != 1 ? best_c : 0.f, mode != 1 ? best_c * 1e3 / T : 0.f, S, claimed, 80 * S,
                        mode != 0 ? best_g : 0.f, best_w, read_err());
                 CK(hipMemset(d.err, 0, 4));
+            }
+            // the forward side: the packed forward chain beside the projection (M = T B rows, K = 512, one slab) confined to the
+            // free XCDs -- every tile on offer at once, i.e. interference and confined rate, not the dependency on h_t
+            {
+                GemmArgs p2{};
+                p2.A = A; p2.lda = 512; p2.B = Bm; p2.ldb = N; p2.C = slabs; p2.ldc = N; p2.M = 5760; p2.N = N; p2.K = 512; p2.ksplit = 1; p2.bx3 = 3; p2.nt_store = 1;
+                p2.work = ctl; p2.stop = ctl + 2; p2.claim = ctl + 4; p2.work_limit = 1 << 30;
+                for (int mode = 0; mode < 3; ++mode) {
+                    float best_c = 1e9f, best_g = 1e9f, best_w = 1e9f;
+                    for (int rep = 0; rep < 4; ++rep) {
+                        fwd_xcd(T, 0);                 // resets only
+                        CK(hipMemsetAsync(ctl, 0, 4 * 65536, s)); CK(hipStreamSynchronize(s));
+                        const auto w0 = std::chrono::steady_clock::now();
+                        if (mode != 1) {
+                            LstmFwdXcdArgs a{};
+                            a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
+                            a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = 32; a.Hp = H; a.bx3 = 1; a.rpx = g_rpx;
+                            CK(hipEventRecord(c0, s)); CK(launch_lstm_fwd_xcd(s, a)); CK(hipEventRecord(c1, s));
+                        }
+                        if (mode != 0) {
+                            GemmArgs r1 = p2; r1.xcd_first = 3;
+                            CK(hipEventRecord(g0, s2)); CK(launch_gemm(s2, OP_KC, OP_XC, r1, 0)); CK(hipEventRecord(g1, s2));
+                        }
+                        CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
+                        const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                        float ms;
+                        if (mode != 1) { CK(hipEventElapsedTime(&ms, c0, c1)); best_c = std::min(best_c, ms); }
+                        if (mode != 0) { CK(hipEventElapsedTime(&ms, g0, g1)); best_g = std::min(best_g, ms); }
+                        best_w = std::min(best_w, wall);
+                    }
+                    printf("[5] CONC forward mode %d (%s): chain %.3f ms (%.2f us/step)  confined projection (920 tiles) %.3f ms  wall %.3f ms  err_flag %d\n", mode,
+                           mode == 0 ? "chain alone" : mode == 1 ? "GEMM alone on XCDs 3-7" : "both", mode != 1 ? best_c : 0.f, mode != 1 ? best_c * 1e3 / T : 0.f,
+                           mode != 0 ? best_g : 0.f, best_w, read_err());
+                    CK(hipMemset(d.err, 0, 4));
+                }
             }
             hipFree(A); hipFree(Bm); hipFree(slabs); hipFree(ctl);
         }
