@@ -47,17 +47,91 @@ __global__ __launch_bounds__(256) void k_fill32_if(const int* __restrict__ cond,
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = word;
 }
 
-// several fills in one launch (blockIdx.y = range): a step needs ~10 small fills, each a ~5 us dispatch on its own
-__global__ __launch_bounds__(256) void k_fill_multi(const FillRanges r) {
-    const int k = blockIdx.y;
-    if (r.cond[k] != nullptr && *r.cond[k] == 0) return;
-    uint32_t* p = r.p[k];
-    const uint32_t word = r.word[k];
-    const long long n = r.n[k], n4 = n >> 2;
-    const uint4 w4 = make_uint4(word, word, word, word);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
-        reinterpret_cast<uint4*>(p)[i] = w4;
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = word;
+// several small memory passes in one launch (blockIdx.y = op): a step needs ~10 fills and up to five split-K slab sums, each a
+// ~5 us dispatch on its own.  Op kinds: FILL -- 32-bit pattern, optionally only when *cond != 0; REDUCE -- out[i] = sum_z
+// slabs[z][i] in slab order (deterministic split-K), optionally with the squared-norm partials of `out` as a by-product:
+// partial c covers elements [c * SQ_CHUNK, (c + 1) * SQ_CHUNK) with the thread -> element map and the summation order of
+// k_sqnorm_partials, so the fused pass and the separate one give the same bits.
+constexpr int SQ_CHUNK = 256 * 16;   // elements per squared-norm partial
+__global__ __launch_bounds__(256) void k_multi_op(const MultiOps r) {
+    const MultiOp& o = r.op[blockIdx.y];
+    if (o.kind == MULTI_FILL) {
+        if (o.cond != nullptr && *o.cond == 0) return;
+        uint32_t* p = (uint32_t*)o.dst;
+        const uint32_t word = o.word;
+        const long long n = o.n, n4 = n >> 2;
+        const uint4 w4 = make_uint4(word, word, word, word);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+            reinterpret_cast<uint4*>(p)[i] = w4;
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = word;
+        return;
+    }
+    // REDUCE: chunks of SQ_CHUNK elements, grid-stride over the chunks.  A thread owns four float4 of a chunk; the four loads of a
+    // slab are issued together (and two slabs per round), so a thread has eight 16-byte loads in flight instead of one -- the first
+    // version walked the slabs of one float4 at a time and ran at a third of the HBM rate (26 us for 70 MB).
+    __shared__ double sh[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* sl = (const float*)o.src;
+    float* out = (float*)o.dst;
+    const long long n = o.n, nchunks = (n + SQ_CHUNK - 1) / SQ_CHUNK;
+    const bool vec = (o.stride & 3) == 0 && (n & 3) == 0;     // 16-byte aligned slabs and rows (every slab base is: allocations are 256-byte aligned)
+    for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const long long base = c * SQ_CHUNK;
+        double s = 0.0;
+        if (vec && base + SQ_CHUNK <= n) {
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(sl + base + 4 * (tid + 256 * i));
+            int z = 1;
+            for (; z + 1 < o.nslab; z += 2) {
+                float4 w0[4], w1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    w0[i] = *reinterpret_cast<const float4*>(sl + z * o.stride + base + 4 * (tid + 256 * i));
+                    w1[i] = *reinterpret_cast<const float4*>(sl + (z + 1) * o.stride + base + 4 * (tid + 256 * i));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i].x += w0[i].x; v[i].y += w0[i].y; v[i].z += w0[i].z; v[i].w += w0[i].w;
+                    v[i].x += w1[i].x; v[i].y += w1[i].y; v[i].z += w1[i].z; v[i].w += w1[i].w;
+                }
+            }
+            if (z < o.nslab) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 w = *reinterpret_cast<const float4*>(sl + z * o.stride + base + 4 * (tid + 256 * i));
+                    v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<float4*>(out + base + 4 * (tid + 256 * i)) = v[i];
+                s += ((double)v[i].x * v[i].x + (double)v[i].y * v[i].y) + ((double)v[i].z * v[i].z + (double)v[i].w * v[i].w);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long long idx = base + 4 * (tid + 256 * i);
+                float q[4] = {0.f, 0.f, 0.f, 0.f};
+                int k = 0;
+                for (long long j = idx; j < n && j < idx + 4; ++j, ++k) {
+                    float v = sl[j];
+                    for (int z = 1; z < o.nslab; ++z) v += sl[z * o.stride + j];
+                    out[j] = v;
+                    q[k] = v;
+                }
+                if (k == 4) s += ((double)q[0] * q[0] + (double)q[1] * q[1]) + ((double)q[2] * q[2] + (double)q[3] * q[3]);
+                else for (int e = 0; e < k; ++e) s += (double)q[e] * q[e];
+            }
+        }
+        if (o.sq != nullptr) {
+            s = wave_sum_d(s);
+            if (lane == 0) sh[wave] = s;
+            __syncthreads();
+            if (tid == 0) o.sq[c] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+            __syncthreads();
+        }
+    }
 }
 
 // ---------------------------------------------------------------- token prep (K0)
@@ -66,7 +140,7 @@ __global__ __launch_bounds__(256) void k_fill_multi(const FillRanges r) {
 // of the [nseq][T] token rows, time-major writes.
 __global__ void k_token_prep(const int* __restrict__ support, int n_support, const int* __restrict__ query,
                              int n_query, int T, int vocab, int start_word, int* __restrict__ X,
-                             int* __restrict__ Y, int* __restrict__ err_flag) {
+                             int* __restrict__ Y, int* __restrict__ err_flag, int* __restrict__ tok_first, int* __restrict__ tok_count) {
     const int B = n_support + n_query;
     const long long total = (long long)B * T;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -81,6 +155,12 @@ __global__ void k_token_prep(const int* __restrict__ support, int n_support, con
         Y[(long long)t * B + b] = tok;
         if (t + 1 < T) X[(long long)(t + 1) * B + b] = tok;
         if (t == 0) X[b] = start_word;
+        // occurrence table of the input ids (train passes): first position and count per token -- integer atomics, the result
+        // does not depend on their order.  k_embed_grad's owner blocks read it and put it back to (INT_MAX, 0).
+        if (tok_first != nullptr) {
+            if (t + 1 < T) { atomicMin(tok_first + tok, (int)((long long)(t + 1) * B + b)); atomicAdd(tok_count + tok, 1); }
+            if (t == 0) { atomicMin(tok_first + start_word, b); atomicAdd(tok_count + start_word, 1); }
+        }
     }
 }
 
@@ -260,18 +340,29 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ c
 // ---------------------------------------------------------------- embedding gradient (K7 tail)
 // dEmb[tok] = sum of dX rows of every occurrence of tok, accumulated in increasing position
 // order by the block of the FIRST occurrence (owner computes: no atomics, deterministic).
+// tok_first / tok_count (k_token_prep): the block of position r owns X[r] iff tok_first[X[r]] == r, and it stops scanning
+// once it has seen tok_count[X[r]] occurrences -- at cfg-B three positions in four hold a token that occurs once, whose
+// block copies one row; without the table every block scanned all earlier positions for a duplicate and all later ones
+// for more occurrences (25 us for 5.9 MB).  The owner resets its table entry, so a completed pass leaves the table clean.
 __global__ __launch_bounds__(256) void k_embed_grad(const int* __restrict__ X, int n, const float* __restrict__ dX,
-                                                    int Ep, float* __restrict__ dEmb) {
+                                                    int Ep, float* __restrict__ dEmb, int* __restrict__ tok_first, int* __restrict__ tok_count) {
     __shared__ unsigned long long mask[4];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tok = X[r];
-    // earlier duplicate? then another block owns this token
-    int dup = 0;
-    for (int i = tid; i < r; i += 256) dup |= (X[i] == tok);
-    if (__syncthreads_or(dup)) return;
+    int want = n + 1;                           // occurrences to find (no table: scan to the end)
+    if (tok_first != nullptr) {
+        if (tok_first[tok] != r) return;        // (uniform: every thread reads the same word)
+        want = tok_count[tok];
+    } else {
+        // earlier duplicate? then another block owns this token
+        int dup = 0;
+        for (int i = tid; i < r; i += 256) dup |= (X[i] == tok);
+        if (__syncthreads_or(dup)) return;
+    }
 
     float acc[4] = {0.f, 0.f, 0.f, 0.f};       // columns tid, tid+256, ... (Ep <= 1024)
-    for (int base = r; base < n; base += 256) {
+    int found = 0;
+    for (int base = r; base < n && found < want; base += 256) {
         const int i = base + tid;
         const bool hit = (i < n) && (X[i] == tok);
         const unsigned long long bal = __ballot(hit);
@@ -280,6 +371,7 @@ __global__ __launch_bounds__(256) void k_embed_grad(const int* __restrict__ X, i
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             unsigned long long mk = mask[w];
+            found += __popcll(mk);
             while (mk) {
                 const int bit = __ffsll((long long)mk) - 1;
                 mk &= mk - 1;
@@ -294,10 +386,10 @@ __global__ __launch_bounds__(256) void k_embed_grad(const int* __restrict__ X, i
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (tid + 256 * c < Ep) dEmb[(long long)tok * Ep + tid + 256 * c] = acc[c];
+    if (tok_first != nullptr && tid == 0) { tok_first[tok] = 0x7FFFFFFF; tok_count[tok] = 0; }
 }
 
 // ---------------------------------------------------------------- global norm + Adam (K8 + K9)
-constexpr int SQ_CHUNK = 256 * 16;   // elements per block
 __global__ __launch_bounds__(256) void k_sqnorm_partials(const float* __restrict__ x, long long n,
                                                          double* __restrict__ partials) {
     __shared__ double sh[4];
@@ -329,7 +421,7 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
     __shared__ float s_scale, s_alpha;
     // the gradients of a step whose persistent recurrent kernel timed out are garbage, and a batch with an out-of-range
     // token is rejected as a whole (the reference would fail the feed): keep the parameters
-    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f) return;
+    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f || a.tail[4] != 0.0f) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;
     for (int i = tid; i < a.n_partials; i += 256) s += a.partials[i];
@@ -378,7 +470,7 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
 __global__ __launch_bounds__(256) void k_sgd_update(const UpdateArgs a) {
     __shared__ double sh[4];
     __shared__ float s_scale;
-    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f) return;
+    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f || a.tail[4] != 0.0f) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;
     for (int i = tid; i < a.n_partials; i += 256) s += a.partials[i];
@@ -408,28 +500,9 @@ __global__ __launch_bounds__(256) void k_sgd_update(const UpdateArgs a) {
 // tallied in `counters` (host-mapped: [0] time-outs, [1] token-range rejections; the host compares them with what it has
 // seen, no read-back needed) and the flag is CLEARED, so that the next step starts clean instead of every later launch
 // bailing out on a stale flag.
-__global__ void k_step_increment(long long* step, const float* loss_src, float loss_scale, float* ring,
-                                 int ring_cap, int* err_flag, long long* counters, int* handoff_dirty) {
+__global__ void k_step_increment(const StepIncArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int e = err_flag != nullptr ? *err_flag : 0;
-    // a pass that was aborted by a time-out leaves dh partials in the BPTT inboxes: the next pass refills them (k_fill32_if);
-    // a pass that completed left every word reset by its reader
-    if (handoff_dirty != nullptr) *handoff_dirty = (e == 2) ? 1 : 0;
-    const bool peer_timeout = loss_src != nullptr && loss_src[1] != 0.0f;      // loss_src is tail[1]; tail[2] is the indicator
-    const bool peer_token = loss_src != nullptr && loss_src[2] != 0.0f;        // tail[3]: some rank's batch held an out-of-range id
-    if (e != 0 || peer_timeout || peer_token) {
-        if (counters != nullptr) {
-            if (e == 2 || peer_timeout) counters[0] += 1; else counters[1] += 1;
-            __threadfence_system();
-        }
-        if (err_flag != nullptr) *err_flag = 0;
-        return;
-    }
-    {
-        const long long s = *step;
-        if (ring != nullptr && loss_src != nullptr) ring[s % ring_cap] = *loss_src * loss_scale;
-        *step = s + 1;
-    }
+    step_increment_body(a);
 }
 
 // flag_src != nullptr: also dst[2] = (*flag_src == 2), dst[3] = (*flag_src == 1) -- the "a persistent recurrent kernel timed out" /
@@ -437,7 +510,7 @@ __global__ void k_step_increment(long long* step, const float* loss_src, float l
 // in the gradient tail, so after the all-reduce EVERY rank of an episode-parallel step knows that some rank's gradients
 // are garbage
 __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partials, int n, float* dst,
-                                                      const int* flag_src) {
+                                                      const int* flag_src, const float* __restrict__ ce, int ce_n, float* loss_out) {
     __shared__ double sh[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;
@@ -447,8 +520,80 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
     __syncthreads();
     if (tid == 0) {
         dst[0] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
-        if (flag_src != nullptr) { dst[2] = (*flag_src == 2) ? 1.0f : 0.0f; dst[3] = (*flag_src == 1) ? 1.0f : 0.0f; }
+        if (flag_src != nullptr) { dst[2] = (*flag_src == 2) ? 1.0f : 0.0f; dst[3] = (*flag_src == 1) ? 1.0f : 0.0f; dst[4] = 0.0f; }
     }
+    if (ce == nullptr) return;
+    // the mean loss of a train pass (k_loss_reduce with one group: same order, same bits) -- nobody reads it before the
+    // step's last kernels, so it rides here instead of costing a launch behind the cross entropy
+    __syncthreads();
+    double l = 0.0;
+    for (int i0 = tid; i0 < ce_n; i0 += 256 * 16) {        // sixteen loads in flight, added in index order (the order of k_loss_reduce)
+        float b[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) b[k] = (i0 + 256 * k < ce_n) ? ce[i0 + 256 * k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (i0 + 256 * k < ce_n) l += (double)b[k];
+    }
+    l = wave_sum_d(l);
+    if (lane == 0) sh[wave] = l;
+    __syncthreads();
+    if (tid == 0) *loss_out = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / ((double)ce_n + 1e-12));
+}
+
+// ---------------------------------------------------------------- unigram baseline
+// Reference src/models/unigram_model.py:26-39: word_count (alpha = 1) + scatter_add of ones, prob = gather / reduce_sum,
+// loss = -mean(log prob).  Counts are integers (unsigned atomics: exact and order-independent), handed to the caller as floats.
+__global__ void k_unigram_update(const int* __restrict__ words, long long n, unsigned* __restrict__ counts, int vocab, int* err_flag) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int w = words[i];
+        if (w < 0 || w >= vocab) { atomicOr(err_flag, 1); continue; }
+        atomicAdd(counts + w, 1u);
+    }
+}
+// one block: total = sum(counts) (exact in double), then -mean(log(float(count[w]) / float(total))) in the reference's fp32
+// arithmetic per word, accumulated in double in a fixed order
+__global__ __launch_bounds__(1024) void k_unigram_nll(const int* __restrict__ words, long long n, const unsigned* __restrict__ counts, int vocab,
+                                                      float* out, int* err_flag) {
+    __shared__ double sh[16];
+    __shared__ float s_total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;
+    for (int i = tid; i < vocab; i += 1024) s += (double)counts[i];
+    s = wave_sum_d(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < 16; ++w) t += sh[w]; s_total = (float)t; }
+    __syncthreads();
+    const float total = s_total;
+    double l = 0.0;
+    for (long long i = tid; i < n; i += 1024) {
+        const int w = words[i];
+        if (w < 0 || w >= vocab) { atomicOr(err_flag, 1); continue; }
+        l += (double)logf((float)counts[w] / total);
+    }
+    l = wave_sum_d(l);
+    __syncthreads();
+    if (lane == 0) sh[wave] = l;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < 16; ++w) t += sh[w]; out[0] = (float)(-t / (double)(n > 0 ? n : 1)); out[1] = total; }
+}
+// argmax of the counts, lowest index on ties (np.argmax)
+__global__ __launch_bounds__(1024) void k_unigram_argmax(const unsigned* __restrict__ counts, int vocab, int* out) {
+    __shared__ unsigned sc[1024];
+    __shared__ int si[1024];
+    const int tid = threadIdx.x;
+    unsigned best = 0; int bi = 0x7FFFFFFF;
+    for (int i = tid; i < vocab; i += 1024) { const unsigned c = counts[i]; if (c > best || (c == best && i < bi)) { best = c; bi = i; } }
+    sc[tid] = best; si[tid] = bi;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) {
+            const unsigned c = sc[tid + o]; const int i = si[tid + o];
+            if (c > sc[tid] || (c == sc[tid] && i < si[tid])) { sc[tid] = c; si[tid] = i; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *out = si[0];
 }
 
 // ---------------------------------------------------------------- greedy decode (K10)
@@ -524,13 +669,13 @@ __global__ void k_decode_pick(const float* blk_max, const int* blk_idx, int nblk
 }  // namespace
 
 hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, const int* query, int n_query,
-                             int T, int vocab, int start_word, int* X, int* Y, int* err_flag) {
+                             int T, int vocab, int start_word, int* X, int* Y, int* err_flag, int* tok_first, int* tok_count) {
     const long long total = (long long)(n_support + n_query) * T;
     if (total <= 0) return hipSuccess;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(k_token_prep, dim3(blocks), dim3(256), 0, s, support, n_support, query, n_query, T, vocab,
-                       start_word, X, Y, err_flag);
+                       start_word, X, Y, err_flag, tok_first, tok_count);
     return hipGetLastError();
 }
 
@@ -561,20 +706,22 @@ hipError_t launch_loss_reduce(hipStream_t s, const float* ce, int T, int B, int 
     return hipGetLastError();
 }
 
-hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX, int Ep, float* dEmb) {
+hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX, int Ep, float* dEmb, int* tok_first, int* tok_count) {
     if (n <= 0) return hipSuccess;
     if (Ep > 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_embed_grad, dim3(n), dim3(256), 0, s, X, n, dX, Ep, dEmb);
+    hipLaunchKernelGGL(k_embed_grad, dim3(n), dim3(256), 0, s, X, n, dX, Ep, dEmb, tok_first, tok_count);
     return hipGetLastError();
 }
 
-hipError_t launch_fill_multi(hipStream_t s, const FillRanges& r) {
+hipError_t launch_multi_op(hipStream_t s, const MultiOps& r) {
     if (r.count <= 0) return hipSuccess;
-    long long most = 0;
-    for (int k = 0; k < r.count; ++k) most = std::max(most, r.n[k]);
-    long long bx = (most / 4 + 255) / 256;
-    bx = std::max<long long>(1, std::min<long long>(bx, 512));
-    hipLaunchKernelGGL(k_fill_multi, dim3((int)bx, r.count), dim3(256), 0, s, r);
+    long long bx = 1;
+    for (int k = 0; k < r.count; ++k) {
+        const long long want = r.op[k].kind == MULTI_FILL ? (r.op[k].n / 4 + 255) / 256 : (r.op[k].n + SQ_CHUNK - 1) / SQ_CHUNK;
+        bx = std::max(bx, want);
+    }
+    bx = std::max<long long>(1, std::min<long long>(bx, 1024));
+    hipLaunchKernelGGL(k_multi_op, dim3((int)bx, r.count), dim3(256), 0, s, r);
     return hipGetLastError();
 }
 
@@ -630,14 +777,28 @@ hipError_t launch_sgd_update(hipStream_t s, const UpdateArgs& a) {
     return hipGetLastError();
 }
 
-hipError_t launch_step_increment(hipStream_t s, long long* step, const float* loss_src, float loss_scale,
-                                 float* loss_ring, int ring_cap, int* err_flag, long long* counters, int* handoff_dirty) {
-    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(64), 0, s, step, loss_src, loss_scale, loss_ring, ring_cap, err_flag, counters, handoff_dirty);
+hipError_t launch_step_increment(hipStream_t s, const StepIncArgs& a) {
+    hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst, const int* flag_src) {
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partials, n, dst, flag_src);
+hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst, const int* flag_src,
+                               const float* ce, int ce_n, float* loss_out) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partials, n, dst, flag_src, ce, ce_n, loss_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_unigram_update(hipStream_t s, const int* words, long long n, unsigned* counts, int vocab, int* err_flag) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unigram_update, dim3((int)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, s, words, n, counts, vocab, err_flag);
+    return hipGetLastError();
+}
+hipError_t launch_unigram_nll(hipStream_t s, const int* words, long long n, const unsigned* counts, int vocab, float* out, int* err_flag) {
+    hipLaunchKernelGGL(k_unigram_nll, dim3(1), dim3(1024), 0, s, words, n, counts, vocab, out, err_flag);
+    return hipGetLastError();
+}
+hipError_t launch_unigram_argmax(hipStream_t s, const unsigned* counts, int vocab, int* out) {
+    hipLaunchKernelGGL(k_unigram_argmax, dim3(1), dim3(1024), 0, s, counts, vocab, out);
     return hipGetLastError();
 }
 

@@ -91,7 +91,7 @@ struct fsmg_model {
     int fallback_left = 0;
     long long* host_counters = nullptr; // host-mapped tallies written by k_step_increment: [0] steps skipped after a time-out, [1] after a token-range error
     long long* d_counters = nullptr;    // the same memory as the device sees it
-    long long seen_timeouts = 0, seen_token_errors = 0;
+    long long seen_timeouts = 0, seen_token_errors = 0, seen_peer_failures = 0;
     bool force_fwd_rt = false;          // FSMG_FWD_RT=1: take the all-row-tiles forward kernel wherever it applies (tests)
     bool persist_fwd = true, persist_bwd = true;   // FSMG_PERSIST_FWD / FSMG_PERSIST_BWD = 0: that direction launches per step
     bool persist = true;                // FSMG_PERSISTENT=0: one launch per time step instead of one persistent launch per chain chunk
@@ -122,6 +122,19 @@ struct fsmg_model {
     int64_t n_timeouts = 0, n_persist_launches = 0, n_xcd_launches = 0, n_step_launches = 0;   // fsmg_get_stats
     bool khf_dirty = true;              // host wrote parameters since the last repack
     float* slabs = nullptr;             // split-K partial outputs of the GEMMs on the main stream
+    float* arena = nullptr;             // slabs of the GEMMs whose sums are deferred into one launch (gemm(..., defer)): bump-allocated per pass
+    int64_t arena_cap = 0, arena_off = 0;
+    bool warned_split = false;
+    // occurrence table of the input ids of a train pass (k_token_prep -> k_embed_grad): [V1] first position, [V1] count
+    int* tok_first = nullptr; int* tok_count = nullptr;
+    bool tok_table_open = false;        // a train-pass token_prep has been issued whose embed_grad has not (a failed call): refill before the next use
+    bool last_bwd_xcd = false;          // the backward pass in flight took the XCD-local BPTT kernels (they did the conditional inbox refill)
+    // eager passes: a pass on the persistent recurrent kernels is ~25 launches, which the host issues in < 0.1 ms -- replaying it
+    // from a hipGraph buys nothing (measured: 534 vs 532 episodes/s at cfg-B) and costs the token staging copies, because a
+    // captured token_prep cannot take the caller's pointers.  FSMG_EAGER=0: graphs wherever fsmg_config.use_graph allows.
+    bool eager = true, eager_call = false;
+    const int* cur_sup = nullptr; const int* cur_qry = nullptr;     // what token_prep reads: the caller's device buffers (eager) or the staging buffer
+    bool fill_early = false;            // FSMG_FILL_EARLY=1: the forward hand-off fills in front of the zx GEMM instead of behind it (A/B)
     float* colsum_slabs = nullptr;
     float* slabs2 = nullptr;            // ... and of the GEMMs on the auxiliary stream
     float* colsum_slabs2 = nullptr;
@@ -445,19 +458,29 @@ int ensure_scratch(fsmg_model* h, int B) {
     const int64_t o_cep = place(8 * rows * nparts), o_tl = place(4 * rows);
     h->partials_cap = sqnorm_blocks(h->n_flat) + sqnorm_blocks(rows * h->Ep) + 8;
     const int64_t o_part = place(8 * (int64_t)h->partials_cap);
-    // split-K slabs: the largest S*M*N over the backward GEMMs of this shape
-    int64_t slab_need = 0;
+    // split-K slabs: the largest S*M*N over the backward GEMMs of this shape, over every (kernel, slot count) gemm() may pick
+    // -- the 128-tile kernels on 256 .. 1024 slots, the wave-specialised one (682) and the 256 x 256-tile one (256 slots)
+    int64_t slab_need = 0, arena_need = 0;
     {
-        auto need = [&](int64_t M, int64_t N, int64_t K) {
-            for (int64_t slots : {(int64_t)256, (int64_t)512, (int64_t)768, (int64_t)gemm_block_slots()}) {
+        auto worst = [&](int64_t M, int64_t N, int64_t K) {
+            int64_t w = 0;
+            for (int64_t slots : {(int64_t)256, (int64_t)512, (int64_t)682, (int64_t)768, (int64_t)gemm_block_slots()}) {
                 for (bool bx : {false, true}) {
                     const int S = pick_split(M, N, K, slots, bx);
-                    if (S > 1) slab_need = std::max(slab_need, (int64_t)S * M * N);
+                    if (S > 1) w = std::max(w, (int64_t)S * M * N);
                 }
             }
+            const int Sh = pick_split(M, N, K, 256, true, 256);
+            if (Sh > 1) w = std::max(w, (int64_t)Sh * M * N);
+            return w;
         };
+        auto need = [&](int64_t M, int64_t N, int64_t K) { slab_need = std::max(slab_need, worst(M, N, K)); };
+        // the slab sums of these are deferred (OpBatch): each needs its own slabs until the batch is flushed
+        auto keep = [&](int64_t M, int64_t N, int64_t K) { arena_need += round_up(worst(M, N, K), 64) + round_up((int64_t)MAX_SPLIT * N, 64); };
         need(rows, Hp, h->V1p); need(Hp, h->V1p, rows); need(Hp, G4, rows);
         need(h->Ep, G4, rows); need(rows, h->Ep, G4); need(rows, Hp, G4); need(rows, G4, h->Ep); need(rows, G4, Hp);
+        keep(rows, Hp, h->V1p); keep(Hp, h->V1p, rows);
+        for (int l = 0; l < h->L; ++l) { keep(Hp, G4, rows); keep(h->in_dim[l], G4, rows); keep(rows, h->in_dim[l], G4); }
     }
     // chunked dH GEMMs of the overlap schedule have their own (smaller) shapes
     for (int nc : {h->nchunk, h->nchunk_persist})
@@ -477,6 +500,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     const int64_t o_cslab = place(4 * (int64_t)MAX_SPLIT * std::max<int64_t>(h->V1p, G4));
     const int64_t o_slab2 = place(4 * std::max<int64_t>(slab_need, 64));
     const int64_t o_cslab2 = place(4 * (int64_t)MAX_SPLIT * std::max<int64_t>(h->V1p, G4));
+    const int64_t o_arena = place(4 * std::max<int64_t>(arena_need, 64));
     hipError_t e = hipMalloc((void**)&h->scratch, off);
     if (e != hipSuccess) {
         h->Bcap = 0;
@@ -506,6 +530,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     h->ce_part = (float2*)(s + o_cep); h->tgt_logit = (float*)(s + o_tl); h->ce_nparts = nparts;
     h->slabs = (float*)(s + o_slab); h->colsum_slabs = (float*)(s + o_cslab); h->slab_cap = slab_need;
     h->slabs2 = (float*)(s + o_slab2); h->colsum_slabs2 = (float*)(s + o_cslab2);
+    h->arena = (float*)(s + o_arena); h->arena_cap = arena_need; h->arena_off = 0;
     h->Bcap = B;
     return FSMG_OK;
 }
@@ -564,31 +589,45 @@ bool use_h_gemm(fsmg_model* h, int amode, int bmode, const GemmArgs& g, const La
     return g.K >= 384 && tiles >= 512;                                                      // the projection, not zx
 }
 
-int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g) {
-    hipStream_t s = ln.s;
-    g.bx3 = h->bx3;
-    int slots = ln.slots, tile_mn = 0;
-    if (use_h_gemm(h, amode, bmode, g, ln)) {
-        g.bx3 = 3; slots = 256; tile_mn = 256;
-    } else if (use_ws_gemm(h, amode, bmode, g, ln)) {
-        g.bx3 = 2; slots = 512 * 4 / 3;             // pick_split takes 3/4 of `slots` for the bf16-split kernels: 512 here
-        if (amode == OP_KC && bmode == OP_XC) g.group_m = 4;
-    }
-    const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K, slots, g.bx3 != 0, tile_mn) : 1;
-    if (S <= 1 || (int64_t)S * g.M * g.N > h->slab_cap) {
-        g.ksplit = 1;
-        HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
+// defer != nullptr: a split-K GEMM writes its slabs into the handle's slab ARENA (bump-allocated, reset per backward pass) and
+// leaves their sum as REDUCE ops in *defer instead of launching it -- the caller flushes the batch before the first reader of C
+// (the five slab sums of a cfg-B backward pass were five launches of 57 us; two now).  sq: squared-norm partials of C
+// (sqnorm_blocks(M * N) doubles) as a by-product of the sum; *sq_done tells the caller whether that happened.
+struct OpBatch;
+int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g, OpBatch* defer = nullptr, double* sq = nullptr, bool* sq_done = nullptr);
+#define GEMMCK(call) do { int rc_ = (call); if (rc_ != FSMG_OK) return rc_; } while (0)
+
+// collects the small memory passes a phase needs -- pattern fills and split-K slab sums -- and issues them as one launch (flush)
+// right before the first kernel that depends on them
+struct OpBatch {
+    MultiOps r{};
+    fsmg_model* h;
+    explicit OpBatch(fsmg_model* h_) : h(h_) { r.count = 0; }
+    int room(int n) { return (r.count + n > MULTI_MAX_OPS) ? flush() : FSMG_OK; }
+    int add(void* p, uint32_t word, long long n_words, const int* cond = nullptr) {     // cond: fill only when *cond != 0 on the device
+        if (n_words <= 0) return FSMG_OK;
+        const int rc = room(1); if (rc != FSMG_OK) return rc;
+        MultiOp& o = r.op[r.count++];
+        o = MultiOp{}; o.kind = MULTI_FILL; o.dst = p; o.word = word; o.n = n_words; o.cond = cond;
         return FSMG_OK;
     }
-    float* C = g.C; float* colsum = g.colsum;
-    const int64_t mn = (int64_t)g.M * g.N;
-    g.C = ln.slabs; g.c_slab = mn; g.ksplit = S;
-    if (colsum) { g.colsum = ln.colsum_slabs; g.colsum_slab = g.N; }
-    HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
-    HIPCK(h, launch_reduce_slabs2(s, ln.slabs, mn, S, C, mn, ln.colsum_slabs, g.N, colsum, colsum ? g.N : 0));
-    return FSMG_OK;
-}
-#define GEMMCK(call) do { int rc_ = (call); if (rc_ != FSMG_OK) return rc_; } while (0)
+    // out[i] = sum over the nslab slabs (fixed order); sq: squared-norm partials of out as a by-product
+    int reduce(const float* slabs, long long stride, int nslab, float* out, long long n, double* sq = nullptr) {
+        if (n <= 0) return FSMG_OK;
+        const int rc = room(1); if (rc != FSMG_OK) return rc;
+        MultiOp& o = r.op[r.count++];
+        o = MultiOp{}; o.kind = MULTI_REDUCE; o.dst = out; o.src = slabs; o.stride = stride; o.nslab = nslab; o.n = n; o.sq = sq;
+        return FSMG_OK;
+    }
+    int flush() {
+        if (r.count == 0) return FSMG_OK;
+        HIPCK(h, launch_multi_op(h->stream, r));
+        r.count = 0;
+        return FSMG_OK;
+    }
+};
+typedef OpBatch FillBatch;
+
 
 // Run `body` (a pure sequence of stream-ordered launches with call-invariant arguments) through a
 // cached hipGraph: captured on first use for this key, replayed afterwards.  The ~300 launches of a
@@ -598,7 +637,7 @@ template <class F>
 int run_graphed(fsmg_model* h, const std::string& key, F&& body) {
     // hipGraph (ROCm 7.2) runs captured cross-stream branches one after the other, so the two-stream
     // schedule only overlaps with eager launches
-    if (!h->cfg.use_graph || h->timing || h->ov_call || h->xov_call) return body();
+    if (!h->cfg.use_graph || h->timing || h->ov_call || h->xov_call || h->eager_call) return body();
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) {           // a replay launches what the capture launched
         const auto& c = h->graph_counts[key];
@@ -639,15 +678,31 @@ int ensure_khf(fsmg_model* h) {
 // call-invariant arguments and can live in a replayed graph
 int stage_tokens(fsmg_model* h, const int32_t* support, int n_sup, const int32_t* query, int n_qry, int on_device) {
     const size_t T = h->T;
+    if (on_device && h->eager_call) {       // an eager pass reads the caller's device buffers in place: no copies, nothing between two steps
+        h->cur_sup = support; h->cur_qry = query;
+        return FSMG_OK;
+    }
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (n_sup > 0) HIPCK(h, hipMemcpyAsync(h->d_tok, support, sizeof(int) * n_sup * T, kind, h->stream));
     if (n_qry > 0) HIPCK(h, hipMemcpyAsync(h->d_tok + n_sup * T, query, sizeof(int) * n_qry * T, kind, h->stream));
+    h->cur_sup = h->d_tok; h->cur_qry = h->d_tok + n_sup * T;
     return FSMG_OK;
 }
 
-int token_prep(fsmg_model* h, int n_sup, int n_qry) {
-    HIPCK(h, launch_token_prep(h->stream, h->d_tok, n_sup, h->d_tok + (size_t)n_sup * h->T, n_qry, h->T, h->V, h->V,
-                               h->X, h->Y, h->d_err));
+// (INT_MAX, 0) in every entry of the occurrence table
+int reset_tok_table(fsmg_model* h) {
+    if (!h->tok_first) return FSMG_OK;
+    OpBatch ops(h);
+    GEMMCK(ops.add(h->tok_first, 0x7FFFFFFFu, h->V1));
+    GEMMCK(ops.add(h->tok_count, 0u, h->V1));
+    return ops.flush();
+}
+
+// train: the pass ends in k_embed_grad, which wants the occurrence table of the input ids
+int token_prep(fsmg_model* h, int n_sup, int n_qry, bool train = false) {
+    const bool table = train && h->tok_first != nullptr;
+    HIPCK(h, launch_token_prep(h->stream, h->cur_sup, n_sup, h->cur_qry, n_qry, h->T, h->V, h->V,
+                               h->X, h->Y, h->d_err, table ? h->tok_first : nullptr, table ? h->tok_count : nullptr));
     return FSMG_OK;
 }
 
@@ -685,24 +740,52 @@ static void phase_report(fsmg_model* h) {
 #define PHASE(i) ((void)0)
 #endif
 
-// collects the fills a phase needs and issues them as one launch (flush) right before the first kernel that depends on them
-struct FillBatch {
-    FillRanges r{};
-    fsmg_model* h;
-    explicit FillBatch(fsmg_model* h_) : h(h_) { r.count = 0; }
-    int add(void* p, uint32_t word, long long n_words, const int* cond = nullptr) {     // cond: fill only when *cond != 0 on the device
-        if (n_words <= 0) return FSMG_OK;
-        if (r.count == FILL_MAX_RANGES) { const int rc = flush(); if (rc != FSMG_OK) return rc; }
-        r.p[r.count] = (uint32_t*)p; r.word[r.count] = word; r.n[r.count] = n_words; r.cond[r.count] = cond; ++r.count;
+int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g, OpBatch* defer, double* sq, bool* sq_done) {
+    hipStream_t s = ln.s;
+    g.bx3 = h->bx3;
+    if (sq_done) *sq_done = false;
+    int slots = ln.slots, tile_mn = 0;
+    if (use_h_gemm(h, amode, bmode, g, ln)) {
+        g.bx3 = 3; slots = 256; tile_mn = 256;
+    } else if (use_ws_gemm(h, amode, bmode, g, ln)) {
+        g.bx3 = 2; slots = 512 * 4 / 3;             // pick_split takes 3/4 of `slots` for the bf16-split kernels: 512 here
+        if (amode == OP_KC && bmode == OP_XC) g.group_m = 4;
+    }
+    const int S = (g.ldc == g.N) ? pick_split(g.M, g.N, g.K, slots, g.bx3 != 0, tile_mn) : 1;
+    const int64_t mn = (int64_t)g.M * g.N;
+    float* slabs = ln.slabs; float* cslabs = ln.colsum_slabs;
+    bool deferred = false;
+    if (S > 1 && defer != nullptr && ln.s == h->stream && h->arena != nullptr) {
+        const int64_t need = round_up((int64_t)S * mn, 64) + (g.colsum ? round_up((int64_t)S * g.N, 64) : 0);
+        if (h->arena_off + need <= h->arena_cap) {
+            slabs = h->arena + h->arena_off; cslabs = slabs + round_up((int64_t)S * mn, 64);
+            h->arena_off += need;
+            deferred = true;
+        }
+    }
+    if (S <= 1 || (!deferred && (int64_t)S * mn > h->slab_cap)) {
+        if (S > 1 && !h->warned_split) {           // a shape-dependent cliff: say so once
+            h->warned_split = true;
+            fprintf(stderr, "[fsmg] split-K of a %d x %d x %d GEMM dropped: %d slabs do not fit the slab buffer (%lld floats)\n", g.M, g.N, g.K, S, (long long)h->slab_cap);
+        }
+        g.ksplit = 1;
+        HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
         return FSMG_OK;
     }
-    int flush() {
-        if (r.count == 0) return FSMG_OK;
-        HIPCK(h, launch_fill_multi(h->stream, r));
-        r.count = 0;
+    float* C = g.C; float* colsum = g.colsum;
+    g.C = slabs; g.c_slab = mn; g.ksplit = S;
+    if (colsum) { g.colsum = cslabs; g.colsum_slab = g.N; }
+    HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
+    if (deferred) {
+        GEMMCK(defer->room(colsum ? 2 : 1));
+        GEMMCK(defer->reduce(slabs, mn, S, C, mn, sq));
+        if (colsum) GEMMCK(defer->reduce(cslabs, g.N, S, colsum, g.N));
+        if (sq_done) *sq_done = sq != nullptr;
         return FSMG_OK;
     }
-};
+    HIPCK(h, launch_reduce_slabs2(s, slabs, mn, S, C, mn, cslabs, g.N, colsum, colsum ? g.N : 0));
+    return FSMG_OK;
+}
 
 // the XCD-local kernels take this row count at this hidden size (and their buffers exist)
 inline bool use_xcd(const fsmg_model* h, int B, bool backward = false) {
@@ -718,6 +801,10 @@ inline bool use_xcd(const fsmg_model* h, int B, bool backward = false) {
 inline void choose_schedule(fsmg_model* h, int B, bool train = false) {
     h->ov_call = h->overlap && (h->overlap_forced || !use_xcd(h, B));
     h->xov_call = false;
+    // a pass whose recurrence is one persistent launch per direction is short enough to issue eagerly; per-step kernels (big
+    // validation batches, the fallback after a time-out) keep the graph
+    h->eager_call = h->eager && !h->ov_call && h->persist && h->persist_fwd && h->persist_bwd &&
+                    (use_xcd(h, B) || lstm_fwd_chain_supported(B, h->Hp) || lstm_fwd_chain_rt_supported(B, h->Hp));
     if (train && h->xov && h->Hp == 512 && !h->ov_call && !h->timing && h->aux != nullptr && use_xcd(h, B) && h->persist_fwd && h->persist_bwd) {
         const int rpx = lstm_xcd_packed_rows(B);
         h->xov_call = (B + rpx - 1) / rpx < 8;          // packing frees at least one XCD
@@ -792,6 +879,23 @@ int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t 
     return ce_rows(h, ln.s, B, t0, t1, rows_total);
 }
 
+// FSMG_FILL_EARLY=1 (A/B): the hand-off fills of a layer's forward chain in front of its x-part GEMM instead of right in front of
+// the chain, so that the chain does not start on an L2 full of fill lines
+int chain_fills_early(fsmg_model* h, OpBatch& fills, int l, int B, bool chain, bool xcd, int xov_words) {
+    const int T = h->T, Hp = h->Hp;
+    const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
+    if (chain) GEMMCK(fills.add(h->HF[l] + Bp16 * Hp, 0xFFFFFFFFu, (long long)T * Bp16 * Hp));
+    if (xcd) {
+        GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
+        h->ticket_next = 0;
+        const long long step_f = lstm_xcd_hx_floats(B, 0, Hp, h->xcd_bx3);
+        GEMMCK(fills.add(h->HX, 0u, step_f));
+        GEMMCK(fills.add(h->HX + step_f, 0xFFFFFFFFu, step_f * T));
+        if (xov_words > 0) GEMMCK(fills.add(h->xov_ctl, 0u, xov_words));
+    }
+    return fills.flush();
+}
+
 int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_out, bool want_dlogits) {
     ScopedRange rng_(want_dlogits ? "fsmg.forward(train)" : "fsmg.forward(eval)");
     const int T = h->T, Hp = h->Hp, G4 = h->G4;
@@ -817,6 +921,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
         GEMMCK(fills.add(h->Hs[l], 0u, (long long)B * Hp));
         GEMMCK(fills.add(h->Cs[l], 0u, (long long)B * Hp));
         if (!xcd) GEMMCK(fills.add(h->HF[l], 0u, (long long)Bp16 * Hp));
+        if (h->fill_early) GEMMCK(chain_fills_early(h, fills, l, B, chain, xcd, xov && top ? 4 + gemm_items(ghead) : 0));
         {
             ScopedTimer tm(h, "gemm_zx");
             GemmArgs g{};
@@ -828,17 +933,20 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             GEMMCK(gemm(h, mainl, OP_KC, OP_XC, g));
         }
         PHASE(1);
-        if (chain)       // "not written yet" fill pattern of the h fragments of time indices 1..T (index 0 is the zero state)
-            GEMMCK(fills.add(h->HF[l] + Bp16 * Hp, 0xFFFFFFFFu, (long long)T * Bp16 * Hp));
-        if (xcd) {       // the same for the XCD-local hand-off buffer, and fresh ticket counters for this layer's launches
-            GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
-            h->ticket_next = 0;
-            const long long step_f = lstm_xcd_hx_floats(B, 0, Hp, h->xcd_bx3);
-            GEMMCK(fills.add(h->HX, 0u, step_f));
-            GEMMCK(fills.add(h->HX + step_f, 0xFFFFFFFFu, step_f * T));
-            if (xov && top) GEMMCK(fills.add(h->xov_ctl, 0u, 4 + gemm_items(ghead)));
-        }
-        GEMMCK(fills.flush());
+        auto chain_fills = [&]() -> int {
+            if (chain)       // "not written yet" fill pattern of the h fragments of time indices 1..T (index 0 is the zero state)
+                GEMMCK(fills.add(h->HF[l] + Bp16 * Hp, 0xFFFFFFFFu, (long long)T * Bp16 * Hp));
+            if (xcd) {       // the same for the XCD-local hand-off buffer, and fresh ticket counters for this layer's launches
+                GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
+                h->ticket_next = 0;
+                const long long step_f = lstm_xcd_hx_floats(B, 0, Hp, h->xcd_bx3);
+                GEMMCK(fills.add(h->HX, 0u, step_f));
+                GEMMCK(fills.add(h->HX + step_f, 0xFFFFFFFFu, step_f * T));
+                if (xov && top) GEMMCK(fills.add(h->xov_ctl, 0u, 4 + gemm_items(ghead)));
+            }
+            return fills.flush();
+        };
+        if (!h->fill_early) GEMMCK(chain_fills());
         const bool split_head = xov && top && head >= 1;
         const int nch = split_head ? 2 : nch_ov;
         for (int c = 0; c < nch; ++c) {
@@ -905,7 +1013,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     } else {
         GEMMCK(logits_and_ce(h, mainl, B, 0, T, rows, want_dlogits));
     }
-    {
+    if (!want_dlogits) {         // (a train pass reduces its loss in backward(): k_sum_partials, no launch of its own)
         ScopedTimer tm(h, "ce");
         HIPCK(h, launch_loss_reduce(s, h->ce, T, B, rows_per_group, ngroups, loss_out));
     }
@@ -913,13 +1021,13 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     return FSMG_OK;
 }
 
-int dhout_chunk(fsmg_model* h, const Lane& ln, int B, int t0, int t1) {
+int dhout_chunk(fsmg_model* h, const Lane& ln, int B, int t0, int t1, OpBatch* defer = nullptr) {
     ScopedTimer tm(h, "gemm_dhout");     // dH = dlogits * W^T for the rows of time steps [t0, t1)
     const int64_t r0 = (int64_t)t0 * B, m = (int64_t)(t1 - t0) * B;
     GemmArgs g{};
     g.A = h->dlogits + (size_t)r0 * h->V1p; g.lda = h->V1p; g.B = h->P + h->off_w; g.ldb = h->V1p;
     g.C = h->dH + (size_t)r0 * h->Hp; g.ldc = h->Hp; g.M = (int)m; g.N = h->Hp; g.K = h->V1p; g.ksplit = 1;
-    return gemm(h, ln, OP_KC, OP_KC, g);
+    return gemm(h, ln, OP_KC, OP_KC, g, defer);
 }
 
 GemmArgs dw_args(fsmg_model* h, int B) {      // dW = Hout^T * dlogits, dd = colsum(dlogits)
@@ -929,9 +1037,9 @@ GemmArgs dw_args(fsmg_model* h, int B) {      // dW = Hout^T * dlogits, dd = col
     g.colsum = h->G + h->off_d; g.ksplit = 1;
     return g;
 }
-int dw_gemm(fsmg_model* h, const Lane& ln, int B) {
+int dw_gemm(fsmg_model* h, const Lane& ln, int B, OpBatch* defer = nullptr) {
     ScopedTimer tm(h, "gemm_dw");
-    return gemm(h, ln, OP_XC, OP_XC, dw_args(h, B));
+    return gemm(h, ln, OP_XC, OP_XC, dw_args(h, B), defer);
 }
 
 // part 0: the whole pass; part 1: up to and including the projection gradients (dH, dW, dd: bucket 0 of the gradient exchange
@@ -967,8 +1075,19 @@ int backward(fsmg_model* h, int B, int part = 0) {
     // a collective kernel started in front of it only delays it; behind it the exchange of bucket 0 runs beside the
     // weight- / input-gradient GEMMs of the bottom layer, the embedding gradient and the norm
     const bool cut_late = cut && h->dp_split == 2 && part != 0;
+    bool dx_sq_done = false;
     PHASE(3);
+    // Slab sums of the split-K GEMMs ride in two launches per pass instead of one each: `fills` (issued right in front of a
+    // recurrent chain: what the chain reads -- dH -- plus the fills) and `late` (in front of the embedding gradient: every
+    // weight gradient + dx with its squared-norm partials).  Only the order that runs start to end on one stream in one call
+    // defers; the cut (episode-parallel) and overlapped orders keep a sum behind each GEMM.
+    const bool defer_ok = part == 0 && cut;
+    if (part != 2) h->arena_off = 0;
+    h->last_bwd_xcd = xcd;
     FillBatch fills(h);                     // embedding-gradient zero + the top layer's BPTT buffers: one launch
+    OpBatch late(h);
+    OpBatch* const d_now = defer_ok ? &fills : nullptr;
+    OpBatch* const d_late = defer_ok ? &late : nullptr;
     if (part != 2) GEMMCK(fills.add(h->G + h->off_emb, 0u, (long long)h->V1 * h->Ep));
     if (ov) GEMMCK(fills.flush());          // (two-stream order: the auxiliary stream forks right below)
     if (part == 2) {
@@ -997,8 +1116,8 @@ int backward(fsmg_model* h, int B, int part = 0) {
         GEMMCK(gemm_restricted(h, h->aux, OP_XC, OP_XC, gdw, xov_first_free(B), h->xov_ctl + fsmg_model::XOV_CTL, dw_limit));
         HIPCK(h, hipEventRecord(h->ev_join, h->aux));
     } else {
-        GEMMCK(dhout_chunk(h, mainl, B, 0, T));
-        GEMMCK(dw_gemm(h, mainl, B));
+        GEMMCK(dhout_chunk(h, mainl, B, 0, T, d_now));
+        GEMMCK(dw_gemm(h, mainl, B, d_late));
     }
     if (part == 1 && cut && !cut_late) return fills.flush();
     for (int l = h->L - 1; l >= 0; --l) {
@@ -1091,13 +1210,13 @@ int backward(fsmg_model* h, int B, int part = 0) {
             g.A = h->Hs[l]; g.lda = Hp; g.B = h->Z[l]; g.ldb = G4;
             g.C = h->G + h->off_kh[l]; g.ldc = G4; g.M = Hp; g.N = G4; g.K = (int)rows;
             g.colsum = h->G + h->off_b[l]; g.ksplit = 1;
-            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, g));
+            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, g, d_late));
             GemmArgs k{};                     // dKx = in^T * dZ
             if (l == 0) { k.A = h->P + h->off_emb; k.lda = h->Ep; k.gather = h->X; }
             else { k.A = h->Hs[l - 1] + (size_t)B * Hp; k.lda = Hp; }
             k.B = h->Z[l]; k.ldb = G4; k.C = h->G + h->off_kx[l]; k.ldc = G4;
             k.M = in_p; k.N = G4; k.K = (int)rows; k.ksplit = 1;
-            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, k));
+            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, k, d_late));
         }
         {
             ScopedTimer tm(h, "gemm_dx");     // d_in = dZ * Kx^T
@@ -1105,15 +1224,22 @@ int backward(fsmg_model* h, int B, int part = 0) {
             g.A = h->Z[l]; g.lda = G4; g.B = h->P + h->off_kx[l]; g.ldb = G4;
             g.C = (l == 0) ? h->dXemb : h->dH; g.ldc = in_p;
             g.M = (int)rows; g.N = in_p; g.K = G4; g.ksplit = 1;
-            GEMMCK(gemm(h, mainl, OP_KC, OP_KC, g));
+            // layer 0: the sum rides with the weight gradients' and leaves the squared-norm partials of dXemb behind;
+            // above: the layer below reads dH next, the sum goes out with that layer's fills
+            if (l == 0) GEMMCK(gemm(h, mainl, OP_KC, OP_KC, g, d_late, h->partials, &dx_sq_done));
+            else GEMMCK(gemm(h, mainl, OP_KC, OP_KC, g, d_now));
         }
     }
     {
         ScopedTimer tm(h, "embed_grad");
-        HIPCK(h, launch_embed_grad(s, h->X, (int)rows, h->dXemb, h->Ep, h->G + h->off_emb));
+        GEMMCK(late.flush());
+        HIPCK(h, launch_embed_grad(s, h->X, (int)rows, h->dXemb, h->Ep, h->G + h->off_emb, h->tok_first, h->tok_count));
+        h->tok_table_open = false;
         const int nb = sqnorm_blocks(rows * h->Ep);
-        HIPCK(h, launch_sqnorm_partials(s, h->dXemb, rows * h->Ep, h->partials));
-        HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0, h->d_err));   // + tail[2] / tail[3] = time-out / token-range indicators
+        if (!dx_sq_done) HIPCK(h, launch_sqnorm_partials(s, h->dXemb, rows * h->Ep, h->partials));
+        // tail[0] = squared norm of the embedding-slice gradients, tail[1] = mean loss of the pass, tail[2] / tail[3] = time-out /
+        // token-range indicators
+        HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0, h->d_err, h->ce, (int)rows, h->G + h->n_flat + 1));
     }
     if (ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));     // dW / dd landed
     PHASE(6);
@@ -1121,8 +1247,10 @@ int backward(fsmg_model* h, int B, int part = 0) {
     return FSMG_OK;
 }
 
-// K_h of every layer into the layouts the recurrent kernels read: one launch (up to REPACK_MAX_LAYERS layers)
-int repack_recurrent_weights(fsmg_model* h, hipStream_t s) {
+// K_h of every layer into the layouts the recurrent kernels read: one launch (up to REPACK_MAX_LAYERS layers).  inc != nullptr:
+// the launch also closes the train step (k_step_increment's work on one thread of it); *inc_done says whether it did.
+int repack_recurrent_weights(fsmg_model* h, hipStream_t s, const StepIncArgs* inc, bool* inc_done) {
+    if (inc_done) *inc_done = false;
     const bool x_ok = h->khx == nullptr || h->Hp == 512 || h->Hp == 1024;
     if (h->L <= REPACK_MAX_LAYERS && x_ok) {
         RepackAllArgs a{};
@@ -1133,7 +1261,8 @@ int repack_recurrent_weights(fsmg_model* h, hipStream_t s) {
             a.xf[l] = h->khx ? h->khx + (size_t)(2 * l) * lstm_xcd_weight_floats((int)h->Hp, h->xcd_bx3) : nullptr;
             a.xb[l] = h->khx ? h->khx + (size_t)(2 * l + 1) * lstm_xcd_weight_floats((int)h->Hp, h->xcd_bx3) : nullptr;
         }
-        HIPCK(h, launch_repack_kh_all(s, a));
+        HIPCK(h, launch_repack_kh_all(s, a, inc));
+        if (inc_done) *inc_done = inc != nullptr;
         return FSMG_OK;
     }
     for (int l = 0; l < h->L; ++l) {
@@ -1144,6 +1273,7 @@ int repack_recurrent_weights(fsmg_model* h, hipStream_t s) {
     }
     return FSMG_OK;
 }
+int repack_recurrent_weights(fsmg_model* h, hipStream_t s) { return repack_recurrent_weights(h, s, nullptr, nullptr); }
 
 int apply_update(fsmg_model* h, float grad_scale) {
     ScopedRange rng_("fsmg.clip+adam");
@@ -1160,8 +1290,13 @@ int apply_update(fsmg_model* h, float grad_scale) {
     a.grad_scale = grad_scale; a.lr = h->cfg.lr; a.n_decay = h->cfg.n_decay; a.clip = h->cfg.max_grad_norm;
     a.step = h->d_step; a.gnorm_out = h->d_gnorm; a.err_flag = h->d_err;
     HIPCK(h, launch_adam_update(s, a));
-    GEMMCK(repack_recurrent_weights(h, s));  // refresh the fragment-ordered recurrent weights
-    HIPCK(h, launch_step_increment(s, h->d_step, h->G + h->n_flat + 1, grad_scale, h->d_ring, RING_CAP, h->d_err, h->d_counters, h->d_inbox_dirty));
+    // refresh the fragment-ordered recurrent weights and close the step (ring[step] = loss, ++step, or the skip tallies) -- one launch
+    StepIncArgs inc{};
+    inc.step = h->d_step; inc.loss_src = h->G + h->n_flat + 1; inc.loss_scale = grad_scale; inc.ring = h->d_ring; inc.ring_cap = RING_CAP;
+    inc.err_flag = h->d_err; inc.counters = h->d_counters; inc.handoff_dirty = h->d_inbox_dirty; inc.clear_ok = h->last_bwd_xcd ? 1 : 0;
+    bool inc_done = false;
+    GEMMCK(repack_recurrent_weights(h, s, &inc, &inc_done));
+    if (!inc_done) HIPCK(h, launch_step_increment(s, inc));
     PHASE(7);
 #ifdef FSMG_PHASE_DEBUG
     phase_report(h);
@@ -1217,6 +1352,15 @@ void on_timeout(fsmg_model* h) {
         drop_graphs(h);
     }
     h->fallback_left = h->fallback_steps;
+    // the aborted pass may have left dh partials in the BPTT inboxes and nothing on the device is going to say so on the paths that
+    // end without k_step_increment (fsmg_maml_eval's adaptation, a forward-only pass): raise the refill flag from here.  Safe in
+    // stream order: the flag is only read by fills of LATER calls.
+    if (h->d_inbox_dirty) {
+        static const int one = 1;
+        hipStreamSynchronize(h->stream);
+        hipMemcpy(h->d_inbox_dirty, &one, sizeof(int), hipMemcpyHostToDevice);
+    }
+    h->tok_table_open = true;           // and the occurrence table may hold entries of a pass whose embed_grad was cut short
 }
 
 // Compares the host-mapped tallies of k_step_increment with what this handle has already seen (no synchronisation: the
@@ -1226,6 +1370,8 @@ int poll_skipped(fsmg_model* h) {
     if (!h->host_counters) return 0;
     const long long to = h->host_counters[0], tk = h->host_counters[1];
     int what = 0;
+    const long long pf = h->host_counters[2];
+    if (pf != h->seen_peer_failures) { h->seen_peer_failures = pf; what = 3; }
     if (tk != h->seen_token_errors) { h->seen_token_errors = tk; what = 1; }
     if (to != h->seen_timeouts) { h->seen_timeouts = to; on_timeout(h); what = 2; }
     return what;
@@ -1236,6 +1382,7 @@ int report(fsmg_model* h, int what) {
         return fail(h, FSMG_ERR_HIP, "persistent recurrent kernel timed out waiting for a peer block (blocks not co-resident); "
                                      "this handle now uses one launch per time step");
     if (what == 1) return fail(h, FSMG_ERR_TOKEN_RANGE, "token id outside [0, input_size)");
+    if (what == 3) return fail(h, FSMG_ERR_STATE, "a rank of the episode-parallel job failed before the gradient exchange: the step was skipped on every rank");
     return FSMG_OK;
 }
 
@@ -1289,6 +1436,8 @@ int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&
     if ((rc = ensure_scratch(h, B)) != FSMG_OK) return rc;
     choose_schedule(h, B, true);
     if ((rc = ensure_khf(h)) != FSMG_OK) return rc;
+    if (h->tok_table_open && (rc = reset_tok_table(h)) != FSMG_OK) return rc;     // a pass that never reached its embed_grad
+    h->tok_table_open = true;
     if ((rc = stage()) != FSMG_OK) return rc;
     const int n_sup = N * K, n_qry = N * Q;
     h->bucket0_recorded = false;
@@ -1297,7 +1446,7 @@ int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&
         // episode-parallel order: bucket 0 (softmax gradients, 56 % of the bytes at cfg-B) is final when the first graph ends and
         // travels while the second one (BPTT, weight / input gradients, embedding gradient) runs
         rc = run_graphed(h, "fb1:" + shape_key, [&]() -> int {
-            int r = token_prep(h, n_sup, n_qry);
+            int r = token_prep(h, n_sup, n_qry, true);
             if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1, true);
             if (r == FSMG_OK) r = backward(h, B, 1);
             return r;
@@ -1307,7 +1456,7 @@ int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&
         rc = run_graphed(h, "fb2:" + shape_key, [&]() -> int { return backward(h, B, 2); });
     } else {
         rc = run_graphed(h, (with_update ? "fbu:" : "fb:") + shape_key, [&]() -> int {
-            int r = token_prep(h, n_sup, n_qry);
+            int r = token_prep(h, n_sup, n_qry, true);
             if (r == FSMG_OK) r = forward(h, B, B, 1, h->G + h->n_flat + 1, true);
             if (r == FSMG_OK) r = backward(h, B);
             if (r == FSMG_OK && with_update) r = apply_update(h, 1.0f);
@@ -1315,12 +1464,17 @@ int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&
         });
     }
     if (rc != FSMG_OK) return rc;
+    h->tok_table_open = false;          // (a replayed graph ran its embed_grad too)
     // bucket readiness for an overlapped gradient exchange: with the two-stream (eager) schedule bucket 0 was
     // recorded right behind the dW GEMM on the aux stream; a replayed graph finishes as a whole
-    if (!h->bucket0_recorded) HIPCK(h, hipEventRecord(h->ev_bucket[0], h->stream));
-    HIPCK(h, hipEventRecord(h->ev_bucket[1], h->stream));
+    // (the fused single-GPU step has applied its update already: nobody waits for a bucket, and two event records between
+    // consecutive steps are ~10 us of queue time)
+    if (!with_update) {
+        if (!h->bucket0_recorded) HIPCK(h, hipEventRecord(h->ev_bucket[0], h->stream));
+        HIPCK(h, hipEventRecord(h->ev_bucket[1], h->stream));
+    }
     h->lastB = B;
-    h->have_grads = true;
+    h->have_grads = !with_update;
     return FSMG_OK;
 }
 
@@ -1330,7 +1484,7 @@ int after_update(fsmg_model* h, float grad_scale, float* loss) {
     // no read-back: skipped steps of EARLIER calls that have retired by now are noticed here (a time-out switches the
     // handle to per-step launches; the skipped episodes stay skipped -- fsmg_get_stats counts them)
     const int what = poll_skipped(h);
-    if (what == 1) return report(h, 1);
+    if (what == 1 || what == 3) return report(h, what);
     return FSMG_OK;
 }
 
@@ -1396,13 +1550,24 @@ template <class FB>
 int dp_train_step(fsmg_model* h, float* loss, FB&& forward_backward) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         int rc = forward_backward();
-        if (rc == FSMG_OK) rc = exchange_gradients(h);
+        int local_rc = FSMG_OK; std::string local_msg;
+        if (rc != FSMG_OK) {
+            // A failure on THIS rank's host (an allocation, a launch) must not leave the peers blocked in ncclAllReduce: join the
+            // collectives with the "this rank's gradients are garbage" indicator raised (tail[4]; summed like the time-out and
+            // token-range indicators), so that every rank skips the update and every rank's step ends -- then report the failure.
+            local_rc = rc; local_msg = h->err;
+            if (launch_fill32(h->stream, h->G + h->n_flat + 4, 0x3f800000u, 1) != hipSuccess) return local_rc;     // 1.0f
+            if (hipEventRecord(h->ev_bucket[0], h->stream) != hipSuccess || hipEventRecord(h->ev_bucket[1], h->stream) != hipSuccess) return local_rc;
+            h->have_grads = true;
+        }
+        rc = exchange_gradients(h);
         const float scale = 1.0f / (float)h->world;
         if (rc == FSMG_OK) {
             uint32_t bits; std::memcpy(&bits, &scale, 4);
-            rc = run_graphed(h, "up:" + std::to_string(bits), [&]() -> int { return apply_update(h, scale); });
+            rc = run_graphed(h, "up:" + std::to_string(bits) + (h->last_bwd_xcd ? "x" : "s"), [&]() -> int { return apply_update(h, scale); });
         }
         if (rc == FSMG_OK) rc = after_update(h, scale, loss);
+        if (local_rc != FSMG_OK) { h->err = local_msg; return local_rc; }
         // a time-out on ANY rank travelled in the reduced tail: every rank skipped the update, reports it here and repeats the
         // step on per-step launches, in lock-step
         if (rc == FSMG_ERR_HIP && h->persist_timed_out && attempt == 0) { h->persist_timed_out = false; continue; }
@@ -1503,6 +1668,8 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_XOV_DW_SPLIT")) h->xov_dw_split = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("FSMG_XOV_DW_SHARE")) h->xov_dw_share = std::max(0, std::min(100, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_XOV_BLOCKS")) h->xov_blocks = std::max(1, std::min(4, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_EAGER")) h->eager = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_FILL_EARLY")) h->fill_early = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
         h->persist_cfg = h->persist;
         if (const char* e = std::getenv("FSMG_FALLBACK_STEPS")) h->fallback_steps = std::max(1, std::atoi(e));
@@ -1550,7 +1717,9 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     if (hipMemsetAsync(h->state, 0, sb, h->stream) != hipSuccess) return bail(FSMG_ERR_HIP, "memset(state) failed");
 
     char* small = nullptr;
-    const size_t small_bytes = 256 * 4 + sizeof(float) * RING_CAP + sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES + sizeof(int) * 2 * fsmg_model::XOV_CTL;
+    const size_t tok_words = (size_t)round_up(h->V1, 64);
+    const size_t small_bytes = 256 * 4 + sizeof(float) * RING_CAP + sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES + sizeof(int) * 2 * fsmg_model::XOV_CTL +
+                               sizeof(int) * 2 * tok_words;
     if (hipMalloc((void**)&small, small_bytes) != hipSuccess) return bail(FSMG_ERR_NOMEM, "hipMalloc(scalars) failed");
     hipMemsetAsync(small, 0, small_bytes, h->stream);
     h->d_step = (long long*)small; h->d_err = (int*)(small + 256); h->d_gnorm = (float*)(small + 512);
@@ -1563,6 +1732,8 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     std::memset(h->host_counters, 0, 64);
     h->tickets = (int*)(small + 1024 + sizeof(float) * RING_CAP);
     h->xov_ctl = h->tickets + 8 * fsmg_model::TICKET_LAUNCHES;
+    h->tok_first = h->xov_ctl + 2 * fsmg_model::XOV_CTL; h->tok_count = h->tok_first + tok_words;
+    if (reset_tok_table(h) != FSMG_OK) return bail(FSMG_ERR_HIP, "fill of the token occurrence table failed");
 
     // decode scratch: per layer h ping/pong + c, plus x and argmax block scratch
     {
@@ -1744,6 +1915,7 @@ static int stage_indexed(fsmg_handle h, int32_t table_id, const int32_t* sup_idx
     if (n_sup > 0) HIPCK(h, hipMemcpyAsync(h->d_idx, sup_idx, sizeof(int) * n_sup, hipMemcpyHostToDevice, h->stream));
     if (n_qry > 0) HIPCK(h, hipMemcpyAsync(h->d_idx + n_sup, qry_idx, sizeof(int) * n_qry, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, launch_gather_rows(h->stream, h->table[table_id], h->d_idx, n, h->T, (int)h->table_rows[table_id], h->d_tok, h->d_err));
+    h->cur_sup = h->d_tok; h->cur_qry = h->d_tok + (size_t)n_sup * h->T;
     return FSMG_OK;
 }
 
@@ -1788,7 +1960,7 @@ int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss) {
     if (!h->have_grads) return fail(h, FSMG_ERR_STATE, "fsmg_apply_update without a preceding fsmg_forward_backward");
     if (!(grad_scale > 0.f)) return fail(h, FSMG_ERR_INVALID, "grad_scale must be > 0");
     uint32_t bits; std::memcpy(&bits, &grad_scale, 4);
-    int rc = run_graphed(h, "up:" + std::to_string(bits), [&]() -> int { return apply_update(h, grad_scale); });
+    int rc = run_graphed(h, "up:" + std::to_string(bits) + (h->last_bwd_xcd ? "x" : "s"), [&]() -> int { return apply_update(h, grad_scale); });
     if (rc != FSMG_OK) return rc;
     return after_update(h, grad_scale, loss);
 }
@@ -2038,11 +2210,155 @@ int fsmg_get_stats(fsmg_handle h, fsmg_stats* out) {
     out->timeouts = h->n_timeouts;
     out->steps_skipped_timeout = h->host_counters ? h->host_counters[0] : 0;
     out->steps_skipped_token_range = h->host_counters ? h->host_counters[1] : 0;
+    out->steps_skipped_peer_failure = h->host_counters ? h->host_counters[2] : 0;
     out->xcd_launches = h->n_xcd_launches;
     out->persistent_launches = h->n_persist_launches;
     out->step_launches = h->n_step_launches;
     out->persistent_path = h->persist ? 1 : 0;
     out->fallback_steps_left = h->fallback_left;
+    return FSMG_OK;
+}
+
+int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value) {
+    if (!h || !what) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->aux) HIPCK(h, hipStreamSynchronize(h->aux));
+    if (!std::strcmp(what, "chain_spin_limit")) h->chain_spin_limit = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
+    else if (!std::strcmp(what, "fallback_steps")) h->fallback_steps = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 30));
+    else if (!std::strcmp(what, "eager")) h->eager = value != 0;
+    else if (!std::strcmp(what, "persistent")) { h->persist = h->persist_cfg = value != 0; h->fallback_left = 0; }
+    else return fail(h, FSMG_ERR_NAME, std::string("unknown knob '") + what + "'");
+    drop_graphs(h);
+    return FSMG_OK;
+}
+
+// ---- unigram baseline
+struct fsmg_unigram {
+    int V = 0, device = 0;
+    hipStream_t stream = nullptr;
+    unsigned* counts = nullptr;
+    int* words = nullptr; int64_t words_cap = 0;
+    float* out = nullptr;           // [0] nll, [1] sum of counts; then an int: argmax; then an int: error flag
+    std::string err;
+};
+namespace {
+int ufail(fsmg_unigram* u, int code, const std::string& msg) { if (u) u->err = msg; else g_create_error = msg; return code; }
+#define UCK(u, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return ufail(u, FSMG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+int unigram_stage(fsmg_unigram* u, const int32_t* words, int64_t n, int on_device, const int** dev) {
+    if (on_device) { *dev = words; return FSMG_OK; }
+    if (u->words_cap < n) {
+        UCK(u, hipStreamSynchronize(u->stream));
+        if (u->words) hipFree(u->words);
+        u->words = nullptr; u->words_cap = 0;
+        const int64_t cap = std::max<int64_t>(n, 1 << 16);
+        if (hipMalloc((void**)&u->words, sizeof(int) * (size_t)cap) != hipSuccess) return ufail(u, FSMG_ERR_NOMEM, "hipMalloc(words) failed");
+        u->words_cap = cap;
+    }
+    UCK(u, hipMemcpyAsync(u->words, words, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, u->stream));
+    *dev = u->words;
+    return FSMG_OK;
+}
+int unigram_read(fsmg_unigram* u, float* nll) {
+    float host[4] = {0.f, 0.f, 0.f, 0.f};
+    UCK(u, hipMemcpyAsync(host, u->out, sizeof(host), hipMemcpyDeviceToHost, u->stream));
+    UCK(u, hipStreamSynchronize(u->stream));
+    int flag; std::memcpy(&flag, &host[3], 4);
+    if (flag != 0) {
+        UCK(u, hipMemsetAsync(u->out + 3, 0, 4, u->stream));
+        return ufail(u, FSMG_ERR_TOKEN_RANGE, "word id outside [0, input_size)");
+    }
+    if (nll) *nll = host[0];
+    return FSMG_OK;
+}
+}  // namespace
+
+int fsmg_unigram_create(int32_t input_size, int32_t device, fsmg_unigram_handle* out) {
+    if (!out || input_size <= 0) return ufail(nullptr, FSMG_ERR_INVALID, "bad input_size / out");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ufail(nullptr, FSMG_ERR_NO_DEVICE, "no HIP device visible: libfsmg has no CPU fallback");
+    if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return ufail(nullptr, FSMG_ERR_NO_DEVICE, "device ordinal out of range");
+    fsmg_unigram* u = new (std::nothrow) fsmg_unigram();
+    if (!u) return ufail(nullptr, FSMG_ERR_NOMEM, "host allocation failed");
+    u->V = input_size; u->device = device;
+    if (hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&u->counts, sizeof(unsigned) * (size_t)input_size) != hipSuccess ||
+        hipMalloc((void**)&u->out, 256) != hipSuccess) { fsmg_unigram_destroy(u); return ufail(nullptr, FSMG_ERR_NOMEM, "device allocation failed"); }
+    hipMemsetAsync(u->out, 0, 256, u->stream);
+    if (launch_fill32(u->stream, u->counts, 1u, input_size) != hipSuccess || hipStreamSynchronize(u->stream) != hipSuccess) {     // alpha = 1
+        fsmg_unigram_destroy(u); return ufail(nullptr, FSMG_ERR_HIP, "count initialisation failed");
+    }
+    *out = u;
+    return FSMG_OK;
+}
+int fsmg_unigram_destroy(fsmg_unigram_handle u) {
+    if (!u) return FSMG_OK;
+    hipSetDevice(u->device);
+    if (u->stream) hipStreamSynchronize(u->stream);
+    if (u->counts) hipFree(u->counts);
+    if (u->words) hipFree(u->words);
+    if (u->out) hipFree(u->out);
+    if (u->stream) hipStreamDestroy(u->stream);
+    delete u;
+    return FSMG_OK;
+}
+const char* fsmg_unigram_last_error(fsmg_unigram_handle u) { return u ? u->err.c_str() : g_create_error.c_str(); }
+int fsmg_unigram_nll(fsmg_unigram_handle u, const int32_t* words, int64_t n, int32_t on_device, float* nll) {
+    if (!u || !words || n <= 0 || !nll) return FSMG_ERR_INVALID;
+    hipSetDevice(u->device);
+    const int* dev = nullptr;
+    int rc = unigram_stage(u, words, n, on_device, &dev);
+    if (rc != FSMG_OK) return rc;
+    UCK(u, launch_unigram_nll(u->stream, dev, n, u->counts, u->V, u->out, (int*)(u->out + 3)));
+    return unigram_read(u, nll);
+}
+int fsmg_unigram_train(fsmg_unigram_handle u, const int32_t* words, int64_t n, int32_t on_device, float* loss) {
+    if (!u || !words || n <= 0) return FSMG_ERR_INVALID;
+    hipSetDevice(u->device);
+    const int* dev = nullptr;
+    int rc = unigram_stage(u, words, n, on_device, &dev);
+    if (rc != FSMG_OK) return rc;
+    // the loss with the counts BEFORE the update, like LSTMBaseline.train's pre-update loss; a batch with an id out of range
+    // is rejected as a whole (the NLL kernel has seen every word before the update runs)
+    UCK(u, launch_unigram_nll(u->stream, dev, n, u->counts, u->V, u->out, (int*)(u->out + 3)));
+    float l = 0.f;
+    rc = unigram_read(u, &l);
+    if (rc != FSMG_OK) return rc;
+    UCK(u, launch_unigram_update(u->stream, dev, n, u->counts, u->V, (int*)(u->out + 3)));
+    if (!on_device) UCK(u, hipStreamSynchronize(u->stream));      // the staging buffer may be reused by the next call
+    if (loss) *loss = l;
+    return FSMG_OK;
+}
+int fsmg_unigram_get_counts(fsmg_unigram_handle u, float* host, int64_t count) {
+    if (!u || !host || count != u->V) return FSMG_ERR_INVALID;
+    hipSetDevice(u->device);
+    std::vector<unsigned> tmp((size_t)count);
+    UCK(u, hipStreamSynchronize(u->stream));
+    UCK(u, hipMemcpy(tmp.data(), u->counts, sizeof(unsigned) * (size_t)count, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < count; ++i) host[i] = (float)tmp[(size_t)i];
+    return FSMG_OK;
+}
+int fsmg_unigram_set_counts(fsmg_unigram_handle u, const float* host, int64_t count) {
+    if (!u || !host || count != u->V) return FSMG_ERR_INVALID;
+    hipSetDevice(u->device);
+    std::vector<unsigned> tmp((size_t)count);
+    for (int64_t i = 0; i < count; ++i) {
+        if (!(host[i] >= 0.f) || host[i] > 4.0e9f) return ufail(u, FSMG_ERR_INVALID, "counts must be finite and >= 0");
+        tmp[(size_t)i] = (unsigned)std::llround((double)host[i]);
+    }
+    UCK(u, hipStreamSynchronize(u->stream));
+    UCK(u, hipMemcpy(u->counts, tmp.data(), sizeof(unsigned) * (size_t)count, hipMemcpyHostToDevice));
+    return FSMG_OK;
+}
+int fsmg_unigram_argmax(fsmg_unigram_handle u, int32_t* word) {
+    if (!u || !word) return FSMG_ERR_INVALID;
+    hipSetDevice(u->device);
+    UCK(u, launch_unigram_argmax(u->stream, u->counts, u->V, (int*)(u->out + 2)));
+    int w = 0;
+    UCK(u, hipMemcpyAsync(&w, u->out + 2, sizeof(int), hipMemcpyDeviceToHost, u->stream));
+    UCK(u, hipStreamSynchronize(u->stream));
+    *word = w;
     return FSMG_OK;
 }
 

@@ -200,18 +200,25 @@ int lstm_xcd_packed_rows(int B);               // rows per XCD that leave whole 
 hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp = 512, bool bx3 = false);
 // all layers, both layouts, one launch: Kh[l] -> cf / cb (launch_repack_kh) and, where xf[l] != nullptr, xf / xb (launch_repack_kh_xcd)
 constexpr int REPACK_MAX_LAYERS = 4;
+struct StepIncArgs;
 struct RepackAllArgs { int n; int Hp; const float* Kh[REPACK_MAX_LAYERS]; float* cf[REPACK_MAX_LAYERS]; float* cb[REPACK_MAX_LAYERS]; float* xf[REPACK_MAX_LAYERS]; float* xb[REPACK_MAX_LAYERS];
                        int bx3; /* hidden 512: the XCD images as three bf16 planes (k_lstm_*_xcd16) */ };
-hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a);
+// inc != nullptr: thread 0 of block (0, 0) also closes the train step (step_increment_body: the repack is the last kernel of a step)
+hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a, const StepIncArgs* inc = nullptr);
 hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a);
 hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);
 
 // ---------------------------------------------------------------- everything else (elementwise.hip)
-// up to FILL_MAX_RANGES 32-bit pattern fills in ONE launch (each p 16-byte aligned)
-constexpr int FILL_MAX_RANGES = 16;
-// cond[k] != nullptr: range k is filled only when *cond[k] != 0 (read on the device when the launch runs)
-struct FillRanges { uint32_t* p[FILL_MAX_RANGES]; uint32_t word[FILL_MAX_RANGES]; long long n[FILL_MAX_RANGES]; const int* cond[FILL_MAX_RANGES]; int count; };
-hipError_t launch_fill_multi(hipStream_t s, const FillRanges& r);
+// up to MULTI_MAX_OPS small memory passes in ONE launch (every pointer 16-byte aligned):
+//   MULTI_FILL    dst[0 .. n) = word (32-bit pattern); cond != nullptr: only when *cond != 0 (read on the device when the launch runs)
+//   MULTI_REDUCE  dst[i] = sum_z src[z * stride + i] for i < n, slabs added in order z = 0 .. nslab - 1 (deterministic split-K);
+//                 sq != nullptr: also the squared-norm partials of dst, one double per SQ_CHUNK (= sqnorm_blocks) elements, bit-equal
+//                 to launch_sqnorm_partials(dst, n, sq)
+enum { MULTI_FILL = 0, MULTI_REDUCE = 1 };
+constexpr int MULTI_MAX_OPS = 16;
+struct MultiOp { int kind; void* dst; const void* src; long long n; long long stride; int nslab; uint32_t word; const int* cond; double* sq; };
+struct MultiOps { MultiOp op[MULTI_MAX_OPS]; int count; };
+hipError_t launch_multi_op(hipStream_t s, const MultiOps& r);
 // out[r][0..T) = table[idx[r]][0..T) for r < n_rows (device-resident split table -> the token staging buffer)
 hipError_t launch_gather_rows(hipStream_t s, const int* table, const int* idx, int n_rows, int T, int n_songs, int* out, int* err_flag);
 // p[0 .. n_words) = word (p 16-byte aligned); the step uses this instead of hipMemsetAsync so that its hipGraph holds kernel nodes only
@@ -220,8 +227,10 @@ hipError_t launch_fill32(hipStream_t s, void* p, uint32_t word, long long n_word
 hipError_t launch_fill32_if(hipStream_t s, const int* cond, void* p, uint32_t word, long long n_words);
 // tokens [nseq][T] (support rows then query rows) -> time-major input ids X[t][b] (start word at t=0)
 // and targets Y[t][b]; sets *err_flag if any id is outside [0, vocab).
+// tok_first / tok_count != nullptr (train passes): also the occurrence table of the input ids for launch_embed_grad -- first
+// position (atomicMin) and count per token; both arrays [vocab + 1], (INT_MAX, 0) before the launch
 hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, const int* query, int n_query,
-                             int T, int vocab, int start_word, int* X, int* Y, int* err_flag);
+                             int T, int vocab, int start_word, int* X, int* Y, int* err_flag, int* tok_first = nullptr, int* tok_count = nullptr);
 // per logits row: lse and cross entropy against the target; dlogits != nullptr also materialises
 // (softmax - onehot) * inv_n (pad columns zero) for the backward projection GEMMs
 hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt,
@@ -232,7 +241,9 @@ hipError_t launch_ce_combine(hipStream_t s, const float2* part, int nparts, cons
 hipError_t launch_loss_reduce(hipStream_t s, const float* ce, int T, int B, int rows_per_group, int ngroups,
                               float* out);
 // dEmb[tok] = sum over occurrences r (increasing r) of dX[r]; dEmb must be zero-filled before
-hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX, int Ep, float* dEmb);
+// tok_first / tok_count: the occurrence table launch_token_prep filled for this X (nullptr: every block scans for duplicates);
+// the owners put their entries back to (INT_MAX, 0)
+hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX, int Ep, float* dEmb, int* tok_first = nullptr, int* tok_count = nullptr);
 // partial sums of squares (double) of x[0..n) into partials[pofs .. pofs+nblocks); returns nblocks via out param
 int sqnorm_blocks(long long n);
 hipError_t launch_sqnorm_partials(hipStream_t s, const float* x, long long n, double* partials);
@@ -240,7 +251,7 @@ hipError_t launch_sqnorm_partials(hipStream_t s, const float* x, long long n, do
 struct UpdateArgs {
     float* p; float* m; float* v; const float* g; long long n;   // flat buffers
     const double* partials; int n_partials;       // squared-norm partials of everything that counts
-    const float* tail;                            // grad tail scalars (tail[0] = slices_sq, used when slices; tail[2] / tail[3] != 0: no update)
+    const float* tail;                            // grad tail scalars (tail[0] = slices_sq, used when slices; tail[2] / tail[3] / tail[4] != 0: no update)
     int use_slices;                               // add tail[0]*grad_scale^2 to the norm
     float grad_scale;                             // 1/world (g is a SUM over ranks)
     float lr, n_decay, clip;
@@ -254,10 +265,41 @@ hipError_t launch_sgd_update(hipStream_t s, const UpdateArgs& a);
 // last kernel of a train step: counts the step (ring[step % cap] = loss, ++step) or, when *err_flag != 0 or the
 // all-reduced time-out indicator tail[2] is set, tallies it in counters ([0] time-outs, [1] token-range rejections;
 // host-mapped memory) and clears the flag
-hipError_t launch_step_increment(hipStream_t s, long long* step, const float* loss_src, float loss_scale,
-                                 float* loss_ring, int ring_cap, int* err_flag, long long* counters, int* handoff_dirty = nullptr);
+// handoff_dirty (the "refill the BPTT inboxes" flag) is sticky: set when *err_flag == 2, cleared only when clear_ok != 0 (the
+// step ran an XCD-local BPTT pass, which did the conditional refill) and nothing timed out
+struct StepIncArgs { long long* step; const float* loss_src; float loss_scale; float* ring; int ring_cap; int* err_flag; long long* counters;
+                     int* handoff_dirty; int clear_ok; };
+__device__ __forceinline__ void step_increment_body(const StepIncArgs& a) {
+    const int e = a.err_flag != nullptr ? *a.err_flag : 0;
+    if (a.handoff_dirty != nullptr) {
+        if (e == 2) *a.handoff_dirty = 1;
+        else if (a.clear_ok) *a.handoff_dirty = 0;
+    }
+    const bool peer_timeout = a.loss_src != nullptr && a.loss_src[1] != 0.0f;      // loss_src is tail[1]; tail[2] is the indicator
+    const bool peer_token = a.loss_src != nullptr && a.loss_src[2] != 0.0f;        // tail[3]: some rank's batch held an out-of-range id
+    const bool peer_failed = a.loss_src != nullptr && a.loss_src[3] != 0.0f;       // tail[4]: some rank's pass failed on the host before the exchange
+    if (e != 0 || peer_timeout || peer_token || peer_failed) {
+        if (a.counters != nullptr) {
+            if (e == 2 || peer_timeout) a.counters[0] += 1; else if (e == 1 || peer_token) a.counters[1] += 1; else a.counters[2] += 1;
+            __threadfence_system();
+        }
+        if (a.err_flag != nullptr) *a.err_flag = 0;
+        return;
+    }
+    const long long s = *a.step;
+    if (a.ring != nullptr && a.loss_src != nullptr) a.ring[s % a.ring_cap] = *a.loss_src * a.loss_scale;
+    *a.step = s + 1;
+}
+hipError_t launch_step_increment(hipStream_t s, const StepIncArgs& a);
 // dst[0] = (float) sum of partials[0..n) (fixed order)
-hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst, const int* flag_src = nullptr);
+// ce != nullptr: also *loss_out = sum(ce[0 .. ce_n)) / (ce_n + 1e-12) -- launch_loss_reduce with one group, same bits
+hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst, const int* flag_src = nullptr,
+                               const float* ce = nullptr, int ce_n = 0, float* loss_out = nullptr);
+// unigram baseline (reference src/models/unigram_model.py:26-39): counts[w] += 1 per word; out[0] = -mean(log(count[w] / sum(counts))),
+// out[1] = sum(counts); *out = argmax (lowest index on ties).  *err_flag |= 1 for a word outside [0, vocab)
+hipError_t launch_unigram_update(hipStream_t s, const int* words, long long n, unsigned* counts, int vocab, int* err_flag);
+hipError_t launch_unigram_nll(hipStream_t s, const int* words, long long n, const unsigned* counts, int vocab, float* out, int* err_flag);
+hipError_t launch_unigram_argmax(hipStream_t s, const unsigned* counts, int vocab, int* out);
 // greedy decode step pieces (sample)
 hipError_t launch_decode_cell(hipStream_t s, const float* Kx, int in_dim, const float* Kh, const float* bias,
                               const float* x, const float* h_in, float* h_out, float* c, int Hp);

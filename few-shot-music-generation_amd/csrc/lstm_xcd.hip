@@ -1715,7 +1715,8 @@ __global__ void k_repack_kh_pair(const float* __restrict__ Kh, float* __restrict
 // every layer's K_h into every layout the recurrent kernels read, ONE launch (blockIdx.y = 2 * layer + {0: the column-split
 // kernels' fragment order, 1: the XCD / XCD-pair register image}): the four repacks of a two-layer model were 56 us of a
 // 2.85 ms cfg-C step as separate launches
-__global__ void k_repack_kh_all(const RepackAllArgs a) {
+__global__ void k_repack_kh_all(const RepackAllArgs a, const StepIncArgs inc) {
+    if (inc.step != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_increment_body(inc);
     const int l = blockIdx.y >> 1, kind = blockIdx.y & 1;
     if (kind == 0) { repack_kh_chunked(a.Kh[l], a.cf[l], a.cb[l], a.Hp, blockIdx.x, gridDim.x); return; }
     if (a.xf[l] == nullptr) return;
@@ -1726,14 +1727,15 @@ __global__ void k_repack_kh_all(const RepackAllArgs a) {
 
 }  // namespace
 
-hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a) {
+hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a, const StepIncArgs* inc) {
     if (a.n <= 0) return hipSuccess;
     if (a.n > REPACK_MAX_LAYERS) return hipErrorInvalidValue;
     for (int l = 0; l < a.n; ++l) if (a.xf[l] != nullptr && !(a.Hp == XH || a.Hp == PH)) return hipErrorInvalidValue;
     const long long total = (long long)a.Hp * 4 * a.Hp / 4;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
     if (a.bx3 && a.Hp != XH) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_repack_kh_all, dim3(blocks, 2 * a.n), dim3(256), 0, s, a);
+    StepIncArgs none{};
+    hipLaunchKernelGGL(k_repack_kh_all, dim3(blocks, 2 * a.n), dim3(256), 0, s, a, inc ? *inc : none);
     return hipGetLastError();
 }
 

@@ -40,7 +40,7 @@ class FsmgConfig(C.Structure):
 class FsmgStats(C.Structure):
     _fields_ = [('timeouts', C.c_int64), ('steps_skipped_timeout', C.c_int64), ('steps_skipped_token_range', C.c_int64),
                 ('xcd_launches', C.c_int64), ('persistent_launches', C.c_int64), ('step_launches', C.c_int64),
-                ('persistent_path', C.c_int32), ('fallback_steps_left', C.c_int32)]
+                ('persistent_path', C.c_int32), ('fallback_steps_left', C.c_int32), ('steps_skipped_peer_failure', C.c_int64)]
 
 
 _P = C.c_void_p
@@ -88,6 +88,15 @@ SIGNATURES = {
     'fsmg_get_stats': (C.c_int, [_P, C.POINTER(FsmgStats)]),
     'fsmg_debug_read': (C.c_int, [_P, C.c_char_p, _F32P, C.c_int64]),
     'fsmg_debug_dims': (C.c_int, [_P, _I32P]),
+    'fsmg_debug_set': (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    'fsmg_unigram_create': (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_P)]),
+    'fsmg_unigram_destroy': (C.c_int, [_P]),
+    'fsmg_unigram_last_error': (C.c_char_p, [_P]),
+    'fsmg_unigram_nll': (C.c_int, [_P, _P, C.c_int64, C.c_int32, _F32P]),
+    'fsmg_unigram_train': (C.c_int, [_P, _P, C.c_int64, C.c_int32, _F32P]),
+    'fsmg_unigram_get_counts': (C.c_int, [_P, _F32P, C.c_int64]),
+    'fsmg_unigram_set_counts': (C.c_int, [_P, _F32P, C.c_int64]),
+    'fsmg_unigram_argmax': (C.c_int, [_P, _I32P]),
     'fsmg_debug_step_profile': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint64), C.c_int64, _I32P, _I32P]),
     'fsmg_timing_enable': (C.c_int, [_P, C.c_int32]),
     'fsmg_timing_select': (C.c_int, [_P, C.c_char_p]),
@@ -413,6 +422,10 @@ class FsmgModel(object):
         self._ck(self._lib.fsmg_debug_dims(self._h, d))
         return dict(Ep=d[0], Hp=d[1], V1p=d[2], B=d[3], T=d[4])
 
+    def debug_set(self, what, value):
+        """run-time knob of the handle (include/fsmg.h: chain_spin_limit, fallback_steps, eager)"""
+        self._ck(self._lib.fsmg_debug_set(self._h, what.encode(), int(value)))
+
     def debug_read(self, what, count):
         out = np.empty(int(count), np.float32)
         self._ck(self._lib.fsmg_debug_read(self._h, what.encode(), _f32p(out), out.size))
@@ -439,3 +452,67 @@ class FsmgModel(object):
         ms, n = C.c_double(), C.c_int64()
         self._ck(self._lib.fsmg_timing_read(self._h, kernel_class.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class FsmgUnigram(object):
+    """Device-resident unigram counts (include/fsmg.h fsmg_unigram_*): the graph of the reference's UnigramModel
+    (/root/reference/src/models/unigram_model.py:26-39) -- scatter_add histogram, gather / reduce_sum, -mean(log)."""
+
+    def __init__(self, input_size, device=0):
+        self._lib = load_library()
+        self.input_size = int(input_size)
+        handle = _P()
+        rc = self._lib.fsmg_unigram_create(self.input_size, int(device), C.byref(handle))
+        if rc != 0:
+            raise FsmgError(rc, self._lib.fsmg_unigram_last_error(None).decode())
+        self._h = handle
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise FsmgError(rc, self._lib.fsmg_unigram_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.fsmg_unigram_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _words(words):
+        if isinstance(words, tuple):                  # (device address, count)
+            return C.c_void_p(int(words[0])), int(words[1]), 1, None
+        a = np.ascontiguousarray(words, dtype=np.int32).ravel()
+        return C.c_void_p(a.ctypes.data), a.size, 0, a
+
+    def nll(self, words):
+        ptr, n, dev, keep = self._words(words)
+        out = C.c_float()
+        self._ck(self._lib.fsmg_unigram_nll(self._h, ptr, n, dev, C.byref(out)))
+        return float(out.value)
+
+    def train(self, words, want_loss=True):
+        ptr, n, dev, keep = self._words(words)
+        out = C.c_float()
+        self._ck(self._lib.fsmg_unigram_train(self._h, ptr, n, dev, C.byref(out) if want_loss else None))
+        return float(out.value) if want_loss else None
+
+    def get_counts(self):
+        out = np.empty(self.input_size, np.float32)
+        self._ck(self._lib.fsmg_unigram_get_counts(self._h, _f32p(out), out.size))
+        return out
+
+    def set_counts(self, counts):
+        a = np.ascontiguousarray(counts, dtype=np.float32)
+        if a.size != self.input_size:
+            raise ValueError('counts must have input_size entries')
+        self._ck(self._lib.fsmg_unigram_set_counts(self._h, _f32p(a), a.size))
+
+    def argmax(self):
+        w = C.c_int32()
+        self._ck(self._lib.fsmg_unigram_argmax(self._h, C.byref(w)))
+        return int(w.value)

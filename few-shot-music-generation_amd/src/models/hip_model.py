@@ -107,8 +107,14 @@ class HIPModel(BaseModel):
         """Every rank of an initialised torch.distributed job: rank 0's ncclUniqueId travels through the job's own store, each
         rank joins with ncclCommInitRank, and from then on train steps are ONE library call per rank -- PyTorch is left with
         the memory (model config key `dp_exchange: 'library'`)."""
+        import os
         import torch.distributed as dist
         world, rank = dist.get_world_size(), dist.get_rank()
+        if world > 1 and os.environ.get('FSMG_ALLOW_LIBRARY_RCCL', '0') != '1':
+            # EXPERIMENTAL: no box with two GPUs has run this path yet (tests/test_dist_hip.py covers it with one rank, and with
+            # two as soon as two devices are visible); the torch-issued exchange is the tested default
+            raise RuntimeError("dp_exchange: 'library' (RCCL calls issued by libfsmg) has not run with more than one rank yet; "
+                               "set FSMG_ALLOW_LIBRARY_RCCL=1 to use it, or keep dp_exchange: 'torch'")
         ids = [FsmgModel.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         self._model.comm_init(ids[0], world, rank)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FSMG_VERSION 300 /* 0.3.0 */
+#define FSMG_VERSION 400 /* 0.4.0 */
 #define FSMG_CONFIG_VERSION 3 /* layout of struct fsmg_config; fsmg_create rejects any other value in .config_version */
 
 enum {
@@ -51,8 +51,9 @@ enum {
 };
 
 enum { FSMG_CLIP_TF1_SLICES = 0, FSMG_CLIP_DENSE = 1 };
-/* arithmetic of the dense contractions: AUTO = BX3 (fp32 products assembled exactly from bf16 pieces on the bf16 matrix pipe,
- * fp32 accumulation: DESIGN.md section 4); F32 = v_mfma_f32_32x32x2_f32 */
+/* arithmetic of the dense contractions: AUTO = BX3 (every operand split exactly into three bf16 pieces, the six partial products
+ * >= 2^-23 of the fp32 product summed on the bf16 matrix pipe: each product to within half an fp32 ulp, fp32 accumulation:
+ * DESIGN.md section 4); F32 = v_mfma_f32_32x32x2_f32 */
 enum { FSMG_GEMM_AUTO = 0, FSMG_GEMM_BX3 = 1, FSMG_GEMM_F32 = 2 };
 /* order of a pass: AUTO picks from the shapes; SINGLE_STREAM = one hipGraph per pass; TWO_STREAM = projection GEMMs on an
  * auxiliary stream beside the recurrence (eager); XCD_PARTITIONED = recurrence packed on six XCDs, work-queue GEMMs on the rest */
@@ -149,7 +150,9 @@ int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* 
  * fsmg_apply_update then leaves parameters, Adam state and step counter alone on every rank and, when it reads the
  * loss back, returns FSMG_ERR_HIP after switching the handle to one launch per time step -- repeat the step;
  * [3] = non-zero when this rank's batch held a token id outside [0, input_size): summed like [2], so EVERY rank skips the
- * update (replicas stay identical) and every rank's read-back returns FSMG_ERR_TOKEN_RANGE */
+ * update (replicas stay identical) and every rank's read-back returns FSMG_ERR_TOKEN_RANGE;
+ * [4] = non-zero when this rank's pass failed on the host before the exchange (library-owned exchange: the rank still joins
+ * the collectives so that no peer blocks): every rank skips the update, peers' read-backs return FSMG_ERR_STATE */
 #define FSMG_GRAD_TAIL 16
 int fsmg_grad_buffer(fsmg_handle h, void** device_ptr, int64_t* count);
 int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss);
@@ -221,6 +224,25 @@ int fsmg_maml_eval(fsmg_handle h, const int32_t* support, const int32_t* query, 
  * `num` tokens from the start word and a zero state (the support set is ignored there). */
 int fsmg_sample(fsmg_handle h, int32_t num, int32_t* out_tokens);
 
+/* ---- unigram baseline.  Replaces the graph of UnigramModel (src/models/unigram_model.py:26-39): a
+ * word_count variable initialised to alpha = 1, tf.scatter_add of ones, prob = gather(word_count) / reduce_sum(word_count),
+ * loss = -mean(log prob).  Counts live on the device as unsigned integers (exact, order-independent atomics) and cross the
+ * boundary as float32 like the reference's variable.  `words` is a flat int32 array (host, or device when on_device != 0) of ids
+ * in [0, input_size); an id outside -> FSMG_ERR_TOKEN_RANGE (counts untouched by that call's NLL, the update skips the id). */
+typedef struct fsmg_unigram* fsmg_unigram_handle;
+int fsmg_unigram_create(int32_t input_size, int32_t device, fsmg_unigram_handle* out);
+int fsmg_unigram_destroy(fsmg_unigram_handle u);
+const char* fsmg_unigram_last_error(fsmg_unigram_handle u);     /* NULL: the text of a failed fsmg_unigram_create */
+/* *nll = -mean(log(count[w] / sum(counts))) over the n words, counts as they are (unigram_model.py:35-37) */
+int fsmg_unigram_nll(fsmg_unigram_handle u, const int32_t* words, int64_t n, int32_t on_device, float* nll);
+/* counts[w] += 1 per word (unigram_model.py:31-33); with loss != NULL the NLL of the same words BEFORE the update is returned
+ * (UnigramModel.train fetches both in one sess.run) */
+int fsmg_unigram_train(fsmg_unigram_handle u, const int32_t* words, int64_t n, int32_t on_device, float* loss);
+int fsmg_unigram_get_counts(fsmg_unigram_handle u, float* host, int64_t count);
+int fsmg_unigram_set_counts(fsmg_unigram_handle u, const float* host, int64_t count);
+/* argmax of the counts, lowest id on ties (UnigramModel.sample, unigram_model.py:71-78) */
+int fsmg_unigram_argmax(fsmg_unigram_handle u, int32_t* word);
+
 /* last n train losses (oldest first), n <= 1024; synchronises the stream */
 int fsmg_read_losses(fsmg_handle h, float* out, int32_t n);
 
@@ -239,6 +261,7 @@ typedef struct fsmg_stats {
     int64_t step_launches;              /* one-launch-per-time-step recurrent launches                               */
     int32_t persistent_path;            /* 1: persistent kernels are in force right now                              */
     int32_t fallback_steps_left;
+    int64_t steps_skipped_peer_failure; /* train steps every rank skipped because one rank failed before the exchange (library-owned exchange) */
 } fsmg_stats;
 int fsmg_get_stats(fsmg_handle h, fsmg_stats* out);
 
@@ -249,6 +272,14 @@ int fsmg_get_stats(fsmg_handle h, fsmg_stats* out);
  *   rows are TIME-major (row = t*B + b).  count = elements to copy (<= buffer size).
  *   "xcd_bx3" [1]: 1.0 when the handle runs the bf16-split XCD-local recurrent kernels (hidden 512, created for > 64 rows) */
 int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count);
+/* run-time knobs of a handle that used to be create-time environment variables (tests, diagnostics):
+ *   "chain_spin_limit"  polls before a persistent recurrent kernel gives up (0 forces the time-out path)
+ *   "fallback_steps"    train steps on per-step launches after a time-out before the persistent path is tried again
+ *   "persistent"        0: one launch per time step instead of the persistent recurrent kernels, 1: back (buffers permitting)
+ *   "eager"             0: passes are replayed from hipGraphs wherever fsmg_config.use_graph allows, 1: passes on the persistent
+ *                       recurrent kernels are issued eagerly (default)
+ * Synchronises the stream and drops the captured graphs. */
+int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value);
 /* padded sizes: writes Ep, Hp, V1p, last B, T */
 int fsmg_debug_dims(fsmg_handle h, int32_t dims[5]);
 /* diagnostics: run ONE instrumented recurrent step kernel (which = 0 forward, 1 backward) at t = T/2 on the

@@ -19,6 +19,7 @@ from oracle import lstm_oracle as O     # noqa: E402
 
 def main():
     hidden, maml = int(sys.argv[1]), int(sys.argv[2])
+    exchange = sys.argv[3] if len(sys.argv) > 3 else 'torch'          # 'library': the RCCL calls issued by libfsmg (fsmg_comm_*)
     # FSMG_TEST_SAME_GPU=1: both ranks on GPU 0 with the gloo backend (RCCL refuses two ranks on one device) -- exercises the
     # same host code (sharding, bucketed exchange on the communication stream, lock-step recovery) on a 1-GPU box
     same_gpu = os.environ.get('FSMG_TEST_SAME_GPU', '0') == '1'
@@ -26,7 +27,9 @@ def main():
     local = 0 if same_gpu else int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     cfg = small_config(hidden_size=hidden, embedding_size=24, input_size=150, max_len=10, max_grad_norm=0.5, device=local,
-                       name='maml_lstm' if maml else 'lstm_baseline', inner_steps=1, inner_lr=0.2)
+                       name='maml_lstm' if maml else 'lstm_baseline', inner_steps=1, inner_lr=0.2, dp_exchange=exchange)
+    if exchange == 'library':
+        os.environ['FSMG_ALLOW_LIBRARY_RCCL'] = '1'
     if same_gpu:
         os.environ['LOCAL_RANK'] = '0'
     if maml:

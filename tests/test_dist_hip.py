@@ -22,11 +22,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('hidden,maml', [(48, 0), (512, 0), (48, 1)])
-def test_two_ranks_on_the_hip_engine_equal_one_rank_on_the_concatenated_batch(hidden, maml, record_property):
+@pytest.mark.parametrize('hidden,maml,exchange', [(48, 0, 'torch'), (512, 0, 'torch'), (48, 1, 'torch'), (512, 0, 'library'), (48, 1, 'library')])
+def test_two_ranks_on_the_hip_engine_equal_one_rank_on_the_concatenated_batch(hidden, maml, exchange, record_property):
     import re
     import warnings
     import torch
+    if exchange == 'library' and torch.cuda.device_count() < 2:
+        pytest.skip('the library-owned exchange is RCCL only: two ranks need two GPUs (this is the 2-GPU parity test the path is gated on)')
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     if torch.cuda.device_count() < 2:
         # RCCL cannot place two ranks on one device ("Duplicate GPU detected"): both ranks share GPU 0 and exchange over gloo --
@@ -34,7 +36,7 @@ def test_two_ranks_on_the_hip_engine_equal_one_rank_on_the_concatenated_batch(hi
         # processes' persistent kernels get in each other's way); the RCCL leg runs wherever 2 GPUs are visible
         env['FSMG_TEST_SAME_GPU'] = '1'
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dist_hip_worker.py'), str(hidden), str(maml)]
+           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', '_dist_hip_worker.py'), str(hidden), str(maml), exchange]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600, env=env)
     assert proc.returncode == 0 and 'DIST_HIP_OK' in proc.stdout, proc.stdout[-4000:]
     # say which transport carried the exchange: a 1-GPU box cannot run RCCL with two ranks, and a green test must not read as

@@ -357,6 +357,54 @@ def test_persistent_kernel_timeout_falls_back_and_repeats_the_step(monkeypatch):
     assert model2.apply_update(1.0) == want[0]
 
 
+def test_inbox_refill_flag_survives_the_fallback_period():
+    """a time-out leaves dh partials in the BPTT inboxes of the XCD-local kernels; the refill flag must stay
+    up through the fallback steps (per-step kernels: no refill) until an XCD-local pass has really refilled.  Handle A times out
+    on its second step (spin limit 0), repeats it and runs the next one on per-step launches, then goes back to the XCD-local
+    kernels; handle B runs the same kernel families on the same episodes without ever timing out.  Same bits."""
+    cfg = small_config(hidden_size=512, embedding_size=32, input_size=150, max_len=12)
+    eps = O.synthetic_episodes(6, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=33)
+    a, b = new_model(cfg), new_model(cfg)
+    la, lb = [], []
+    la.append(a.train_step(*eps[0])); lb.append(b.train_step(*eps[0]))
+    assert a.stats()['xcd_launches'] > 0
+    a.debug_set('fallback_steps', 3)
+    a.debug_set('chain_spin_limit', 0)
+    la.append(a.train_step(*eps[1]))                    # times out, is skipped on the device, repeated on per-step launches
+    st = a.stats()
+    assert st['timeouts'] == 1 and st['steps_skipped_timeout'] == 1 and not st['persistent_path'] and a.step == 2
+    a.debug_set('chain_spin_limit', 1 << 18)
+    b.debug_set('persistent', 0)
+    lb.append(b.train_step(*eps[1]))
+    la.append(a.train_step(*eps[2])); lb.append(b.train_step(*eps[2]))      # A: second fallback step
+    b.debug_set('persistent', 1)
+    x0 = a.stats()['xcd_launches']
+    for e in eps[3:]:                                   # A: the persistent path is tried again -- on inboxes that still hold the aborted pass's partials
+        la.append(a.train_step(*e)); lb.append(b.train_step(*e))
+    st = a.stats()
+    assert st['persistent_path'] and st['xcd_launches'] > x0 and st['timeouts'] == 1
+    assert la == lb
+    for k, v in b.get_params().items():
+        np.testing.assert_array_equal(a.get_param(k), v)
+
+
+def test_eager_and_graph_replayed_passes_give_the_same_bits():
+    """Passes on the persistent recurrent kernels are issued eagerly by default (the caller's device token buffers are read in
+    place); debug_set('eager', 0) replays them from hipGraphs with staged tokens.  Same kernels, same order: same bits."""
+    import torch
+    cfg = small_config(hidden_size=512, embedding_size=32, input_size=150, max_len=12)
+    eps = O.synthetic_episodes(4, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=34)
+    a, b = new_model(cfg), new_model(cfg)
+    b.debug_set('eager', 0)
+    dev = [(torch.from_numpy(s_).cuda(), torch.from_numpy(q_).cuda()) for s_, q_ in eps]
+    la = [a.train_step(ds.data_ptr(), dq.data_ptr(), shape=(5, 5, 4)) for ds, dq in dev]
+    lb = [b.train_step(ds.data_ptr(), dq.data_ptr(), shape=(5, 5, 4)) for ds, dq in dev]
+    lc = [new_model(cfg).train_step(*eps[0])]                                  # host tokens through the staging buffer
+    assert la == lb and lc[0] == la[0]
+    for k, v in b.get_params().items():
+        np.testing.assert_array_equal(a.get_param(k), v)
+
+
 def test_xcd_local_and_column_split_kernels_agree_and_fall_back(monkeypatch):
     """Hidden size 512 takes the XCD-local recurrence (csrc/lstm_xcd.hip) by default.  FSMG_XCD=0 keeps the column-split
     persistent kernels: a different summation order (K split 4 x 128 per wave in both, but 16-wide k groups in another

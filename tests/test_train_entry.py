@@ -86,6 +86,7 @@ def test_episode_size_for_the_kernel_choice_comes_from_the_merged_yamls(tmp_path
     assert episode_sequences(shipped) == 45
 
 
+@pytest.mark.gpu
 def test_unigram_plugin_stays_selectable(tmp_path, golden_dir, capsys):
     cfg = dict(LOOP, name='unigram_model', model_module_name='models.unigram_model', model_class_name='UnigramModel')
     cfg['batch_size'] = 1

@@ -14,3 +14,7 @@ for name, s, e, q in seg:
     else: out.append([n, (s - t0) / 1e3, (e - t0) / 1e3, 1, q])
 for o in out: print('%-30s q%-2s %8.1f -> %8.1f us  x%-3d %s' % (o[0][:30], o[4], o[1], o[2], o[3], ('%.1f us/launch' % ((o[2] - o[1]) / o[3])) if o[3] > 1 else ''))
 print('step span %.1f us' % ((seg[-1][2] - t0) / 1e3))
+# period = start of the next step's first kernel - start of this one's: the gap between two steps is period - span (copies, event
+# records, launch boundaries); mean over the steps around the one printed
+per = [(rows[idx[i + 1]][1] - rows[idx[i]][1]) / 1e3 for i in range(max(which - 8, 0), min(which + 8, len(idx) - 1))]
+if per: print('step period %.1f us (median of %d consecutive steps; min %.1f max %.1f)' % (sorted(per)[len(per) // 2], len(per), min(per), max(per)))
