@@ -574,6 +574,18 @@ def main():
                            'bound for fp32-equivalent work is %.0f TFLOP/s (frac_bf16_split)' % PEAK_BX3_TFLOPS if cell_bx3 else '')}
             if cell_bx3:
                 out['roofline']['frac_bf16_split'] = ach / PEAK_BX3_TFLOPS
+            try:
+                xp = eng.debug_read('xcd_partitioned', 2)
+            except Exception:                  # noqa: BLE001
+                xp = [0.0, 8.0]
+            if xp[0]:
+                # XCD-partitioned order: the chains run on a few XCDs BESIDE the projection / dW GEMMs, slower per step than alone on
+                # the whole chip -- by design.  Both ways of pricing them: against the whole chip's peak (frac) and against the peak
+                # of the XCDs they occupy; the step as a whole is priced by roofline_step
+                nx = max(int(xp[1]), 1)
+                out['roofline'].update({'schedule': 'xcd_partitioned', 'xcds_occupied': nx,
+                                        'frac_of_occupied_xcds_peak': ach / (PEAK_F32_MFMA_TFLOPS * nx / 8.0),
+                                        'frac_bf16_split_of_occupied_xcds': ach / (PEAK_BX3_TFLOPS * nx / 8.0)})
     if rank == 0 and not maml:
         try:
             # the other half of BASELINE.json's metric: the validation path (query-only forward, batched 16 episodes

@@ -66,10 +66,29 @@ __global__ __launch_bounds__(256) void k_multi_op(const MultiOps r) {
         if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = word;
         return;
     }
+    __shared__ double sh[4];
+    if (o.kind == MULTI_MEAN) {
+        if (blockIdx.x != 0) return;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const float* x = (const float*)o.src;
+        const int n = (int)o.n;
+        double l = 0.0;
+        for (int i0 = tid; i0 < n; i0 += 256 * 16) {          // sixteen loads in flight, added in index order (the order of k_loss_reduce)
+            float b[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) b[k] = (i0 + 256 * k < n) ? x[i0 + 256 * k] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (i0 + 256 * k < n) l += (double)b[k];
+        }
+        l = wave_sum_d(l);
+        if (lane == 0) sh[wave] = l;
+        __syncthreads();
+        if (tid == 0) *(float*)o.dst = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / ((double)n + 1e-12));
+        return;
+    }
     // REDUCE: chunks of SQ_CHUNK elements, grid-stride over the chunks.  A thread owns four float4 of a chunk; the four loads of a
     // slab are issued together (and two slabs per round), so a thread has eight 16-byte loads in flight instead of one -- the first
     // version walked the slabs of one float4 at a time and ran at a third of the HBM rate (26 us for 70 MB).
-    __shared__ double sh[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* sl = (const float*)o.src;
     float* out = (float*)o.dst;
@@ -717,7 +736,7 @@ hipError_t launch_multi_op(hipStream_t s, const MultiOps& r) {
     if (r.count <= 0) return hipSuccess;
     long long bx = 1;
     for (int k = 0; k < r.count; ++k) {
-        const long long want = r.op[k].kind == MULTI_FILL ? (r.op[k].n / 4 + 255) / 256 : (r.op[k].n + SQ_CHUNK - 1) / SQ_CHUNK;
+        const long long want = r.op[k].kind == MULTI_FILL ? (r.op[k].n / 4 + 255) / 256 : r.op[k].kind == MULTI_MEAN ? 1 : (r.op[k].n + SQ_CHUNK - 1) / SQ_CHUNK;
         bx = std::max(bx, want);
     }
     bx = std::max<long long>(1, std::min<long long>(bx, 1024));

@@ -134,6 +134,7 @@ struct fsmg_model {
     // captured token_prep cannot take the caller's pointers.  FSMG_EAGER=0: graphs wherever fsmg_config.use_graph allows.
     bool eager = true, eager_call = false;
     const int* cur_sup = nullptr; const int* cur_qry = nullptr;     // what token_prep reads: the caller's device buffers (eager) or the staging buffer
+    bool fills_late = false;            // FSMG_FILLS_LATE=1: dH's slab sum + the BPTT fills behind the dW GEMM instead of in front of it (A/B)
     bool fill_early = false;            // FSMG_FILL_EARLY=1: the forward hand-off fills in front of the zx GEMM instead of behind it (A/B)
     float* colsum_slabs = nullptr;
     float* slabs2 = nullptr;            // ... and of the GEMMs on the auxiliary stream
@@ -158,10 +159,11 @@ struct fsmg_model {
     int bx3 = 1;                        // FSMG_GEMM=f32 selects the fp32-MFMA GEMM, default: bf16-split (k_gemm_bx3)
     bool xov = false, xov_call = false;
     bool bucket0_recorded = false;      // backward() recorded ev_bucket[0] itself (two-stream / XCD-partitioned order)
-    int xov_dw_split = 6;               // K split of dW under this schedule: short tiles, so little is in flight when the chain ends
-    int xov_dw_share = 15;              // percent of dW's tiles offered to the restricted launch
-    int xov_blocks = 2;                 // resident blocks per CU of the restricted launches
-    int xov_head = 18;                  // forward: time steps whose projection runs beside the rest of the recurrence
+    int xov_dw_split = 4;               // K split of dW under this schedule: an item must be short against the chain it runs beside
+    int xov_tail = 0;                   // FSMG_XOV_TAIL: time steps whose projection rows are left to a chip-wide launch behind the chain (0: none)
+    int xov_pub = 6;                    // FSMG_XOV_PUB: the forward chain publishes every this many steps (a 256-row tile is 5.7 steps of 45 rows)
+    int xov_parts = 3;                  // FSMG_XOV_PARTS: 1 = forward pair only, 2 = backward pair only, 3 = both
+    int* xov_prog = nullptr;            // [T] progress counters of the forward chain (LstmFwdXcdArgs::progress), the projection's gate
     // forward projection / dW: [0..1] draw counters, [2] stop flag, [3] items, [4 ..] claim words (gemm_restricted)
     static constexpr int XOV_CTL = 8192;
     int* xov_ctl = nullptr;             // [2][XOV_CTL]
@@ -619,6 +621,13 @@ struct OpBatch {
         o = MultiOp{}; o.kind = MULTI_REDUCE; o.dst = out; o.src = slabs; o.stride = stride; o.nslab = nslab; o.n = n; o.sq = sq;
         return FSMG_OK;
     }
+    int mean(const float* x, long long n, float* out) {       // *out = sum(x) / (n + 1e-12): one block of the launch
+        if (n <= 0) return FSMG_OK;
+        const int rc = room(1); if (rc != FSMG_OK) return rc;
+        MultiOp& o = r.op[r.count++];
+        o = MultiOp{}; o.kind = MULTI_MEAN; o.dst = out; o.src = x; o.n = n;
+        return FSMG_OK;
+    }
     int flush() {
         if (r.count == 0) return FSMG_OK;
         HIPCK(h, launch_multi_op(h->stream, r));
@@ -805,13 +814,17 @@ inline void choose_schedule(fsmg_model* h, int B, bool train = false) {
     // validation batches, the fallback after a time-out) keep the graph
     h->eager_call = h->eager && !h->ov_call && h->persist && h->persist_fwd && h->persist_bwd &&
                     (use_xcd(h, B) || lstm_fwd_chain_supported(B, h->Hp) || lstm_fwd_chain_rt_supported(B, h->Hp));
-    if (train && h->xov && h->Hp == 512 && !h->ov_call && !h->timing && h->aux != nullptr && use_xcd(h, B) && h->persist_fwd && h->persist_bwd) {
-        const int rpx = lstm_xcd_packed_rows(B);
-        h->xov_call = (B + rpx - 1) / rpx < 8;          // packing frees at least one XCD
+    // XCD-partitioned schedule (round 4 form): the bf16-split chains packed on ceil(B / 16) XCDs, the 256-tile work-queue GEMMs of
+    // the projection / its weight gradient on the others
+    if (train && h->xov && h->Hp == 512 && h->xcd_bx3 && h->bx3 && h->L == 1 && !h->ov_call && h->aux != nullptr && use_xcd(h, B) && h->persist_fwd && h->persist_bwd &&
+        (!h->timing || h->timing_only == "lstm_fwd" || h->timing_only == "lstm_bwd")) {
+        const int rpx = lstm_xcd16_packed_rows(B);
+        h->xov_call = rpx > 0 && (B + rpx - 1) / rpx <= 5;          // at least three XCDs for the GEMMs
+        if (h->xov_call) h->eager_call = true;
     }
 }
 // first XCD the packed recurrence leaves free
-inline int xov_first_free(int B) { const int rpx = lstm_xcd_packed_rows(B); return (B + rpx - 1) / rpx; }
+inline int xov_first_free(int B) { const int rpx = lstm_xcd16_packed_rows(B); return rpx > 0 ? (B + rpx - 1) / rpx : 8; }
 
 // every XCD-local launch of a pass gets its own 8 zeroed ticket counters
 inline int* next_tickets(fsmg_model* h) {
@@ -820,18 +833,30 @@ inline int* next_tickets(fsmg_model* h) {
     return t;
 }
 
-// Work-queue GEMM in two launches (GemmArgs::xcd_first): the restricted one lets the XCDs >= first draw items below
-// `limit` until *stop is raised; the clean-up one, ordered by the caller after the inputs of the remaining items, drains the
-// queue chip-wide.  work / stop are zeroed on the main stream before the fork.
-inline int gemm_items(const GemmArgs& g) { return ((g.M + gemm_tile_m() - 1) / gemm_tile_m()) * ((g.N + 127) / 128) * std::max(1, g.ksplit); }
+// Work-queue GEMM in two launches of k_gemm_bx3h<..., QUEUE> (GemmArgs::xcd_first): the restricted one lets the XCDs >= first
+// draw items (all of them: the two launches drain one queue); the clean-up one, ordered behind the kernel that owned the other
+// XCDs, lets the whole chip take what is left.  work / claim words are zeroed on the main stream before the fork.
+inline int gemm_items(const GemmArgs& g) { return ((g.M + 255) / 256) * ((g.N + 255) / 256) * std::max(1, g.ksplit); }
 inline bool xov_fits(const GemmArgs& g) { return 4 + gemm_items(g) <= fsmg_model::XOV_CTL; }
-int gemm_restricted(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int first, int* ctl, int limit) {
-    g.xcd_first = first; g.work = ctl; g.stop = ctl + 2; g.claim = ctl + 4; g.work_limit = limit;
-    HIPCK(h, launch_gemm(s, amode, bmode, g, gemm_lds_pad_for(h->xov_blocks)));
+inline void xov_gate(fsmg_model* h, GemmArgs& g, int B) {     // the projection's A rows arrive time step by time step
+    const int rpx = lstm_xcd16_packed_rows(B);
+    g.gate = h->xov_prog; g.gate_expect = lstm_xcd_active_blocks(B, rpx); g.gate_rows = B; g.gate_last = h->T - 1;       // (blocks below xcd_first join when the CHAIN is over)
+    g.gate_err = h->d_err; g.gate_spin = std::max(h->chain_spin_limit, 1) * 4; g.gate_every = h->xov_pub;
+}
+int gemm_restricted(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int first, int* ctl) {
+    static const int dbg = std::getenv("FSMG_XOV_DEBUG") ? std::atoi(std::getenv("FSMG_XOV_DEBUG")) : 0;
+    g.bx3 = 3; g.xcd_first = first; g.work = ctl; g.stop = ctl + 2; g.claim = ctl + 4; g.work_limit = (dbg & 1) ? 0 : gemm_items(g);
+    if ((dbg & 1) && (dbg & (128 | 256))) g.gate = nullptr;
+    if (dbg & 4) g.gate_spin = -g.gate_spin;       // (diagnostic: the gated blocks sleep once more behind a passed gate)
+    if (dbg & 16) g.dbg |= 32;                     // (diagnostic: agent-scope loads of the gated operand)
+    if (dbg & 8) g.dbg |= 128;                     // (diagnostic: agent-scope acquire behind the gate)
+    if (dbg & 32) g.dbg |= 64;                     // (diagnostic: blocks below xcd_first never join)
+    HIPCK(h, launch_gemm(s, amode, bmode, g, 0));
     return FSMG_OK;
 }
 int gemm_cleanup(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int* ctl) {
-    g.xcd_first = -1; g.work = ctl; g.claim = ctl + 4;
+    g.bx3 = 3; g.xcd_first = -1; g.work = ctl; g.claim = ctl + 4;
+    { static const int dbg = std::getenv("FSMG_XOV_DEBUG") ? std::atoi(std::getenv("FSMG_XOV_DEBUG")) : 0; if ((dbg & 1) && (dbg & (128 | 256))) g.gate = nullptr; }
     HIPCK(h, launch_gemm(s, amode, bmode, g, 0));
     return FSMG_OK;
 }
@@ -908,11 +933,18 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     const bool chain_rt = !xcd && h->persist && h->persist_fwd && !chain1 && lstm_fwd_chain_rt_supported(B, Hp);   // all row tiles per block
     const bool chain = chain1 || chain_rt;
     const int nch_ov = ov ? ((chain || xcd) ? h->nchunk_persist : h->nchunk) : 1;
-    // XCD-partitioned schedule: the projection of the first `head` steps runs on the free XCDs beside the rest of the chain
-    const GemmArgs ghead = logits_args(h, B, 0, T);
-    const bool xov = h->xov_call && xcd && want_dlogits && !ov && xov_fits(ghead);
-    const int head = std::min(h->xov_head, T - 1), xfree = xov_first_free(B);
-    const int rpx = xov ? lstm_xcd_packed_rows(B) : 0;
+    // XCD-partitioned schedule: the chain packed on the first XCDs publishes the time steps it has finished, the projection's
+    // row tiles are drawn by the other XCDs as their rows arrive (and by the whole chip once the chain is over)
+    // The queue takes the rows of the time steps [0, t_cut); the last few steps' rows (complete only when the chain is) go to a
+    // chip-wide launch of the 128-tile kernel behind it: a 256 x 256 tile is 85 us of latency with 1/6 of the CUs busy, the same
+    // rows as 128 x 128 tiles are one under-full round of ~40 us (same bits: the kernels share k order and term order, K = H is never split)
+    // (t_cut is a multiple of the publishing period: the queue's last row tile then waits for a step that IS published)
+    const int t_cut = (T >= 4 * h->xov_tail && h->xov_tail > 0) ? (T - h->xov_tail) / h->xov_pub * h->xov_pub : T;
+    GemmArgs ghead = logits_args(h, B, 0, t_cut);
+    const bool xov = h->xov_call && (h->xov_parts & 1) && xcd && want_dlogits && !ov && xov_fits(ghead);
+    const int xfree = xov_first_free(B);
+    const int rpx = xov ? lstm_xcd16_packed_rows(B) : 0;
+    if (xov) xov_gate(h, ghead, B);
     PHASE(0);
     for (int l = 0; l < h->L; ++l) {
         const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
@@ -921,7 +953,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
         GEMMCK(fills.add(h->Hs[l], 0u, (long long)B * Hp));
         GEMMCK(fills.add(h->Cs[l], 0u, (long long)B * Hp));
         if (!xcd) GEMMCK(fills.add(h->HF[l], 0u, (long long)Bp16 * Hp));
-        if (h->fill_early) GEMMCK(chain_fills_early(h, fills, l, B, chain, xcd, xov && top ? 4 + gemm_items(ghead) : 0));
+        if (h->fill_early && !xov) GEMMCK(chain_fills_early(h, fills, l, B, chain, xcd, 0));
         {
             ScopedTimer tm(h, "gemm_zx");
             GemmArgs g{};
@@ -939,23 +971,35 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             if (xcd) {       // the same for the XCD-local hand-off buffer, and fresh ticket counters for this layer's launches
                 GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
                 h->ticket_next = 0;
-                const long long step_f = lstm_xcd_hx_floats(B, 0, Hp, h->xcd_bx3);
+                const long long step_f = lstm_xcd_hx_floats(B, 0, Hp, h->xcd_bx3, xov && top ? rpx : 0);
                 GEMMCK(fills.add(h->HX, 0u, step_f));
                 GEMMCK(fills.add(h->HX + step_f, 0xFFFFFFFFu, step_f * T));
-                if (xov && top) GEMMCK(fills.add(h->xov_ctl, 0u, 4 + gemm_items(ghead)));
+                if (xov && top) {
+                    GEMMCK(fills.add(h->xov_ctl, 0u, 4 + gemm_items(ghead)));
+                    GEMMCK(fills.add(h->xov_prog, 0u, T));
+                }
             }
             return fills.flush();
         };
-        if (!h->fill_early) GEMMCK(chain_fills());
-        const bool split_head = xov && top && head >= 1;
-        const int nch = split_head ? 2 : nch_ov;
+        if (!h->fill_early || xov) GEMMCK(chain_fills());
+        if (xov && top) {         // the projection's queue launch on the auxiliary stream, confined to the XCDs the chain leaves free
+            HIPCK(h, hipEventRecord(h->ev_fork, s));
+            HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+            GEMMCK(gemm_restricted(h, h->aux, OP_KC, OP_XC, ghead, xfree, h->xov_ctl));
+            HIPCK(h, hipEventRecord(h->ev_join, h->aux));
+        }
+        const int nch = nch_ov;
         for (int c = 0; c < nch; ++c) {
-            const int t0 = split_head ? (c == 0 ? 0 : head) : chunk_begin(h, c, nch);
-            const int t1 = split_head ? (c == 0 ? head : T) : chunk_begin(h, c + 1, nch);
+            const int t0 = chunk_begin(h, c, nch);
+            const int t1 = chunk_begin(h, c + 1, nch);
             if (xcd) {
                 ScopedTimer tm(h, "lstm_fwd");
                 LstmFwdXcdArgs a{};
-                a.rpx = rpx; a.Hp = Hp; a.bx3 = h->xcd_bx3 ? 1 : 0; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, true, Hp);
+                a.rpx = (xov && top) ? rpx : 0; a.progress = (xov && top) ? h->xov_prog : nullptr; a.Hp = Hp;
+                { static const int dbg = std::getenv("FSMG_XOV_DEBUG") ? std::atoi(std::getenv("FSMG_XOV_DEBUG")) : 0;
+                  a.progress_lag = ((dbg & 2) ? 2 : 0) | ((dbg & 256) ? 256 : 0); if ((dbg & 128) && (dbg & 1)) a.progress = nullptr; }
+                a.progress_every = h->xov_pub; a.bx3 = h->xcd_bx3 ? 1 : 0;
+                a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, true, Hp, a.rpx);
                 a.KhX = h->khx + (size_t)(2 * l) * lstm_xcd_weight_floats((int)Hp, h->xcd_bx3); a.HX = h->HX; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
                 a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_fwd_xcd(s, a));
@@ -988,26 +1032,22 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
                 HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_chunk[c], 0));
                 GEMMCK(logits_and_ce(h, aux_lane(h, !want_dlogits, chain || xcd), B, t0, t1, rows, want_dlogits));
             }
-            if (split_head && c == 0) {
-                HIPCK(h, hipEventRecord(h->ev_chunk[0], s));
-                HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_chunk[0], 0));
-                // whole row tiles inside the finished steps, all column tiles
-                const int limit = (int)((int64_t)head * B / gemm_tile_m()) * ((h->V1p + 127) / 128);
-                GEMMCK(gemm_restricted(h, h->aux, OP_KC, OP_XC, ghead, xfree, h->xov_ctl, limit));
-                HIPCK(h, hipEventRecord(h->ev_join, h->aux));
-            }
         }
     }
     PHASE(2);
     if (ov) {
         HIPCK(h, hipEventRecord(h->ev_join, h->aux));
         HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));
-    } else if (xov && head >= 1) {
-        HIPCK(h, launch_fill32(s, h->xov_ctl + 2, 1u, 1));     // chain done: the free XCDs stop drawing tiles
+    } else if (xov) {
         {
-            ScopedTimer tm(h, "gemm_logits");
+            ScopedTimer tm(h, "gemm_logits");      // (what is left of the queue when the chain is over, on the whole chip)
+            if (t_cut < T) {       // the last steps' rows as 128 x 128 tiles (three blocks per CU): they fit the XCDs the chain has just left,
+                GemmArgs gt = logits_args(h, B, t_cut, T);      // beside the queue's tiles still in flight on the others
+                gt.bx3 = 1; gt.ksplit = 1;
+                HIPCK(h, launch_gemm(s, OP_KC, OP_XC, gt, 0));
+            }
             GEMMCK(gemm_cleanup(h, s, OP_KC, OP_XC, ghead, h->xov_ctl));
-            HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));    // tiles that were in flight on the free XCDs
+            HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));    // the restricted launch and its tiles in flight
         }
         GEMMCK(ce_rows(h, s, B, 0, T, rows));
     } else {
@@ -1042,6 +1082,26 @@ int dw_gemm(fsmg_model* h, const Lane& ln, int B, OpBatch* defer = nullptr) {
     return gemm(h, ln, OP_XC, OP_XC, dw_args(h, B), defer);
 }
 
+// what a BPTT chain wants filled before it starts (dC zero, hand-off patterns, ticket counters); rpx: rows packed per XCD
+int bptt_fills(fsmg_model* h, OpBatch& fills, int B, bool xcd, bool rs, bool chain, int rpx) {
+    const int T = h->T, Hp = h->Hp, G4 = h->G4;
+    GEMMCK(fills.add(h->dC, 0u, (long long)B * Hp));
+    if (xcd) {
+        // the dh-partial inboxes are refilled only when the device flag says so: every word a pass writes is read and reset
+        // by its consumer, so a completed pass leaves them all-"not written" (33 MB per pass at hidden 512, 100 MB per
+        // layer at hidden 1024 otherwise)
+        GEMMCK(fills.add(h->inboxX, 0xFFFFFFFFu, lstm_xcd_inbox_floats(B, Hp, rpx), h->d_inbox_dirty));    // same launch as the zero fills
+        GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
+        h->ticket_next = 0;
+    } else if (rs) {        // "not written yet" fill pattern of the dh partial inboxes
+        GEMMCK(fills.add(h->inbox, 0xFFFFFFFFu, lstm_bwd_rs_inbox_floats(B, Hp)));
+    } else if (chain) {     // ... or of the dz fragments of every time step
+        const long long Bp16 = (B + 15) / 16 * 16;
+        GEMMCK(fills.add(h->dzF_all, 0xFFFFFFFFu, (long long)T * Bp16 * G4));
+    }
+    return FSMG_OK;
+}
+
 // part 0: the whole pass; part 1: up to and including the projection gradients (dH, dW, dd: bucket 0 of the gradient exchange
 // is final behind it); part 2: the rest.  Only the single-stream order can be cut there: the two-stream and the XCD-partitioned
 // orders run everything in part 1 (they record bucket 0 themselves) and nothing in part 2.
@@ -1060,28 +1120,28 @@ int backward(fsmg_model* h, int B, int part = 0) {
     const Lane auxl = aux_lane(h, false, chain);
     // XCD-partitioned schedule: dW's tiles are claimed by the free XCDs while the top layer's chain runs, the rest after it
     GemmArgs gdw = dw_args(h, B);
-    int dw_split = pick_split(gdw.M, gdw.N, gdw.K, mainl.slots);
-    if (h->xov_call && xcd && !ov) dw_split = std::max(dw_split, std::min(std::min(h->xov_dw_split, MAX_SPLIT), gdw.K / 256));
+    int dw_split = 1;
+    if (h->xov_call && (h->xov_parts & 2) && xcd && !ov) dw_split = std::max(1, std::min(std::min(h->xov_dw_split, MAX_SPLIT), gdw.K / 256));
     while (dw_split > 1 && (int64_t)dw_split * gdw.M * gdw.N > h->slab_cap) --dw_split;
     if (dw_split > 1) {
         gdw.C = mainl.slabs; gdw.c_slab = (int64_t)gdw.M * gdw.N; gdw.ksplit = dw_split;
         gdw.colsum = mainl.colsum_slabs; gdw.colsum_slab = gdw.N;
     }
-    const bool xov = h->xov_call && xcd && !ov && xov_fits(gdw);
-    const int rpx = xov ? lstm_xcd_packed_rows(B) : 0;
+    const bool xov = h->xov_call && (h->xov_parts & 2) && xcd && !ov && dw_split > 1 && xov_fits(gdw);
+    const int rpx = xov ? lstm_xcd16_packed_rows(B) : 0;
     const bool cut = !ov && !xov;           // the order that can be cut behind the projection gradients
     if (part == 2 && !cut) return FSMG_OK;
     // dp_split == 2: the cut sits behind the LAST recurrent chain instead -- an XCD-local chain needs every CU of the chip, so
     // a collective kernel started in front of it only delays it; behind it the exchange of bucket 0 runs beside the
     // weight- / input-gradient GEMMs of the bottom layer, the embedding gradient and the norm
     const bool cut_late = cut && h->dp_split == 2 && part != 0;
-    bool dx_sq_done = false;
+    bool dx_sq_done = false, top_fills_done = false;
     PHASE(3);
     // Slab sums of the split-K GEMMs ride in two launches per pass instead of one each: `fills` (issued right in front of a
     // recurrent chain: what the chain reads -- dH -- plus the fills) and `late` (in front of the embedding gradient: every
     // weight gradient + dx with its squared-norm partials).  Only the order that runs start to end on one stream in one call
     // defers; the cut (episode-parallel) and overlapped orders keep a sum behind each GEMM.
-    const bool defer_ok = part == 0 && cut;
+    const bool defer_ok = part == 0 && (cut || xov);
     if (part != 2) h->arena_off = 0;
     h->last_bwd_xcd = xcd;
     FillBatch fills(h);                     // embedding-gradient zero + the top layer's BPTT buffers: one launch
@@ -1106,17 +1166,19 @@ int backward(fsmg_model* h, int B, int part = 0) {
         h->bucket0_recorded = true;
     } else if (xov) {
         GEMMCK(fills.add(h->xov_ctl + fsmg_model::XOV_CTL, 0u, 4 + gemm_items(gdw)));
-        GEMMCK(fills.flush());
-        GEMMCK(dhout_chunk(h, mainl, B, 0, T));
+        GEMMCK(fills.flush());                // (the queue words must be zero before the auxiliary stream forks)
+        GEMMCK(dhout_chunk(h, mainl, B, 0, T, d_now));
         HIPCK(h, hipEventRecord(h->ev_fork, s));
         HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-        // no more blocks than the free XCDs can use while the chain runs: the replicas dealt to the chain's XCDs only
-        // start (and leave) when it is over, in the way of the clean-up launch
-        const int dw_limit = (int)((int64_t)gemm_items(gdw) * h->xov_dw_share / 100);
-        GEMMCK(gemm_restricted(h, h->aux, OP_XC, OP_XC, gdw, xov_first_free(B), h->xov_ctl + fsmg_model::XOV_CTL, dw_limit));
+        GEMMCK(gemm_restricted(h, h->aux, OP_XC, OP_XC, gdw, xov_first_free(B), h->xov_ctl + fsmg_model::XOV_CTL));
         HIPCK(h, hipEventRecord(h->ev_join, h->aux));
     } else {
         GEMMCK(dhout_chunk(h, mainl, B, 0, T, d_now));
+        if (defer_ok && !h->fills_late) {     // dH's slab sum + the top chain's fills go out in front of dW: the chain starts right behind a GEMM
+            GEMMCK(bptt_fills(h, fills, B, xcd, rs, chain, 0));
+            GEMMCK(fills.flush());
+            top_fills_done = true;
+        }
         GEMMCK(dw_gemm(h, mainl, B, d_late));
     }
     if (part == 1 && cut && !cut_late) return fills.flush();
@@ -1125,30 +1187,19 @@ int backward(fsmg_model* h, int B, int part = 0) {
         if (part == 2 && cut_late && l > 0) continue;                       // done in part 1
         const bool skip_chain = part == 2 && cut_late;                      // layer 0: its chain ran in part 1
         if (!skip_chain) {
-        GEMMCK(fills.add(h->dC, 0u, (long long)B * Hp));
         if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[nch - 1], 0));
         PHASE(4);
-        if (xcd) {
-            // the dh-partial inboxes are refilled only when the device flag says so: every word a pass writes is read and reset
-            // by its consumer, so a completed pass leaves them all-"not written" (33 MB per pass at hidden 512, 100 MB per
-            // layer at hidden 1024 otherwise)
-            GEMMCK(fills.add(h->inboxX, 0xFFFFFFFFu, lstm_xcd_inbox_floats(B, Hp), h->d_inbox_dirty));    // same launch as the zero fills
-            GEMMCK(fills.add(h->tickets, 0u, (long long)8 * fsmg_model::TICKET_LAUNCHES));
-            h->ticket_next = 0;
-        } else if (rs) {        // "not written yet" fill pattern of the dh partial inboxes
-            GEMMCK(fills.add(h->inbox, 0xFFFFFFFFu, lstm_bwd_rs_inbox_floats(B, Hp)));
-        } else if (chain) {     // ... or of the dz fragments of every time step
-            const long long Bp16 = (B + 15) / 16 * 16;
-            GEMMCK(fills.add(h->dzF_all, 0xFFFFFFFFu, (long long)T * Bp16 * G4));
+        if (!(top && top_fills_done)) {
+            GEMMCK(bptt_fills(h, fills, B, xcd, rs, chain, xov && top ? rpx : 0));
+            GEMMCK(fills.flush());
         }
-        GEMMCK(fills.flush());
         for (int c = nch - 1; c >= 0; --c) {
             const int t0 = chunk_begin(h, c, nch), t1 = chunk_begin(h, c + 1, nch);
             if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[c], 0));
             ScopedTimer tm(h, "lstm_bwd");
             if (xcd) {
                 LstmBwdXcdArgs a{};
-                a.rpx = rpx; a.Hp = Hp; a.bx3 = h->xcd_bx3 ? 1 : 0; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, false, Hp);
+                a.rpx = (xov && top) ? rpx : 0; a.Hp = Hp; a.bx3 = h->xcd_bx3 ? 1 : 0; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, false, Hp);
                 a.KhXb = h->khx + (size_t)(2 * l + 1) * lstm_xcd_weight_floats((int)Hp, h->xcd_bx3); a.inbox = h->inboxX; a.Z = h->Z[l]; a.Cs = h->Cs[l];
                 a.dc = h->dC; a.dH = h->dH; a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_bwd_xcd(s, a));
@@ -1189,16 +1240,20 @@ int backward(fsmg_model* h, int B, int part = 0) {
         }
         if (xov && top) {                     // the rest of dW chip-wide, then the fixed-order slab sum
             ScopedTimer tm(h, "gemm_dw");
-            HIPCK(h, launch_fill32(s, h->xov_ctl + fsmg_model::XOV_CTL + 2, 1u, 1));
             GEMMCK(gemm_cleanup(h, s, OP_XC, OP_XC, gdw, h->xov_ctl + fsmg_model::XOV_CTL));
             HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));
             if (dw_split > 1) {
                 const int64_t mn = (int64_t)gdw.M * gdw.N;
-                HIPCK(h, launch_reduce_slabs(s, mainl.slabs, mn, dw_split, h->G + h->off_w, mn));
-                HIPCK(h, launch_reduce_slabs(s, mainl.colsum_slabs, gdw.N, dw_split, h->G + h->off_d, gdw.N));
+                if (d_late) {                     // the fixed-order slab sums ride with the other weight gradients'
+                    GEMMCK(late.reduce(mainl.slabs, mn, dw_split, h->G + h->off_w, mn));
+                    GEMMCK(late.reduce(mainl.colsum_slabs, gdw.N, dw_split, h->G + h->off_d, gdw.N));
+                } else {
+                    HIPCK(h, launch_reduce_slabs(s, mainl.slabs, mn, dw_split, h->G + h->off_w, mn));
+                    HIPCK(h, launch_reduce_slabs(s, mainl.colsum_slabs, gdw.N, dw_split, h->G + h->off_d, gdw.N));
+                    HIPCK(h, hipEventRecord(h->ev_bucket[0], s));
+                    h->bucket0_recorded = true;
+                }
             }
-            HIPCK(h, hipEventRecord(h->ev_bucket[0], s));
-            h->bucket0_recorded = true;
         }
         }   // !skip_chain
         if (part == 1 && cut_late && l == 0) return FSMG_OK;                // bucket 0 travels beside what follows
@@ -1232,6 +1287,10 @@ int backward(fsmg_model* h, int B, int part = 0) {
     }
     {
         ScopedTimer tm(h, "embed_grad");
+        // tail[1] = the mean loss of the pass: nobody reads it before the step's last kernels, so it rides with the slab sums (one
+        // block of a launch that keeps the rest of the chip busy) instead of costing a launch behind the cross entropy
+        const bool loss_in_batch = late.r.count > 0;
+        if (loss_in_batch) GEMMCK(late.mean(h->ce, rows, h->G + h->n_flat + 1));
         GEMMCK(late.flush());
         HIPCK(h, launch_embed_grad(s, h->X, (int)rows, h->dXemb, h->Ep, h->G + h->off_emb, h->tok_first, h->tok_count));
         h->tok_table_open = false;
@@ -1239,7 +1298,7 @@ int backward(fsmg_model* h, int B, int part = 0) {
         if (!dx_sq_done) HIPCK(h, launch_sqnorm_partials(s, h->dXemb, rows * h->Ep, h->partials));
         // tail[0] = squared norm of the embedding-slice gradients, tail[1] = mean loss of the pass, tail[2] / tail[3] = time-out /
         // token-range indicators
-        HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0, h->d_err, h->ce, (int)rows, h->G + h->n_flat + 1));
+        HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0, h->d_err, loss_in_batch ? nullptr : h->ce, (int)rows, h->G + h->n_flat + 1));
     }
     if (ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));     // dW / dd landed
     PHASE(6);
@@ -1664,12 +1723,13 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (env) { h->overlap = env[0] != '0'; h->overlap_forced = true; }
         if (const char* e = std::getenv("FSMG_GEMM")) h->bx3 = std::strcmp(e, "f32") != 0;
         if (const char* e = std::getenv("FSMG_XCD_OVERLAP")) h->xov = std::atoi(e) != 0;
-        if (const char* e = std::getenv("FSMG_XOV_HEAD")) h->xov_head = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("FSMG_XOV_DW_SPLIT")) h->xov_dw_split = std::max(1, std::atoi(e));
-        if (const char* e = std::getenv("FSMG_XOV_DW_SHARE")) h->xov_dw_share = std::max(0, std::min(100, std::atoi(e)));
-        if (const char* e = std::getenv("FSMG_XOV_BLOCKS")) h->xov_blocks = std::max(1, std::min(4, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_XOV_PARTS")) h->xov_parts = std::max(1, std::min(3, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_XOV_PUB")) h->xov_pub = std::max(1, std::min(64, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_XOV_TAIL")) h->xov_tail = std::max(0, std::min(64, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_EAGER")) h->eager = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_FILL_EARLY")) h->fill_early = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_FILLS_LATE")) h->fills_late = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
         h->persist_cfg = h->persist;
         if (const char* e = std::getenv("FSMG_FALLBACK_STEPS")) h->fallback_steps = std::max(1, std::atoi(e));
@@ -1718,8 +1778,9 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
 
     char* small = nullptr;
     const size_t tok_words = (size_t)round_up(h->V1, 64);
+    const size_t prog_words = (size_t)round_up(h->T + 8, 64);
     const size_t small_bytes = 256 * 4 + sizeof(float) * RING_CAP + sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES + sizeof(int) * 2 * fsmg_model::XOV_CTL +
-                               sizeof(int) * 2 * tok_words;
+                               sizeof(int) * 2 * tok_words + sizeof(int) * prog_words;
     if (hipMalloc((void**)&small, small_bytes) != hipSuccess) return bail(FSMG_ERR_NOMEM, "hipMalloc(scalars) failed");
     hipMemsetAsync(small, 0, small_bytes, h->stream);
     h->d_step = (long long*)small; h->d_err = (int*)(small + 256); h->d_gnorm = (float*)(small + 512);
@@ -1733,6 +1794,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     h->tickets = (int*)(small + 1024 + sizeof(float) * RING_CAP);
     h->xov_ctl = h->tickets + 8 * fsmg_model::TICKET_LAUNCHES;
     h->tok_first = h->xov_ctl + 2 * fsmg_model::XOV_CTL; h->tok_count = h->tok_first + tok_words;
+    h->xov_prog = h->tok_count + tok_words;
     if (reset_tok_table(h) != FSMG_OK) return bail(FSMG_ERR_HIP, "fill of the token occurrence table failed");
 
     // decode scratch: per layer h ping/pong + c, plus x and argmax block scratch
@@ -1747,6 +1809,20 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         // bf16-split XCD-local kernels where the episode the handle is created for has the rows that make them the faster ones
         // (cfg-D: 100 sequences); FSMG_XCD_BX3=0/1 forces.  One format per handle: weight images and hand-off buffer follow it.
         h->xcd_bx3 = lstm_xcd_bx3_pays(cfg->max_sequences > 0 ? cfg->max_sequences : 45, h->Hp) && (cfg->max_sequences <= h->xcd_max_rows);
+        // AUTO schedule: the XCD-partitioned order where it was measured to pay (cfg-B: +8 % against the serial order, same bits as
+        // the serial order on the same kernels) -- one 512-unit layer, the episode's rows on at most five XCDs (16 per XCD), and a
+        // projection with enough 256 x 256 tiles to keep the other XCDs busy for the length of a chain
+        {
+            const int b0 = cfg->max_sequences > 0 ? cfg->max_sequences : 45;
+            const int rpx = lstm_xcd16_packed_rows(b0);
+            const long long items = (((long long)h->T * b0 + 255) / 256) * ((h->V1p + 255) / 256);
+            const bool eligible = h->bx3 && h->Hp == 512 && h->L == 1 && rpx > 0 && (b0 + rpx - 1) / rpx <= 5 && b0 >= 16 && h->T >= 32 && items >= 320 &&
+                                  4 + items <= fsmg_model::XOV_CTL;
+            if (cfg->schedule == FSMG_SCHEDULE_AUTO && std::getenv("FSMG_XCD_OVERLAP") == nullptr && !h->overlap_forced) h->xov = eligible;
+        }
+        // the XCD-partitioned schedule packs the rows on ceil(B / 16) XCDs: only the bf16-split kernels take 16 rows per XCD at one
+        // MFMA phase's cost
+        if (h->xov && h->bx3 && h->Hp == 512) h->xcd_bx3 = true;
         if (const char* e = std::getenv("FSMG_XCD_BX3")) h->xcd_bx3 = std::atoi(e) != 0 && h->Hp == 512;
         if (hipMalloc((void**)&h->khx, sizeof(float) * (size_t)h->L * 2 * lstm_xcd_weight_floats(h->Hp, h->xcd_bx3)) != hipSuccess)
             return bail(FSMG_ERR_NOMEM, "hipMalloc(XCD-local weight images) failed");
@@ -2381,6 +2457,11 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
     };
     int l;
     if (!std::strcmp(what, "xcd_bx3")) { host[0] = h->xcd_bx3 ? 1.0f : 0.0f; return FSMG_OK; }      // a host-side fact: which XCD-local kernel family this handle runs
+    if (!std::strcmp(what, "xcd_partitioned")) {      // ... and whether its train passes take the XCD-partitioned order: [0] yes / no, [1] XCDs the chains occupy
+        host[0] = h->xov ? 1.0f : 0.0f;
+        if (count > 1) { const int b = h->lastB > 0 ? h->lastB : 45, rpx = lstm_xcd16_packed_rows(b); host[1] = (h->xov && rpx > 0) ? (float)((b + rpx - 1) / rpx) : 8.0f; }
+        return FSMG_OK;
+    }
     if (!std::strcmp(what, "logits")) { src = h->logits; cap = rows * h->V1p; }
     else if (!std::strcmp(what, "dlogits")) { src = h->dlogits; cap = rows * h->V1p; }
     else if (!std::strcmp(what, "lse")) { src = h->lse; cap = rows; }

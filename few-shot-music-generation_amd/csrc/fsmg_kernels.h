@@ -37,6 +37,14 @@ struct GemmArgs {
     //                  the remaining items read.
     // Placement decides speed, never results: an item is computed once, by the same code either way.
     int xcd_first; int* work; int* claim; int work_limit; const int* stop;
+    // Gate of a work-queue launch whose A rows are still being produced by a kernel on the other XCDs (the overlapped step: the
+    // projection beside the forward recurrence).  gate[t] reaches gate_expect when the rows of time step t (gate_rows rows each,
+    // time-major) are in memory; a block that has drawn a row tile waits for the tile's last step, then takes an agent-scope
+    // acquire.  Bounded: after gate_spin polls, or when *gate_err == 2 (the producer gave up), the block raises *gate_err = 2 and
+    // leaves its tile uncomputed -- the step is skipped like any timed-out step.  Blocks of a restricted launch that land below
+    // xcd_first join the drawing once gate[gate_last] is complete (the producer has left those XCDs).
+    const int* gate; int gate_expect; int gate_rows; int gate_last; int* gate_err; int gate_spin;
+    int gate_every;         // the producer publishes every gate_every-th step only (LstmFwdXcdArgs::progress_every): wait for the group's last
     int bx3;                // 1: k_gemm_bx3 -- fp32 product from three bf16 planes per operand on the bf16 matrix pipe (gemm.hip);
                             // 2: k_gemm_bx3w, its wave-specialised variant (same bits; two 512-thread blocks per CU)
     int group_m;                // bf16-split kernels: tile order, see tile_coords (gemm.hip); 0 = row tiles fastest
@@ -156,7 +164,7 @@ hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* b
 enum { XCD_DEFER_OUTPUTS = 16,      // forward: c / h / gate stores of step t are issued behind the poll of step t+1; backward: dz stores behind the drain
        XCD_NO_POLL_SLEEP = 32,      // no s_sleep between two polls of a hand-off
        XCD_CHAINS = 64 };           // hidden 1024: the row groups of an XCD pair as independent chains (k_lstm_*_pair_chains)
-int lstm_xcd_default_variant(int B, bool forward, int Hp = 512);
+int lstm_xcd_default_variant(int B, bool forward, int Hp = 512, int rpx = 0);
 struct LstmFwdXcdArgs {
     const float* KhX;     // forward register image of K_h (launch_repack_kh_xcd)
     float* HX;            // [T+1][8][4][RG][2][64][4] hand-off buffer; index 0 = zero state, t0+1 .. t1 = 0xFF fill
@@ -172,6 +180,12 @@ struct LstmFwdXcdArgs {
     int variant;                // XCD_* bits; lstm_xcd_default_variant(B, forward) has the measured choice
     int Hp;                     // 512 (0 = 512): one copy of K_h per XCD; 1024: one copy per XCD PAIR (k_lstm_fwd_pair)
     int bx3;                    // hidden 512: KhX / HX are in the bf16-split format, run k_lstm_fwd_xcd16
+    int* progress;              // bf16-split kernels only, nullptr = off: [T] counters, ZERO before the launch; progress[t] reaches
+                                // lstm_xcd_active_blocks(B, rpx) when the row-major h of step t (Hs index t + 1) is in memory
+                                // (write-through stores) -- what a GEMM on the other XCDs gates its row tiles on
+    int progress_lag;           // diagnostics: publish this many steps later than the stores' completion requires
+    int progress_every;         // publish every this many steps (0 = 1): only progress[t] with t % every == every - 1, and progress[T - 1],
+                                // are counted up -- a publish is a memory operation in front of the next poll of the publishing wave
 };
 struct LstmBwdXcdArgs {
     const float* KhXb;    // backward register image of K_h
@@ -192,8 +206,10 @@ struct LstmBwdXcdArgs {
 };
 bool lstm_xcd_supported(int B, int Hp);        // Hp 512: up to 128 rows; Hp 1024 (one copy of K_h per XCD pair): up to 64 rows
 int lstm_xcd_max_rows(int Hp);                 // 128 / 64 / 0
-long long lstm_xcd_hx_floats(int B, int T, int Hp = 512, bool bx3 = false);   // bx3: for the bf16-split kernels (hidden 512)
-long long lstm_xcd_inbox_floats(int B, int Hp = 512);
+long long lstm_xcd_hx_floats(int B, int T, int Hp = 512, bool bx3 = false, int rpx = 0);   // bx3: for the bf16-split kernels (hidden 512); rpx: rows packed per XCD
+long long lstm_xcd_inbox_floats(int B, int Hp = 512, int rpx = 0);
+int lstm_xcd16_packed_rows(int B);             // bf16-split kernels: rows per XCD that put B rows on the fewest XCDs (up to 16 each)
+inline int lstm_xcd_active_blocks(int B, int rpx) { return 32 * ((B + rpx - 1) / rpx); }     // blocks of a packed launch that own rows
 long long lstm_xcd_weight_floats(int Hp = 512, bool bx3 = false);   // floats per register image
 bool lstm_xcd_bx3_pays(int B, int Hp);         // the bf16-split kernels are the faster ones at this row count
 int lstm_xcd_packed_rows(int B);               // rows per XCD that leave whole XCDs free without adding row groups (hidden 512)
@@ -214,7 +230,9 @@ hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);
 //   MULTI_REDUCE  dst[i] = sum_z src[z * stride + i] for i < n, slabs added in order z = 0 .. nslab - 1 (deterministic split-K);
 //                 sq != nullptr: also the squared-norm partials of dst, one double per SQ_CHUNK (= sqnorm_blocks) elements, bit-equal
 //                 to launch_sqnorm_partials(dst, n, sq)
-enum { MULTI_FILL = 0, MULTI_REDUCE = 1 };
+//   MULTI_MEAN    *dst = sum(src[0 .. n)) / (n + 1e-12), one block, double accumulation in the order of launch_loss_reduce with one
+//                 group (the mean loss of a train pass: rides in a launch that has work for the rest of the chip)
+enum { MULTI_FILL = 0, MULTI_REDUCE = 1, MULTI_MEAN = 2 };
 constexpr int MULTI_MAX_OPS = 16;
 struct MultiOp { int kind; void* dst; const void* src; long long n; long long stride; int nslab; uint32_t word; const int* cond; double* sq; };
 struct MultiOps { MultiOp op[MULTI_MAX_OPS]; int count; };

@@ -612,6 +612,7 @@ struct BxStager {
     __amdgpu_buffer_rsrc_t rs;
     unsigned vo[2], so, sstep;
     static constexpr bool use_buf = BUF;
+    bool coherent = false;      // KC buffer path: agent-scope (sc1) loads -- the rows are being written by a kernel on another XCD (gated queue launch)
     __device__ __forceinline__ void load_ids() {
 #pragma unroll
         for (int i = 0; i < 8; ++i) gi[i] = gp[min(i, gK - 1 - gk)];      // clamped: the id of a row past K is never used
@@ -674,7 +675,7 @@ struct BxStager {
                 const unsigned s0 = __builtin_amdgcn_readfirstlane(so);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const u4_ q = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[i], s0, 0);
+                    const u4_ q = coherent ? __builtin_amdgcn_raw_buffer_load_b128(rs, vo[i], s0, 16) : __builtin_amdgcn_raw_buffer_load_b128(rs, vo[i], s0, 0);
                     v[4 * i] = __uint_as_float(q.x); v[4 * i + 1] = __uint_as_float(q.y); v[4 * i + 2] = __uint_as_float(q.z); v[4 * i + 3] = __uint_as_float(q.w);
                 }
                 so += sstep;
@@ -1115,7 +1116,18 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
         if (g.xcd_first > 0) {
             int xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            if ((xcc & 7) < g.xcd_first) return;
+            // below xcd_first: the XCDs of the kernel this launch runs beside.  A block can only be placed there before that kernel
+            // has taken its CUs (leave at once) or after it has left them (gated launches: join the drawing when it is really over)
+            if ((xcc & 7) < g.xcd_first) {
+                if (g.gate == nullptr || (g.dbg & 64)) return;
+                // ONE thread decides for the block: the counter may be completing while the block reads it, and a block whose threads
+                // disagree would go on with half its waves (first version: half-computed tiles, one step in three)
+                if (tid == 0) s_item = __hip_atomic_load(g.gate + g.gate_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= g.gate_expect;
+                __syncthreads();
+                const int join = s_item;
+                __syncthreads();
+                if (!join) return;
+            }
         }
         if (tid == 0) {
             int item = -1;
@@ -1126,11 +1138,32 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
                 const int j = atomicAdd(g.work, 1);
                 if (j < min(g.work_limit, total) && atomicCAS(g.claim + j, 0, 1) == 0) item = j;
             }
+            if (item >= 0 && g.gate != nullptr) {          // wait for the last time step the tile's rows belong to
+                const int tm_ = (item / tilesN) % tilesM;
+                int t_need = (min(g.M, (tm_ + 1) * XT) - 1) / g.gate_rows;
+                if (g.gate_every > 1) t_need = min(g.gate_last, (t_need / g.gate_every + 1) * g.gate_every - 1);
+                const int spin_cap = g.gate_spin < 0 ? -g.gate_spin : g.gate_spin;
+                if (g.gate_spin < 0) for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(127);       // diagnostic: ~4 us at 2 GHz
+                for (int spins = 0; __hip_atomic_load(g.gate + t_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.gate_expect; ++spins) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (spins >= spin_cap || ((spins & 63) == 63 && __hip_atomic_load(g.gate_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) {
+                        __hip_atomic_store(g.gate_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        item = -1;
+                        break;
+                    }
+                }
+            }
             s_item = item;
         }
         __syncthreads();
         const int item = s_item;
         if (item < 0) return;
+        // The rows were written (write-through) by another XCD while this launch was running, and are read with ordinary loads:
+        // this XCD's L2 was invalidated when the launch started (the acquire of every kernel dispatch -- what makes any producer /
+        // consumer pair of kernels on different XCDs work), and a row enters it only through loads issued behind that row's gate.
+        // Measured alternatives (profiles/r04_xov_*.log): an agent-scope acquire here empties the L2 for every block of the XCD
+        // (920 times in 0.5 ms; 105 instead of 85 us per tile), agent-scope (sc1) loads of the operand bypass the L2 (the same 105 us).
+        if (g.gate != nullptr && (g.dbg & 128)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (diagnostic)
         tm = (item / tilesN) % tilesM; tn = item % tilesN; z = item / (tilesM * tilesN);
     } else {
         const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
@@ -1158,6 +1191,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     typename BxStagerSel<DMA, BMODE, XT, 512, (BUFM >= 1)>::type sb;
     if constexpr (DMA && AMODE == OP_XC) sa.init(g.A, g.lda, g.M, m0, nullptr, kb, tid, g.K, smem + 2 * STAGE + wave * 2048);
     else sa.init(g.A, g.lda, g.M, m0, g.gather, kb, tid, g.K);
+    if constexpr (QUEUE && AMODE == OP_KC && BUFM >= 2) sa.coherent = g.gate != nullptr && (g.dbg & 32) != 0;     // (diagnostic: agent-scope loads)
     if constexpr (DMA && BMODE == OP_XC) sb.init(g.B, g.ldb, g.N, n0, nullptr, kb, tid, g.K, smem + 2 * STAGE + ((AMODE == OP_XC) ? 8 * 2048 : 0) + wave * 2048);
     else sb.init(g.B, g.ldb, g.N, n0, nullptr, kb, tid, g.K);
 

@@ -75,6 +75,13 @@ __device__ __forceinline__ void store_l2(f32x4* p, f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 
+// row-major h output of a cell thread.  wt: agent-scope write-through -- a GEMM on ANOTHER XCD reads these rows while the launch
+// still runs (the overlapped step: LstmFwdXcdArgs::progress), so they must not linger in this XCD's L2
+__device__ __forceinline__ void store_h_row(float* p, float v, bool wt) {
+    if (wt) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    else *p = v;
+}
+
 template <int ABID>
 __device__ __forceinline__ f32x4 mfma44(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0);       // A of block ABID broadcast to all 16 blocks
@@ -589,6 +596,14 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd16(const LstmFwdXcdArgs 
     const bool cellw = wave < rgc;
     const bool act = cellw && lrow < rpx && row < B;
     const bool pub = cellw && lrow < rpx;         // rows past B on the last XCD publish zeros: the readers load every row < rpx
+    // overlapped step: the projection GEMM on the other XCDs draws row tiles as the time steps complete.  progress[t] counts the
+    // blocks whose row-major h of step t (Hs index t + 1) has reached memory: the stores are write-through, every wave drains its
+    // vector-memory queue in the poll of a later step, and the block barrier of that step orders all four waves before thread 0
+    // publishes -- `lag` steps behind (1, or 2 when the outputs are deferred behind the next poll); the tail is published at the end
+    const bool wt = a.progress != nullptr;
+    const bool pubs = wt && !(a.progress_lag & 256);                    // (diagnostic bit 256: write-through stores, nothing published)
+    const int lag = ((a.variant & XCD_DEFER_OUTPUTS) ? 2 : 1) + (a.progress_lag & 7);
+    const int pk = a.progress_every > 0 ? a.progress_every : 1;         // a step is published when it is the last of a group of pk (or the pass's last)
     float cp = act ? a.Cs[((size_t)a.t0 * B + row) * XH + unit] : 0.0f;
     const int arow = lane & 15, akg = lane >> 4;
     const bool ldl = arow < rpx;                  // lanes of pad rows never load: their A registers stay zero
@@ -641,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd16(const LstmFwdXcdArgs 
         }
         if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {
             a.Cs[((size_t)t * B + row) * XH + unit] = o_c;
-            a.Hs[((size_t)t * B + row) * XH + unit] = o_hh;
+            store_h_row(a.Hs + ((size_t)t * B + row) * XH + unit, o_hh, wt);
             float* zo = a.Z + ((size_t)(t - 1) * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
             zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
         }
@@ -677,6 +692,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd16(const LstmFwdXcdArgs 
         }
         __syncthreads();
         if (s_fail) return;
+        if (pubs && tid == 0 && t - lag >= a.t0 && (t - lag) % pk == pk - 1)
+            __hip_atomic_fetch_add(a.progress + (t - lag), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         XCD_STAMP(2)
 
         if (cellw) {
@@ -709,16 +726,23 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd16(const LstmFwdXcdArgs 
                 o_c = cp; o_hh = hn; o_g[0] = g_si; o_g[1] = g_tj; o_g[2] = g_sf; o_g[3] = g_so; o_have = true;
             } else if (act) {
                 a.Cs[((size_t)(t + 1) * B + row) * XH + unit] = cp;
-                a.Hs[((size_t)(t + 1) * B + row) * XH + unit] = hn;
+                store_h_row(a.Hs + ((size_t)(t + 1) * B + row) * XH + unit, hn, wt);
                 zp[0] = g_si; zp[4] = g_tj; zp[8] = g_sf; zp[12] = g_so;
             }
         }
     }
     if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {
         a.Cs[((size_t)a.t1 * B + row) * XH + unit] = o_c;
-        a.Hs[((size_t)a.t1 * B + row) * XH + unit] = o_hh;
+        store_h_row(a.Hs + ((size_t)a.t1 * B + row) * XH + unit, o_hh, wt);
         float* zo = a.Z + ((size_t)(a.t1 - 1) * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
         zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+    }
+    if (wt) {                                     // the last `lag` steps: drain, barrier, publish
+        drain_vmem();
+        __syncthreads();
+        if (tid == 0 && pubs)
+            for (int tp = max(a.t0, a.t1 - lag); tp < a.t1; ++tp)
+                if (tp % pk == pk - 1 || tp == a.t1 - 1) __hip_atomic_fetch_add(a.progress + tp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (PROF && lane == 0 && a.prof) {
         XCD_STAMP(4)
@@ -1760,15 +1784,17 @@ static int xcd_row_groups(int B, int Hp) {
 bool lstm_xcd_supported(int B, int Hp) { return (Hp == XH || Hp == PH) && B >= 1 && xcd_row_groups(B, Hp) <= 4; }
 int lstm_xcd_max_rows(int Hp) { return Hp == PH ? 16 * PGRP : (Hp == XH ? 16 * NXCD : 0); }
 
-long long lstm_xcd_hx_floats(int B, int T, int Hp, bool bx3) {
+long long lstm_xcd_hx_floats(int B, int T, int Hp, bool bx3, int rpx) {
     if (Hp == PH) return (long long)(T + 1) * PGRP * 4 * xcd_row_groups(B, Hp) * PNQ * 64 * 4;
-    if (bx3) return (long long)(T + 1) * (4 * xcd_row_groups(B)) * NXCD * HXW16 * 4;      // rows x XCDs x 3 KiB, see k_lstm_fwd_xcd16
-    return (long long)(T + 1) * NXCD * 4 * xcd_row_groups(B) * 2 * 64 * 4;
+    if (bx3) return (long long)(T + 1) * (4 * xcd_row_groups_packed(B, rpx)) * NXCD * HXW16 * 4;      // rows x XCDs x 3 KiB, see k_lstm_fwd_xcd16
+    return (long long)(T + 1) * NXCD * 4 * xcd_row_groups_packed(B, rpx) * 2 * 64 * 4;
 }
-long long lstm_xcd_inbox_floats(int B, int Hp) {
+long long lstm_xcd_inbox_floats(int B, int Hp, int rpx) {
     if (Hp == PH) return 2LL * PGRP * PCU * xcd_row_groups(B, Hp) * PCU * 16 * 4;
-    return 2LL * NXCD * NCU * NCU * xcd_row_groups(B) * 16 * 4;
+    return 2LL * NXCD * NCU * NCU * xcd_row_groups_packed(B, rpx) * 16 * 4;
 }
+// the bf16-split kernels take up to 16 rows per XCD at the same MFMA cost: the fewest XCDs that hold B rows, rows spread evenly
+int lstm_xcd16_packed_rows(int B) { const int nx = (B + 15) / 16; return nx >= 1 && nx <= NXCD ? (B + nx - 1) / nx : 0; }
 long long lstm_xcd_weight_floats(int Hp, bool bx3) { return (bx3 && Hp == XH) ? (long long)Hp * 4 * Hp * 3 / 2 : (long long)Hp * 4 * Hp; }   // three bf16 planes
 // The bf16-split kernels pay 1536 MFMA cycles per step for any row count, the fp32 ones 1024 per row group, and the bf16 hand-off
 // is 1.5x the bytes in 3x the load instructions: measured (profiles/r03_xcd16_probe3.log, us per step forward / backward)
@@ -1786,7 +1812,7 @@ hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, floa
 
 // Variants chosen per shape (tools/xcd_chain_bench, profiles/r03_xcd_probe6*.log; B = 45: forward 2.21 -> 2.14 us per step with
 // the outputs deferred, backward 2.40 -> 2.34 without the sleep; B = 100: deferring costs 4 %, no sleep is neutral)
-int lstm_xcd_default_variant(int B, bool forward, int Hp) {
+int lstm_xcd_default_variant(int B, bool forward, int Hp, int rpx) {
     // hidden 1024 (profiles/r03_pair_probe3..5.log, us per step without / with chains): backward 9.0 -> 7.2 (three row groups),
     // 6.75 -> 5.1 (two), 12.2 -> 9.4 (four); forward 4.65 -> 4.2 with two row groups, but 6.1 -> 6.35 / 7.4 -> 8.4 with three / four
     // (its early polls are ready 95 % of the time: the hand-off IS hidden, the per-phase instruction overhead is what is left).
@@ -1798,7 +1824,7 @@ int lstm_xcd_default_variant(int B, bool forward, int Hp) {
         return XCD_NO_POLL_SLEEP;
     }
     if (!forward) return XCD_NO_POLL_SLEEP;
-    return xcd_row_groups(B) <= 2 ? (XCD_DEFER_OUTPUTS | XCD_NO_POLL_SLEEP) : XCD_NO_POLL_SLEEP;
+    return xcd_row_groups_packed(B, rpx) <= 2 ? (XCD_DEFER_OUTPUTS | XCD_NO_POLL_SLEEP) : XCD_NO_POLL_SLEEP;
 }
 
 hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {

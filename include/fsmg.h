@@ -55,8 +55,9 @@ enum { FSMG_CLIP_TF1_SLICES = 0, FSMG_CLIP_DENSE = 1 };
  * >= 2^-23 of the fp32 product summed on the bf16 matrix pipe: each product to within half an fp32 ulp, fp32 accumulation:
  * DESIGN.md section 4); F32 = v_mfma_f32_32x32x2_f32 */
 enum { FSMG_GEMM_AUTO = 0, FSMG_GEMM_BX3 = 1, FSMG_GEMM_F32 = 2 };
-/* order of a pass: AUTO picks from the shapes; SINGLE_STREAM = one hipGraph per pass; TWO_STREAM = projection GEMMs on an
- * auxiliary stream beside the recurrence (eager); XCD_PARTITIONED = recurrence packed on six XCDs, work-queue GEMMs on the rest */
+/* order of a pass: AUTO picks from the shapes; SINGLE_STREAM = one stream, serial; TWO_STREAM = projection GEMMs on an
+ * auxiliary stream beside the recurrence (eager); XCD_PARTITIONED = the bf16-split recurrence packed on ceil(rows / 16) XCDs, the
+ * projection / its weight gradient as work-queue GEMMs on the other XCDs beside it (hidden 512, one layer; AUTO picks it there) */
 enum { FSMG_SCHEDULE_AUTO = 0, FSMG_SCHEDULE_SINGLE_STREAM = 1, FSMG_SCHEDULE_TWO_STREAM = 2, FSMG_SCHEDULE_XCD_PARTITIONED = 3 };
 /* recurrent kernels: AUTO = the fastest family the shape admits; PER_STEP = one launch per time step; COLUMN_SPLIT = persistent,
  * gate columns over the chip (round 1); XCD_LOCAL = persistent, rows over the XCDs (hidden size 512) */
@@ -270,7 +271,8 @@ int fsmg_get_stats(fsmg_handle h, fsmg_stats* out);
  *   "h<l>" [T+1,B,Hp] (index 0 = zero state), "c<l>" [T+1,B,Hp], "gates<l>" [T,B,4Hp] (packed
  *   gate order, holds dz after a backward), "logits" [T*B,V1p], "lse" [T*B], "ce" [T*B];
  *   rows are TIME-major (row = t*B + b).  count = elements to copy (<= buffer size).
- *   "xcd_bx3" [1]: 1.0 when the handle runs the bf16-split XCD-local recurrent kernels (hidden 512, created for > 64 rows) */
+ *   "xcd_bx3" [1]: 1.0 when the handle runs the bf16-split XCD-local recurrent kernels (hidden 512: created for > 64 rows, or for
+ *   the XCD-partitioned schedule); "xcd_partitioned" [2]: 1.0 when train passes take the XCD-partitioned order, XCDs the chains occupy */
 int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count);
 /* run-time knobs of a handle that used to be create-time environment variables (tests, diagnostics):
  *   "chain_spin_limit"  polls before a persistent recurrent kernel gives up (0 forces the time-out path)

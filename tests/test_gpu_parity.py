@@ -705,18 +705,20 @@ def test_bf16_split_gemm_is_no_less_accurate_than_the_fp32_mfma_gemm(monkeypatch
 
 
 def test_xcd_partitioned_schedule_gives_the_same_bits(monkeypatch):
-    """FSMG_XCD_OVERLAP=1 (off by default): the recurrence packs its rows on six XCDs and work-queue
-    GEMMs on the auxiliary stream take tiles of the projection / of dW on the other two while it runs.  Which XCD computes a
-    tile, and when, must not change a bit: with dW's K split left as the default schedule picks it the losses and every
-    gradient are identical; with the schedule's own finer split only dW's summation order differs."""
+    """FSMG_XCD_OVERLAP=1 (fsmg_config.schedule = XCD_PARTITIONED): the bf16-split recurrence packs the 45
+    rows on three XCDs and publishes the time steps it has finished; the projection's 256 x 256 tiles are drawn from a work queue
+    by the other five XCDs as their rows arrive (and by the whole chip once the chain is over); backward, dW's tiles run beside
+    the BPTT chain the same way.  Which XCD computes a tile, and when, must not change a bit: against the SAME kernels in the
+    serial order (FSMG_XCD_BX3=1) the forward pair alone gives identical losses and gradients; with the backward pair only dW / dd
+    change their summation order (K split 6 instead of 3)."""
     over, N, K, Q = FULL['cfg-B']
     cfg = small_config(**over)
     eps = O.synthetic_episodes(3, N, K, Q, cfg['max_len'], cfg['input_size'], seed=29)
     out = []
-    monkeypatch.setenv('FSMG_GEMM', 'f32')       # the work-queue kernel exists for the fp32-MFMA GEMM only
-    for xov, split in (('0', '1'), ('1', '1'), ('1', '6')):
+    monkeypatch.setenv('FSMG_XCD_BX3', '1')
+    for xov, parts in (('0', '3'), ('1', '1'), ('1', '3')):
         monkeypatch.setenv('FSMG_XCD_OVERLAP', xov)
-        monkeypatch.setenv('FSMG_XOV_DW_SPLIT', split)
+        monkeypatch.setenv('FSMG_XOV_PARTS', parts)
         model = new_model(cfg)
         losses = [model.train_step(s_, q_) for s_, q_ in eps]
         model.forward_backward(*eps[0])
@@ -724,6 +726,7 @@ def test_xcd_partitioned_schedule_gives_the_same_bits(monkeypatch):
     assert out[0][0] == out[1][0]
     for k in out[0][1]:
         np.testing.assert_array_equal(out[0][1][k], out[1][1][k])
+        # (three updates with a dW that differs in its last bits: every tensor of the fourth pass may differ in ITS last bits)
         np.testing.assert_allclose(out[2][1][k], out[0][1][k], rtol=0, atol=1e-5 * np.abs(out[0][1][k]).max())
     np.testing.assert_allclose(out[2][0], out[0][0], rtol=1e-6)
     assert all(st['timeouts'] == 0 and st['xcd_launches'] > 0 for _, _, st in out)
@@ -890,6 +893,59 @@ def test_ten_consecutive_train_losses_at_cfg_b():
         assert abs(got - want) <= NLL_RTOL * abs(want), (s_, got, want)
     assert model.step == 10
     print('ten full-size cfg-B train losses: worst relative error %.2e' % worst)
+
+
+def test_ten_consecutive_train_losses_on_the_bf16_split_chain_at_cfg_d_rows():
+    """The same ten-loss trajectory on cfg-D's episode shape (20-way, 1-shot, 4 query songs: 100 sequences, hidden 512): the
+    bf16-split XCD-local recurrence with four row groups, the family cfg-D really runs (half the time steps of cfg-D to keep the
+    fp64 oracle to seconds; the recurrence's arithmetic does not depend on T)."""
+    over, N, K, Q = FULL['cfg-D']
+    cfg = small_config(**dict(over, max_len=64))
+    eps = O.synthetic_episodes(10, N, K, Q, cfg['max_len'], cfg['input_size'], seed=78, realistic=True)
+    model = new_model(cfg, max_sequences=N * (K + Q))
+    assert bool(model.debug_read('xcd_bx3', 1)[0])
+    params = f64_params(model)
+    opt = O.new_opt_state(params)
+    for s_, (sup, qry) in enumerate(eps):
+        want = O.train_step(params, opt, sup, qry, cfg)
+        got = model.train_step(sup, qry)
+        assert abs(got - want) <= NLL_RTOL * abs(want), (s_, got, want)
+    st = model.stats()
+    assert model.step == 10 and st['timeouts'] == 0 and st['xcd_launches'] > 0
+
+
+FORCED = [(env, i) for env in ({'FSMG_XCD_BX3': '1'}, {'FSMG_GEMM_H': '2'}, {'FSMG_XCD_OVERLAP': '0'}) for i in (2, 4, 9, 10, 11, 12)]
+
+
+@pytest.mark.parametrize('env,idx', FORCED, ids=['%s-%d' % (next(iter(e)) + '=' + next(iter(e.values())), i) for e, i in FORCED])
+def test_forced_kernel_families_on_a_reduced_shape_list(env, idx, monkeypatch):
+    """The kernel families a default run only picks at some shapes, forced at a reduced list of SHAPES (B = 45 rows, two stacked
+    layers, hidden 512 with 1 / 2 / 4 row groups and stacked): the bf16-split XCD-local recurrence (FSMG_XCD_BX3=1), the
+    256 x 256-tile GEMM wherever it can run (FSMG_GEMM_H=2), the serial order where AUTO would take the XCD-partitioned one
+    (FSMG_XCD_OVERLAP=0) -- loss, h, c and every gradient against the fp64 oracle, same bounds as the default families."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    over, N, K, Q = SHAPES[idx]
+    cfg = small_config(**over)
+    sup, qry = _episode(cfg, N, K, Q, seed=3)
+    model = new_model(cfg, max_sequences=N * (K + Q))
+    params = f64_params(model)
+    loss, cache, grads, aux = cached_oracle_step(('shape', repr(sorted(over.items())), N, K, Q), params, sup, qry, cfg)
+    B = N * (K + Q)
+    model.forward_backward(sup, qry)
+    tail = model.debug_read('tail', 16)
+    assert abs(tail[1] - loss) <= NLL_RTOL * abs(loss)
+    for l in range(cfg['n_layers']):
+        hs, cs, _ = read_states(model, cfg, l, B)
+        assert rel_max(hs, cache['layers'][l]['hs']) < 2e-5 and rel_max(cs, cache['layers'][l]['cs']) < 2e-5, 'layer %d' % l
+    for name in grads:
+        assert rel_max(model.get_grad(name), grads[name]) < 2e-4, name
+    assert abs(tail[0] - aux['embedding_slices_sq']) <= 1e-4 * aux['embedding_slices_sq']
+    opt = O.new_opt_state(params)
+    O.apply_update(params, grads, aux, opt, cfg)
+    assert abs(model.apply_update(1.0) - loss) <= NLL_RTOL * abs(loss)
+    for name, ref in params.items():
+        assert rel_max(model.get_param(name), ref) < 5e-4, name
 
 
 @pytest.mark.parametrize('kind', ['bx3', 'f32'])
