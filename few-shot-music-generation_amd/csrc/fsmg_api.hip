@@ -101,6 +101,7 @@ struct fsmg_model {
     int* table[MAX_TABLES] = {};        // device-resident packed splits [n_songs][T] (fsmg_upload_table)
     int64_t table_rows[MAX_TABLES] = {};
     int* d_idx = nullptr; int idx_cap = 0;
+    int* d_gather = nullptr; int64_t gather_cap = 0;     // episode rows gathered from a table for the MAML-style step (its two passes take device token buffers)
     // XCD-local recurrence (lstm_xcd.hip; hidden size 512): per layer the forward and backward register images of K_h,
     // the h hand-off buffer, the dh-partial inboxes and the per-launch ticket counters
     bool xcd = true;                    // FSMG_XCD=0: keep the column-split persistent kernels
@@ -1849,6 +1850,7 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->P_saved) hipFree(h->P_saved);
     for (int* t : h->table) if (t) hipFree(t);
     if (h->d_idx) hipFree(h->d_idx);
+    if (h->d_gather) hipFree(h->d_gather);
     if (h->d_eval) hipFree(h->d_eval);
     if (h->host_counters) hipHostFree(h->host_counters);
     if (h->own_state && h->state) hipFree(h->state);
@@ -2150,6 +2152,45 @@ int fsmg_maml_step(fsmg_handle h, const int32_t* support, const int32_t* query, 
         if (rc == FSMG_OK) rc = fsmg_apply_update(h, 1.0f, loss);
     }
     return rc;
+}
+
+// cfg-E on the device-resident split table: the episode's rows are gathered ONCE into a buffer of the handle's own and the
+// inner / outer passes read them there (an index outside the table raises the token-range flag like any bad token)
+static int gather_episode(fsmg_handle h, int32_t table_id, const int32_t* sup_idx, int n_sup, const int32_t* qry_idx, int n_qry) {
+    if (table_id < 0 || table_id >= fsmg_model::MAX_TABLES || !h->table[table_id]) return fail(h, FSMG_ERR_STATE, "no token table uploaded under this id");
+    const int n = n_sup + n_qry;
+    if (h->idx_cap < n || h->gather_cap < (int64_t)n * h->T) {
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        if (h->d_idx) hipFree(h->d_idx);
+        if (h->d_gather) hipFree(h->d_gather);
+        h->d_idx = nullptr; h->d_gather = nullptr; h->idx_cap = 0; h->gather_cap = 0;
+        const int cap = std::max(n, 4096);
+        if (hipMalloc((void**)&h->d_idx, sizeof(int) * cap) != hipSuccess || hipMalloc((void**)&h->d_gather, sizeof(int) * (size_t)cap * h->T) != hipSuccess)
+            return fail(h, FSMG_ERR_NOMEM, "hipMalloc(episode gather buffers) failed");
+        h->idx_cap = cap; h->gather_cap = (int64_t)cap * h->T;
+    }
+    if (n_sup > 0) HIPCK(h, hipMemcpyAsync(h->d_idx, sup_idx, sizeof(int) * n_sup, hipMemcpyHostToDevice, h->stream));
+    if (n_qry > 0) HIPCK(h, hipMemcpyAsync(h->d_idx + n_sup, qry_idx, sizeof(int) * n_qry, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, launch_gather_rows(h->stream, h->table[table_id], h->d_idx, n, h->T, (int)h->table_rows[table_id], h->d_gather, h->d_err));
+    return FSMG_OK;
+}
+
+int fsmg_maml_forward_backward_indexed(fsmg_handle h, int32_t table_id, const int32_t* support_idx, const int32_t* query_idx,
+                                       int32_t N, int32_t K, int32_t Q, int32_t inner_steps, float inner_lr) {
+    if (!h || !support_idx || !query_idx || N <= 0 || K <= 0 || Q <= 0) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    const int rc = gather_episode(h, table_id, support_idx, N * K, query_idx, N * Q);
+    if (rc != FSMG_OK) return rc;
+    return fsmg_maml_forward_backward(h, h->d_gather, h->d_gather + (size_t)N * K * h->T, N, K, Q, inner_steps, inner_lr, 1);
+}
+
+int fsmg_maml_step_indexed(fsmg_handle h, int32_t table_id, const int32_t* support_idx, const int32_t* query_idx,
+                           int32_t N, int32_t K, int32_t Q, int32_t inner_steps, float inner_lr, float* loss) {
+    if (!h || !support_idx || !query_idx || N <= 0 || K <= 0 || Q <= 0) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    const int rc = gather_episode(h, table_id, support_idx, N * K, query_idx, N * Q);
+    if (rc != FSMG_OK) return rc;
+    return fsmg_maml_step(h, h->d_gather, h->d_gather + (size_t)N * K * h->T, N, K, Q, inner_steps, inner_lr, 1, loss);
 }
 
 int fsmg_maml_eval(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K, int32_t Q,

@@ -81,6 +81,8 @@ SIGNATURES = {
     'fsmg_maml_forward_backward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32]),
     'fsmg_maml_step': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _F32P]),
     'fsmg_maml_eval': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _F32P]),
+    'fsmg_maml_forward_backward_indexed': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float]),
+    'fsmg_maml_step_indexed': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _F32P]),
     'fsmg_eval_step': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _F32P]),
     'fsmg_eval_batch': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F32P]),
     'fsmg_sample': (C.c_int, [_P, C.c_int32, _I32P]),
@@ -363,6 +365,19 @@ class FsmgModel(object):
         loss = C.c_float()
         self._ck(self._lib.fsmg_maml_step(self._h, sp, qp, n, k, q, int(inner_steps), float(inner_lr), dev,
                                           C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
+
+    def maml_forward_backward_indexed(self, table_id, support_idx, query_idx, inner_steps, inner_lr):
+        s, q = self._idx(support_idx, query_idx)
+        self._ck(self._lib.fsmg_maml_forward_backward_indexed(self._h, int(table_id), C.c_void_p(s.ctypes.data), C.c_void_p(q.ctypes.data),
+                                                              s.shape[0], s.shape[1], q.shape[1], int(inner_steps), float(inner_lr)))
+
+    def maml_step_indexed(self, table_id, support_idx, query_idx, inner_steps, inner_lr, want_loss=True):
+        s, q = self._idx(support_idx, query_idx)
+        loss = C.c_float()
+        self._ck(self._lib.fsmg_maml_step_indexed(self._h, int(table_id), C.c_void_p(s.ctypes.data), C.c_void_p(q.ctypes.data),
+                                                  s.shape[0], s.shape[1], q.shape[1], int(inner_steps), float(inner_lr),
+                                                  C.byref(loss) if want_loss else None))
         return loss.value if want_loss else None
 
     def maml_eval(self, support, query, inner_steps, inner_lr, shape=None):

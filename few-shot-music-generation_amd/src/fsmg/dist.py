@@ -67,12 +67,16 @@ class EpisodeParallel(object):
     def _train_step_once(self, support, query, want_loss=True, maml=None, table=None, **kw):
         if self.world == 1 and maml is None and hasattr(self.engine, 'fused_train_step'):
             return self.engine.fused_train_step(support, query, want_loss=want_loss, table=table, **kw)
+        if self.world == 1 and maml is not None and table is not None and hasattr(self.engine, 'fused_maml_step'):
+            return self.engine.fused_maml_step(support, query, maml[0], maml[1], want_loss=want_loss, table=table)
         if getattr(self.engine, 'library_comm', False):
             # the library owns the exchange (fsmg_comm_init): one call per step and rank, collectives issued by libfsmg
             if maml is not None:
-                return self.engine.fused_maml_step(support, query, maml[0], maml[1], want_loss=want_loss, **kw)
+                return self.engine.fused_maml_step(support, query, maml[0], maml[1], want_loss=want_loss, table=table, **kw)
             return self.engine.fused_train_step(support, query, want_loss=want_loss, table=table, **kw)
-        if table is not None:                 # support / query are [N,K] / [N,Q] row indices into a device-resident split table
+        if table is not None and maml is not None:      # cfg-E on the device-resident table: per-rank inner loop, then the exchange below
+            self.engine.maml_forward_backward_indexed(table, support, query, maml[0], maml[1])
+        elif table is not None:               # support / query are [N,K] / [N,Q] row indices into a device-resident split table
             self.engine.forward_backward_indexed(table, support, query)
         elif maml is not None:
             self.engine.maml_forward_backward(support, query, maml[0], maml[1], **kw)

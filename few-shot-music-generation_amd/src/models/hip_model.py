@@ -97,8 +97,13 @@ class HIPModel(BaseModel):
     def apply_update(self, grad_scale=1.0, want_loss=True):
         return self._model.apply_update(grad_scale, want_loss=want_loss)
 
-    def fused_maml_step(self, support, query, inner_steps, inner_lr, want_loss=True, **kw):
+    def fused_maml_step(self, support, query, inner_steps, inner_lr, want_loss=True, table=None, **kw):
+        if table is not None:       # support / query are row indices into the device-resident split table
+            return self._model.maml_step_indexed(table, support, query, inner_steps, inner_lr, want_loss=want_loss)
         return self._model.maml_step(support, query, inner_steps, inner_lr, want_loss=want_loss, **kw)
+
+    def maml_forward_backward_indexed(self, table_id, support_idx, query_idx, inner_steps, inner_lr):
+        self._model.maml_forward_backward_indexed(table_id, support_idx, query_idx, inner_steps, inner_lr)
 
     # -- the gradient exchange inside the library (fsmg_comm_*: RCCL calls issued by libfsmg on its own stream) ----------
     library_comm = False

@@ -84,7 +84,9 @@ class LSTMBaseline(HIPModel):
 
     def log_deferred_losses(self, losses):
         """Train/loss scalars of steps that ran with want_loss=False, written when train.train folds them in"""
-        first = self._train_calls - len(losses)
+        # labelled by the step the device really applied (global_step counts those; a skipped step leaves no loss behind), so the
+        # window's last loss carries the current global_step - 1
+        first = self._model.step - len(losses)
         for i, loss in enumerate(losses):
             self._log_scalar('Train/loss', float(loss), max(first + i, 0))
 

@@ -33,24 +33,16 @@ class MAMLLSTM(LSTMBaseline):
         self._train_calls += 1
         return loss
 
-    # train.train's fast path (episodes as row indices into the split's packed token table, losses left on the device): the
+    # train.train's fast path (episodes as row indices into the split's device-resident token table, losses left on the device): the
     # inherited LSTMBaseline.train_indexed would run the PLAIN baseline step -- inner loop skipped, training and evaluation
-    # silently disagreeing.  The table stays on the host here: the rows of an episode are gathered into the
-    # [N, K, T] / [N, Q, T] tensors MAML's two passes need, and the step keeps the deferred-loss convention.
-    def attach_table(self, split, table):
-        import numpy as np
-        if not hasattr(self, '_host_tables'):
-            self._host_tables = {}
-        self._host_tables[split] = np.ascontiguousarray(table, dtype=np.int32)
-
+    # silently disagreeing.  The table lives on the device like the baseline's (inherited attach_table): the episode's
+    # rows are gathered there once and both passes of the step read them in place (fsmg_maml_step_indexed).
     def train_indexed(self, split, support_idx, query_idx, want_loss=False):
         import numpy as np
         self._require_init()
-        table = self._host_tables[split]
-        support = table[np.asarray(support_idx, dtype=np.int64)]
-        query = table[np.asarray(query_idx, dtype=np.int64)]
-        loss = self._parallel.train_step(self._tokens(support, 3), self._tokens(query, 3), want_loss=want_loss,
-                                         maml=(self._inner_steps, self._inner_lr))
+        loss = self._parallel.train_step(np.ascontiguousarray(support_idx, dtype=np.int32),
+                                         np.ascontiguousarray(query_idx, dtype=np.int32), want_loss=want_loss,
+                                         table=self.TABLE_IDS[split], maml=(self._inner_steps, self._inner_lr))
         if want_loss:
             self._log_scalar('Train/loss', loss, self._train_calls)
         self._train_calls += 1

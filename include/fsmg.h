@@ -220,6 +220,11 @@ int fsmg_maml_step(fsmg_handle h, const int32_t* support, const int32_t* query, 
                    int32_t inner_steps, float inner_lr, int32_t tokens_on_device, float* loss);
 int fsmg_maml_eval(fsmg_handle h, const int32_t* support, const int32_t* query, int32_t N, int32_t K, int32_t Q,
                    int32_t inner_steps, float inner_lr, int32_t tokens_on_device, float* nll);
+/* the same two on the device-resident split table (fsmg_upload_table): the episode is N*K + N*Q ROW INDICES (host int32) */
+int fsmg_maml_forward_backward_indexed(fsmg_handle h, int32_t table_id, const int32_t* support_idx, const int32_t* query_idx,
+                                       int32_t N, int32_t K, int32_t Q, int32_t inner_steps, float inner_lr);
+int fsmg_maml_step_indexed(fsmg_handle h, int32_t table_id, const int32_t* support_idx, const int32_t* query_idx,
+                           int32_t N, int32_t K, int32_t Q, int32_t inner_steps, float inner_lr, float* loss);
 
 /* replaces LSTMBaseline.sample (src/models/lstm_baseline.py:135-156): greedy argmax decode of
  * `num` tokens from the start word and a zero state (the support set is ignored there). */

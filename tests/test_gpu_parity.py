@@ -388,6 +388,33 @@ def test_inbox_refill_flag_survives_the_fallback_period():
         np.testing.assert_array_equal(a.get_param(k), v)
 
 
+def test_partitioned_schedule_times_out_and_recovers(monkeypatch):
+    """The XCD-partitioned order under a forced time-out: the packed chain gives up at its first wait (spin limit 0), the gated
+    projection tiles see the flag and leave, the step is skipped on the device and repeated on per-step launches; later steps go
+    back to the partitioned order.  Against a handle that runs the same kernel families without ever timing out: same bits."""
+    monkeypatch.setenv('FSMG_XCD_OVERLAP', '1')
+    cfg = small_config(hidden_size=512, embedding_size=32, input_size=3000, max_len=32)
+    eps = O.synthetic_episodes(5, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=35)
+    a, b = new_model(cfg, max_sequences=45), new_model(cfg, max_sequences=45)
+    assert a.debug_read('xcd_partitioned', 2)[0] == 1.0 and bool(a.debug_read('xcd_bx3', 1)[0])
+    la, lb = [a.train_step(*eps[0])], [b.train_step(*eps[0])]
+    a.debug_set('fallback_steps', 2)
+    a.debug_set('chain_spin_limit', 0)
+    la.append(a.train_step(*eps[1]))
+    st = a.stats()
+    assert st['timeouts'] == 1 and st['steps_skipped_timeout'] == 1 and a.step == 2
+    a.debug_set('chain_spin_limit', 1 << 18)
+    b.debug_set('persistent', 0)
+    lb.append(b.train_step(*eps[1]))
+    b.debug_set('persistent', 1)
+    for e in eps[2:]:
+        la.append(a.train_step(*e)); lb.append(b.train_step(*e))
+    assert a.stats()['persistent_path'] and a.stats()['timeouts'] == 1
+    assert la == lb
+    for k, v in b.get_params().items():
+        np.testing.assert_array_equal(a.get_param(k), v)
+
+
 def test_eager_and_graph_replayed_passes_give_the_same_bits():
     """Passes on the persistent recurrent kernels are issued eagerly by default (the caller's device token buffers are read in
     place); debug_set('eager', 0) replays them from hipGraphs with staged tokens.  Same kernels, same order: same bits."""
@@ -914,7 +941,8 @@ def test_ten_consecutive_train_losses_on_the_bf16_split_chain_at_cfg_d_rows():
     assert model.step == 10 and st['timeouts'] == 0 and st['xcd_launches'] > 0
 
 
-FORCED = [(env, i) for env in ({'FSMG_XCD_BX3': '1'}, {'FSMG_GEMM_H': '2'}, {'FSMG_XCD_OVERLAP': '0'}) for i in (2, 4, 9, 10, 11, 12)]
+FORCED = [(env, i) for env in ({'FSMG_XCD_BX3': '1'}, {'FSMG_GEMM_H': '2'}, {'FSMG_XCD_OVERLAP': '0'}) for i in (2, 4, 9, 10, 11, 12)] + \
+         [({'FSMG_XCD_OVERLAP': '1'}, i) for i in (9, 10)]      # ... and the XCD-partitioned order at shapes AUTO finds too small for it
 
 
 @pytest.mark.parametrize('env,idx', FORCED, ids=['%s-%d' % (next(iter(e)) + '=' + next(iter(e.values())), i) for e, i in FORCED])
