@@ -97,7 +97,7 @@ def hbm_traffic():
     process, so this is not a measurement of this run.  No x2 on FETCH_SIZE: the guide's gfx950 correction is calibrated for
     16-B/lane streaming loads, and these kernels' raw FETCH_SIZE (47.7 MB forward) already equals their algorithmic read
     (Z: 47.2 MB).  (None, None) when no record exists."""
-    for name in ('r03_lstm_cell_pmc.json', 'r02_lstm_cell_pmc.json'):
+    for name in ('r04_lstm_cell_pmc.json', 'r03_lstm_cell_pmc.json', 'r02_lstm_cell_pmc.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 rec = json.load(f)

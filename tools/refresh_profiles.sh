@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the round artefacts on the GPU box into gpurun_out/ (copy the ones to keep into profiles/).
 #   gpurun -- tools/refresh_profiles.sh [tag]
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
@@ -55,3 +55,13 @@ if f and w:
 json.dump(out, open('%s/%s_lstm_cell_pmc.json' % (O, TAG), 'w'), indent=1)
 print(json.dumps(out))
 PY
+# round 4: the reference's own default dims, the serial order beside the partitioned one (same box), ref-default timeline
+cd /tmp
+python $R/bench.py --config ref-default --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_ref-default.json
+FSMG_HP_ALIGN=16 python $R/bench.py --config ref-default --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_ref-default_hp208.json
+FSMG_XCD_OVERLAP=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_serial_order.json
+rm -rf /tmp/prof_ser; FSMG_XCD_OVERLAP=0 rocprofv3 --kernel-trace --stats -d /tmp/prof_ser -o st -- python $R/bench.py --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > /dev/null
+python $R/tools/step_timeline.py $(find /tmp/prof_ser -name "*.db" | head -1) 150 > $O/${TAG}_step_timeline_serial_order.txt 2>&1
+rm -rf /tmp/prof_rd; rocprofv3 --kernel-trace --stats -d /tmp/prof_rd -o st -- python $R/bench.py --config ref-default --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > /dev/null
+python $R/tools/step_timeline.py $(find /tmp/prof_rd -name "*.db" | head -1) 150 > $O/${TAG}_refdefault_step_timeline.txt 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/prof_rd -name "*.db" | head -1) > $O/${TAG}_refdefault_rocprofv3_kernel_stats.txt 2>&1
