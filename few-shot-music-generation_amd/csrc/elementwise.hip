@@ -701,7 +701,7 @@ hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, c
 hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt,
                           float* lse, float* ce, float* dlogits, float inv_n) {
     if (rows <= 0) return hipSuccess;
-    static const int nt = std::getenv("FSMG_DLOGITS_NT") ? std::atoi(std::getenv("FSMG_DLOGITS_NT")) : 1;      // A/B: non-temporal dlogits stores
+    const int nt = 1;      // non-temporal dlogits stores (A/B settled in round 3: the regular-store instantiations stay for the record)
     if (ld <= 6 * 1024) {
         if (nt) hipLaunchKernelGGL((k_ce_rows_reg<6, true>), dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
         else hipLaunchKernelGGL((k_ce_rows_reg<6, false>), dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);

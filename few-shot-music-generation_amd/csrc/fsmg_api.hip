@@ -848,6 +848,9 @@ inline int* next_tickets(fsmg_model* h) {
     return t;
 }
 
+#ifdef FSMG_EXPERIMENTS
+inline int xov_debug() { static const int dbg = std::getenv("FSMG_XOV_DEBUG") ? std::atoi(std::getenv("FSMG_XOV_DEBUG")) : 0; return dbg; }
+#endif
 // Work-queue GEMM in two launches of k_gemm_bx3h<..., QUEUE> (GemmArgs::xcd_first): the restricted one lets the XCDs >= first
 // draw items (all of them: the two launches drain one queue); the clean-up one, ordered behind the kernel that owned the other
 // XCDs, lets the whole chip take what is left.  work / claim words are zeroed on the main stream before the fork.
@@ -861,19 +864,23 @@ inline void xov_gate(fsmg_model* h, GemmArgs& g, int B) {     // the projection'
     g.gate_err = h->d_err; g.gate_spin = h->chain_spin_limit > 0 ? 20000 : 0; g.gate_every = h->xov_pub;
 }
 int gemm_restricted(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int first, int* ctl) {
-    static const int dbg = std::getenv("FSMG_XOV_DEBUG") ? std::atoi(std::getenv("FSMG_XOV_DEBUG")) : 0;
-    g.bx3 = 3; g.xcd_first = first; g.work = ctl; g.stop = ctl + 2; g.claim = ctl + 4; g.work_limit = (dbg & 1) ? 0 : gemm_items(g);
+    g.bx3 = 3; g.xcd_first = first; g.work = ctl; g.stop = ctl + 2; g.claim = ctl + 4; g.work_limit = gemm_items(g);
+#ifdef FSMG_EXPERIMENTS         // FSMG_XOV_DEBUG (make experiments): the A/B runs of DESIGN.md 9.2
+    const int dbg = xov_debug();
+    if (dbg & 1) g.work_limit = 0;                 // nothing for the restricted launch: the serial order on the packed kernels
     if ((dbg & 1) && (dbg & (128 | 256))) g.gate = nullptr;
-    if (dbg & 4) g.gate_spin = -g.gate_spin;       // (diagnostic: the gated blocks sleep once more behind a passed gate)
-    if (dbg & 16) g.dbg |= 32;                     // (diagnostic: agent-scope loads of the gated operand)
-    if (dbg & 8) g.dbg |= 128;                     // (diagnostic: agent-scope acquire behind the gate)
-    if (dbg & 32) g.dbg |= 64;                     // (diagnostic: blocks below xcd_first never join)
+    if (dbg & 16) g.dbg |= 32;                     // agent-scope loads of the gated operand
+    if (dbg & 8) g.dbg |= 128;                     // agent-scope acquire behind the gate
+    if (dbg & 32) g.dbg |= 64;                     // blocks below xcd_first never join
+#endif
     HIPCK(h, launch_gemm(s, amode, bmode, g, 0));
     return FSMG_OK;
 }
 int gemm_cleanup(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int* ctl) {
     g.bx3 = 3; g.xcd_first = -1; g.work = ctl; g.claim = ctl + 4;
-    { static const int dbg = std::getenv("FSMG_XOV_DEBUG") ? std::atoi(std::getenv("FSMG_XOV_DEBUG")) : 0; if ((dbg & 1) && (dbg & (128 | 256))) g.gate = nullptr; }
+#ifdef FSMG_EXPERIMENTS
+    if ((xov_debug() & 1) && (xov_debug() & (128 | 256))) g.gate = nullptr;
+#endif
     HIPCK(h, launch_gemm(s, amode, bmode, g, 0));
     return FSMG_OK;
 }
@@ -886,8 +893,7 @@ GemmArgs logits_args(fsmg_model* h, int B, int t0, int t1) {
     g.A = h->Hs[h->L - 1] + (size_t)B * Hp + (size_t)r0 * Hp; g.lda = Hp;
     g.B = h->P + h->off_w; g.ldb = h->V1p;
     g.C = h->logits + (size_t)r0 * h->V1p; g.ldc = h->V1p; g.M = (int)m; g.N = h->V1p; g.K = Hp;
-    static const int nt = std::getenv("FSMG_LOGITS_NT") ? std::atoi(std::getenv("FSMG_LOGITS_NT")) : 1;         // A/B: non-temporal logits stores
-    g.bias = h->P + h->off_d; g.ksplit = 1; g.nt_store = nt;
+    g.bias = h->P + h->off_d; g.ksplit = 1; g.nt_store = 1;      // streaming stores: read back by the cross entropy much later (A/B: profiles/r03t_ntp_*)
     return g;
 }
 int ce_rows(fsmg_model* h, hipStream_t s, int B, int t0, int t1, int64_t rows_total) {
@@ -1013,8 +1019,9 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
                 ScopedTimer tm(h, "lstm_fwd");
                 LstmFwdXcdArgs a{};
                 a.rpx = (xov && top) ? rpx : 0; a.progress = (xov && top) ? h->xov_prog : nullptr; a.Hp = Hp;
-                { static const int dbg = std::getenv("FSMG_XOV_DEBUG") ? std::atoi(std::getenv("FSMG_XOV_DEBUG")) : 0;
-                  a.progress_lag = ((dbg & 2) ? 2 : 0) | ((dbg & 256) ? 256 : 0); if ((dbg & 128) && (dbg & 1)) a.progress = nullptr; }
+#ifdef FSMG_EXPERIMENTS
+                { const int dbg = xov_debug(); a.progress_lag = ((dbg & 2) ? 2 : 0) | ((dbg & 256) ? 256 : 0); if ((dbg & 128) && (dbg & 1)) a.progress = nullptr; }
+#endif
                 a.progress_every = h->xov_pub; a.bx3 = h->xcd_bx3 ? 1 : 0;
                 a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, true, Hp, a.rpx);
                 a.KhX = h->khx + (size_t)(2 * l) * lstm_xcd_weight_floats((int)Hp, h->xcd_bx3); a.HX = h->HX; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
@@ -1750,10 +1757,12 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_XOV_DW_SPLIT")) h->xov_dw_split = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("FSMG_XOV_PARTS")) h->xov_parts = std::max(1, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_XOV_PUB")) h->xov_pub = std::max(1, std::min(64, std::atoi(e)));
-        if (const char* e = std::getenv("FSMG_XOV_TAIL")) h->xov_tail = std::max(0, std::min(64, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_EAGER")) h->eager = (e[0] != '0');
+#ifdef FSMG_EXPERIMENTS         // settled A/Bs: experiment builds only
         if (const char* e = std::getenv("FSMG_FILL_EARLY")) h->fill_early = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_FILLS_LATE")) h->fills_late = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_XOV_TAIL")) h->xov_tail = std::max(0, std::min(64, std::atoi(e)));
+#endif
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
         h->persist_cfg = h->persist;
         if (const char* e = std::getenv("FSMG_FALLBACK_STEPS")) h->fallback_steps = std::max(1, std::atoi(e));

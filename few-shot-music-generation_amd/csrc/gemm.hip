@@ -1119,7 +1119,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
             // below xcd_first: the XCDs of the kernel this launch runs beside.  A block can only be placed there before that kernel
             // has taken its CUs (leave at once) or after it has left them (gated launches: join the drawing when it is really over)
             if ((xcc & 7) < g.xcd_first) {
-                if (g.gate == nullptr || (g.dbg & 64)) return;
+#ifdef FSMG_EXPERIMENTS
+                if (g.dbg & 64) return;
+#endif
+                if (g.gate == nullptr) return;
                 // ONE thread decides for the block: the counter may be completing while the block reads it, and a block whose threads
                 // disagree would go on with half its waves (first version: half-computed tiles, one step in three)
                 if (tid == 0) s_item = __hip_atomic_load(g.gate + g.gate_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= g.gate_expect;
@@ -1142,8 +1145,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
                 const int tm_ = (item / tilesN) % tilesM;
                 int t_need = (min(g.M, (tm_ + 1) * XT) - 1) / g.gate_rows;
                 if (g.gate_every > 1) t_need = min(g.gate_last, (t_need / g.gate_every + 1) * g.gate_every - 1);
-                const int spin_cap = g.gate_spin < 0 ? -g.gate_spin : g.gate_spin;
-                if (g.gate_spin < 0) for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(127);       // diagnostic: ~4 us at 2 GHz
+                const int spin_cap = g.gate_spin;
                 for (int spins = 0; __hip_atomic_load(g.gate + t_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.gate_expect; ++spins) {
                     __builtin_amdgcn_s_sleep(32);
                     if (spins >= spin_cap || ((spins & 63) == 63 && __hip_atomic_load(g.gate_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) {
@@ -1163,7 +1165,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
         // consumer pair of kernels on different XCDs work), and a row enters it only through loads issued behind that row's gate.
         // Measured alternatives (profiles/r04_xov_*.log): an agent-scope acquire here empties the L2 for every block of the XCD
         // (920 times in 0.5 ms; 105 instead of 85 us per tile), agent-scope (sc1) loads of the operand bypass the L2 (the same 105 us).
-        if (g.gate != nullptr && (g.dbg & 128)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (diagnostic)
+#ifdef FSMG_EXPERIMENTS
+        if (g.gate != nullptr && (g.dbg & 128)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (the measured alternative)
+#endif
         tm = (item / tilesN) % tilesM; tn = item % tilesN; z = item / (tilesM * tilesN);
     } else {
         const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
@@ -1191,7 +1195,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     typename BxStagerSel<DMA, BMODE, XT, 512, (BUFM >= 1)>::type sb;
     if constexpr (DMA && AMODE == OP_XC) sa.init(g.A, g.lda, g.M, m0, nullptr, kb, tid, g.K, smem + 2 * STAGE + wave * 2048);
     else sa.init(g.A, g.lda, g.M, m0, g.gather, kb, tid, g.K);
-    if constexpr (QUEUE && AMODE == OP_KC && BUFM >= 2) sa.coherent = g.gate != nullptr && (g.dbg & 32) != 0;     // (diagnostic: agent-scope loads)
+#ifdef FSMG_EXPERIMENTS
+    if constexpr (QUEUE && AMODE == OP_KC && BUFM >= 2) sa.coherent = g.gate != nullptr && (g.dbg & 32) != 0;     // (the measured alternative: agent-scope loads)
+#endif
     if constexpr (DMA && BMODE == OP_XC) sb.init(g.B, g.ldb, g.N, n0, nullptr, kb, tid, g.K, smem + 2 * STAGE + ((AMODE == OP_XC) ? 8 * 2048 : 0) + wave * 2048);
     else sb.init(g.B, g.ldb, g.N, n0, nullptr, kb, tid, g.K);
 
@@ -1340,7 +1346,11 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     const bool a_buf = g.gather == nullptr && a_bytes < 0xfffff000LL, b_buf = b_bytes < 0xfffff000LL;
     static const bool buf_off = std::getenv("FSMG_GEMM_BUF") && std::atoi(std::getenv("FSMG_GEMM_BUF")) == 0;      // A/B runs
     const int bufm = (buf_off && g.prof == nullptr) ? 0 : (a_buf && b_buf) ? 2 : (b_buf ? 1 : 0);
+#ifdef FSMG_EXPERIMENTS
     if (g.prof != nullptr && bufm != 2) return hipErrorInvalidValue;     // the stamped instantiations exist for bufm == 2 only
+#else
+    if (g.prof != nullptr) return hipErrorInvalidValue;                  // stamped instantiations + ablations: experiment builds only (make experiments)
+#endif
     if (g.bx3 == 3) {        // 256 x 256 tile
         dim3 grid3(((g.M + 255) / 256) * ((g.N + 255) / 256), g.ksplit > 1 ? g.ksplit : 1);
         // x-contiguous operands through LDS-DMA where their shape allows 16-byte row pieces (BxDmaXC)
@@ -1351,25 +1361,33 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
         // 10 -> 4 loads, 3700 -> 3820: not used there)
         const bool dma = !dma_off && bufm == 2 && a_dma && b_dma;
         if constexpr (AMODE == OP_XC && BMODE == OP_XC) {
+#ifdef FSMG_EXPERIMENTS
             if (dma && g.prof != nullptr) { hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, true, 3>), grid3, dim3(512), lds_pad, s, g); return hipGetLastError(); }
+#endif
             if (dma) { hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 3>), grid3, dim3(512), lds_pad, s, g); return hipGetLastError(); }
         }
-        if (g.prof != nullptr) hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, true, 2>), grid3, dim3(512), lds_pad, s, g);
-        else if (bufm == 2) hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 2>), grid3, dim3(512), lds_pad, s, g);
+#ifdef FSMG_EXPERIMENTS
+        if (g.prof != nullptr) { hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, true, 2>), grid3, dim3(512), lds_pad, s, g); return hipGetLastError(); }
+#endif
+        if (bufm == 2) hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 2>), grid3, dim3(512), lds_pad, s, g);
         else if (bufm == 1) hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 1>), grid3, dim3(512), lds_pad, s, g);
         else hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE>), grid3, dim3(512), lds_pad, s, g);
         return hipGetLastError();
     }
     if (g.bx3 == 2) {        // wave-specialised variant
-        if (g.prof != nullptr) hipLaunchKernelGGL((k_gemm_bx3w<AMODE, BMODE, 1, true, 2>), grid, dim3(512), lds_pad, s, g);
-        else if (bufm == 2) hipLaunchKernelGGL((k_gemm_bx3w<AMODE, BMODE, 1, false, 2>), grid, dim3(512), lds_pad, s, g);
+#ifdef FSMG_EXPERIMENTS
+        if (g.prof != nullptr) { hipLaunchKernelGGL((k_gemm_bx3w<AMODE, BMODE, 1, true, 2>), grid, dim3(512), lds_pad, s, g); return hipGetLastError(); }
+#endif
+        if (bufm == 2) hipLaunchKernelGGL((k_gemm_bx3w<AMODE, BMODE, 1, false, 2>), grid, dim3(512), lds_pad, s, g);
         else if (bufm == 1) hipLaunchKernelGGL((k_gemm_bx3w<AMODE, BMODE, 1, false, 1>), grid, dim3(512), lds_pad, s, g);
         else hipLaunchKernelGGL((k_gemm_bx3w<AMODE, BMODE, 1>), grid, dim3(512), lds_pad, s, g);
         return hipGetLastError();
     }
     if (g.bx3) {             // (gathered K rows included: BxStager)
-        if (g.prof != nullptr) hipLaunchKernelGGL((k_gemm_bx3<AMODE, BMODE, true, 2>), grid, dim3(256), lds_pad, s, g);
-        else if (bufm == 2) hipLaunchKernelGGL((k_gemm_bx3<AMODE, BMODE, false, 2>), grid, dim3(256), lds_pad, s, g);
+#ifdef FSMG_EXPERIMENTS
+        if (g.prof != nullptr) { hipLaunchKernelGGL((k_gemm_bx3<AMODE, BMODE, true, 2>), grid, dim3(256), lds_pad, s, g); return hipGetLastError(); }
+#endif
+        if (bufm == 2) hipLaunchKernelGGL((k_gemm_bx3<AMODE, BMODE, false, 2>), grid, dim3(256), lds_pad, s, g);
         else if (bufm == 1) hipLaunchKernelGGL((k_gemm_bx3<AMODE, BMODE, false, 1>), grid, dim3(256), lds_pad, s, g);
         else hipLaunchKernelGGL((k_gemm_bx3<AMODE, BMODE>), grid, dim3(256), lds_pad, s, g);
         return hipGetLastError();

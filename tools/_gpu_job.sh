@@ -1,12 +1,10 @@
-# scratch job script for `gpurun -- 'bash tools/_gpu_job.sh'` (overwritten per experiment)
+# scratch job script for `gpurun -- 'bash tools/_gpu_job.sh'` (overwritten per experiment): the round-end checks
 cd $GRAFT_REPO_ROOT
-bash tools/refresh_profiles.sh r04 > gpurun_out/r04_refresh.log 2>&1
-tail -5 gpurun_out/r04_refresh.log
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+timeout 3000 python -m pytest tests -m gpu -q -x > $O/r04s_pytest.log 2>&1; tail -12 $O/r04s_pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py 2>/dev/null | tail -1 > $O/r04s_bench.json
 python - <<PY
-import json,glob
-for n in sorted(glob.glob('gpurun_out/r04_bench*.json')):
-    try:
-        d=json.load(open(n)); print('%-50s' % n[11:], round(d['value'],1), round(d['ms_per_step'],4), d['guard']['ok'], 'frac', round(d.get('roofline',{}).get('frac',0),4), d.get('roofline',{}).get('schedule'), round((d.get('roofline_step') or {}).get('frac',0),3))
-    except Exception as e:
-        print(n, 'FAILED', e)
+import json
+d=json.load(open('gpurun_out/r04s_bench.json')); print('bench', round(d['value'],1), round(d['ms_per_step'],4), d['guard']['ok'], round(d['roofline']['frac'],4), d['roofline'].get('schedule'), round(d['roofline_step']['frac'],3), d['cpu_baseline']['value'], d['extras_failed'])
 PY

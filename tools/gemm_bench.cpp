@@ -1,6 +1,6 @@
 // Standalone timing harness for csrc/gemm.hip at the cfg-B shapes of the step (links build/gemm.o directly):
 //   make -C few-shot-music-generation_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 \
-//       -Ifew-shot-music-generation_amd/csrc -Iinclude tools/gemm_bench.cpp few-shot-music-generation_amd/build/gemm.o -o tools/gemm_bench.bin
+//       -Ifew-shot-music-generation_amd/csrc -Iinclude tools/gemm_bench.cpp few-shot-music-generation_amd/build/exp/gemm.o -o tools/gemm_bench.bin   (make -C few-shot-music-generation_amd/csrc experiments: the stamped instantiations live in the experiment build)
 // Usage: gemm_bench.bin [reps] [blocks_per_cu] [verify 0/1: compare every result with a naive fp32 kernel]      (blocks_per_cu < 4 applies the aux-stream LDS cap)
 // Prints per shape: ksplit, kernel-only ms (GEMM without the slab reduce), total ms, TF on the total.
 #include "fsmg_kernels.h"

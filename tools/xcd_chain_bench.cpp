@@ -7,7 +7,7 @@
 //      per step at T = 128 next to the column-split persistent kernels of lstm_step.hip; VARIANT=<XCD_* bits> selects the
 //      variant the correctness / timing / profile legs run (the variant sweep line always covers 16 / 32 / 48)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ifew-shot-music-generation_amd/csrc -Iinclude -c tools/xcd_chain_bench.cpp -o /tmp/xcb.o
-//        hipcc --offload-arch=gfx950 /tmp/xcb.o few-shot-music-generation_amd/build/lstm_xcd.o few-shot-music-generation_amd/build/lstm_step.o few-shot-music-generation_amd/build/gemm.o -o tools/xcd_chain_bench.bin
+//        hipcc --offload-arch=gfx950 /tmp/xcb.o few-shot-music-generation_amd/build/exp/lstm_xcd.o few-shot-music-generation_amd/build/exp/lstm_step.o few-shot-music-generation_amd/build/exp/gemm.o -o tools/xcd_chain_bench.bin
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
