@@ -474,6 +474,22 @@ def main():
                 eng.timing_enable(False)
             except Exception:                  # noqa: BLE001
                 pass
+    # sustained shader clock beside the step: a one-wave probe on its own stream compares the shader-clock counter with the 100 MHz
+    # real-time counter while a few train steps run (the peaks of every `frac` are quoted at the 2.4 GHz spec clock)
+    clock_ghz = None
+    try:
+        n_clk = max(4, min(args.steps, 12))
+        eng.synchronize()
+        for i in range(2):
+            step(i)
+        eng.clock_begin(int(0.8 * n_clk * 1e3 * schedules[used]['ms_per_step']))
+        for i in range(n_clk + 2):
+            step(2 + i)
+        clock_ghz = eng.clock_end()
+        eng.synchronize()
+    except Exception as e:                     # noqa: BLE001
+        log('clock probe failed: %r' % (e,))
+        extras_failed['clock_probe'] = repr(e)
     # communication (N > 1): the all-reduce of the flat gradient buffer alone on the library's stream, and per schedule what the
     # exchange adds to the same timed loop without any exchange (= the exposed, un-overlapped part)
     comm = None
@@ -552,6 +568,9 @@ def main():
                                'v_mfma_f32_16x16x32_bf16, fp32 accumulation')
             elif cfg['hidden_size'] > 512:
                 cell_kernel = 'k_lstm_fwd_pair* + k_lstm_bwd_pair* (recurrent [B x H] x [H x 4H] contraction on v_mfma_f32_4x4x1_16B_f32, K_h in the registers of an XCD pair'
+            elif 192 < cfg['hidden_size'] <= 256:
+                cell_kernel = ('k_lstm_fwd_slice + k_lstm_bwd_slice (hidden size padded to 256: two register-resident copies of K_h per XCD, sixteen row slices, '
+                               'recurrent [B x H] x [H x 4H] contraction on v_mfma_f32_4x4x1_16B_f32')
             elif cfg['hidden_size'] != 512:
                 cell_kernel = ('k_lstm_fwd_chain + k_lstm_bwd_rs / k_lstm_bwd_chain (column-split persistent kernels: gate columns over the chip, cross-XCD hand-off; '
                                'recurrent [B x H] x [H x 4H] contraction on v_mfma_f32_16x16x4_f32')
@@ -572,6 +591,9 @@ def main():
                         'schedule; latency-bound chain: us_per_time_step is the figure to watch (0.60 us at the MFMA peak)'
                         + ('; peak = the fp32 MFMA peak the other kernel family is priced against -- this family runs on the bf16 pipe, whose '
                            'bound for fp32-equivalent work is %.0f TFLOP/s (frac_bf16_split)' % PEAK_BX3_TFLOPS if cell_bx3 else '')}
+            if clock_ghz:
+                out['roofline'].update({'clock_ghz': clock_ghz, 'spec_clock_ghz': 2.4, 'frac_at_sustained_clock': ach / (PEAK_F32_MFMA_TFLOPS * clock_ghz / 2.4),
+                                        'clock_note': 'shader clock sustained while train steps run (s_memtime against the 100 MHz s_memrealtime, one probe wave on its own stream); peak and frac are at the 2.4 GHz spec clock'})
             if cell_bx3:
                 out['roofline']['frac_bf16_split'] = ach / PEAK_BX3_TFLOPS
             try:

@@ -559,6 +559,18 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
     if (tid == 0) *loss_out = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / ((double)ce_n + 1e-12));
 }
 
+// ---------------------------------------------------------------- shader-clock probe
+// One wave that watches two counters for `ticks` of the constant 100 MHz real-time counter (s_memrealtime): out[0] = elapsed shader-clock
+// ticks (s_memtime), out[1] = elapsed real-time ticks.  Launched on a stream of its own BESIDE a few train steps it reports the clock the
+// chip sustains under the step's load -- what a fraction of the 2.4 GHz spec peak has to be read against (bench.py: roofline.clock_ghz).
+__global__ void k_clock_probe(long long ticks, unsigned long long* out) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while ((long long)(r1 - r0) < ticks) { __builtin_amdgcn_s_sleep(64); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+
 // ---------------------------------------------------------------- unigram baseline
 // Reference src/models/unigram_model.py:26-39: word_count (alpha = 1) + scatter_add of ones, prob = gather / reduce_sum,
 // loss = -mean(log prob).  Counts are integers (unsigned atomics: exact and order-independent), handed to the caller as floats.
@@ -807,6 +819,10 @@ hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, flo
     return hipGetLastError();
 }
 
+hipError_t launch_clock_probe(hipStream_t s, long long realtime_ticks, unsigned long long* out) {
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, realtime_ticks, out);
+    return hipGetLastError();
+}
 hipError_t launch_unigram_update(hipStream_t s, const int* words, long long n, unsigned* counts, int vocab, int* err_flag) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_unigram_update, dim3((int)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, s, words, n, counts, vocab, err_flag);

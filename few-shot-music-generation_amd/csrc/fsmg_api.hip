@@ -140,6 +140,8 @@ struct fsmg_model {
     float* colsum_slabs = nullptr;
     float* slabs2 = nullptr;            // ... and of the GEMMs on the auxiliary stream
     float* colsum_slabs2 = nullptr;
+    hipStream_t probe = nullptr;        // fsmg_debug_clock_begin / _end: the shader-clock probe's own stream
+    unsigned long long* d_probe = nullptr;
     hipStream_t aux = nullptr;          // low-priority stream for the projection GEMMs that overlap the recurrence
     static constexpr int NCHUNK = 16;   // max time chunks of the overlap schedule
     std::vector<int> chunk_edges;       // explicit chunk boundaries (FSMG_CHUNK_STEPS), empty = uniform
@@ -464,9 +466,9 @@ int ensure_scratch(fsmg_model* h, int B) {
     const int64_t n_inbox = want_inbox ? lstm_bwd_rs_inbox_floats(rows_rs, (int)Hp) : 0;
     const int64_t o_inbox = place(want_inbox ? 4 * n_inbox : 256);
     // XCD-local kernels: sized for the largest row count they take (not for B, same reason)
-    const int xrows = (h->persist && h->xcd && lstm_xcd_max_rows((int)Hp) > 0 && (Hp == 512 || h->pair_mode >= 1)) ? std::min(h->xcd_max_rows, lstm_xcd_max_rows((int)Hp)) : 0;
+    const int xrows = (h->persist && h->xcd && lstm_xcd_max_rows((int)Hp) > 0 && (Hp != 1024 || h->pair_mode >= 1)) ? std::min(h->xcd_max_rows, lstm_xcd_max_rows((int)Hp)) : 0;
     const int64_t n_hx = xrows ? lstm_xcd_hx_floats(xrows, (int)T, (int)Hp, h->xcd_bx3) : 0;
-    const int64_t n_inx = (xrows && (Hp == 512 || h->pair_mode >= 2)) ? lstm_xcd_inbox_floats(xrows, (int)Hp) : 0;
+    const int64_t n_inx = (xrows && (Hp != 1024 || h->pair_mode >= 2)) ? lstm_xcd_inbox_floats(xrows, (int)Hp) : 0;
     const int64_t o_hx = place(xrows ? 4 * n_hx : 256), o_inx = place(n_inx ? 4 * n_inx : 256);
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
     const int64_t o_lg = place(4 * rows * h->V1p), o_dlg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
@@ -813,10 +815,10 @@ int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g, OpBatc
 
 // the XCD-local kernels take this row count at this hidden size (and their buffers exist)
 inline bool use_xcd(const fsmg_model* h, int B, bool backward = false) {
-    if (h->Hp != 512 && h->pair_mode < (backward ? 2 : 1)) return false;
+    if (h->Hp == 1024 && h->pair_mode < (backward ? 2 : 1)) return false;
     return h->persist && h->xcd && h->khx != nullptr && h->HX != nullptr && B <= h->xcd_max_rows && lstm_xcd_supported(B, h->Hp) &&
            lstm_xcd_hx_floats(B, h->T, h->Hp, h->xcd_bx3) <= h->hx_floats &&
-           ((h->Hp != 512 && !backward) || lstm_xcd_inbox_floats(B, h->Hp) <= h->inboxx_floats);
+           ((h->Hp == 1024 && !backward) || lstm_xcd_inbox_floats(B, h->Hp) <= h->inboxx_floats);
 }
 // Two-stream (eager) or single-stream (hipGraph replay) order for a pass over B sequences.  The XCD-local recurrent kernels
 // put a high-priority wave on every SIMD of the chip and spend half of their time in hand-offs; GEMM waves beside them
@@ -1334,7 +1336,7 @@ int backward(fsmg_model* h, int B, int part = 0) {
 // the launch also closes the train step (k_step_increment's work on one thread of it); *inc_done says whether it did.
 int repack_recurrent_weights(fsmg_model* h, hipStream_t s, const StepIncArgs* inc, bool* inc_done) {
     if (inc_done) *inc_done = false;
-    const bool x_ok = h->khx == nullptr || h->Hp == 512 || h->Hp == 1024;
+    const bool x_ok = h->khx == nullptr || h->Hp == 512 || h->Hp == 1024 || h->Hp == 256;
     if (h->L <= REPACK_MAX_LAYERS && x_ok) {
         RepackAllArgs a{};
         a.n = h->L; a.Hp = h->Hp; a.bx3 = h->xcd_bx3 ? 1 : 0;
@@ -1894,6 +1896,8 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->comm && h->own_comm && rccl().ok) rccl().CommDestroy(h->comm);
     if (h->ev_comm) hipEventDestroy(h->ev_comm);
     if (h->comm_stream) hipStreamDestroy(h->comm_stream);
+    if (h->probe) { hipStreamSynchronize(h->probe); hipStreamDestroy(h->probe); }
+    if (h->d_probe) hipFree(h->d_probe);
     if (h->aux) hipStreamDestroy(h->aux);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -2508,6 +2512,26 @@ int fsmg_unigram_argmax(fsmg_unigram_handle u, int32_t* word) {
     UCK(u, hipMemcpyAsync(&w, u->out + 2, sizeof(int), hipMemcpyDeviceToHost, u->stream));
     UCK(u, hipStreamSynchronize(u->stream));
     *word = w;
+    return FSMG_OK;
+}
+
+int fsmg_debug_clock_begin(fsmg_handle h, int32_t microseconds) {
+    if (!h || microseconds <= 0 || microseconds > 1000000) return FSMG_ERR_INVALID;
+    hipSetDevice(h->device);
+    if (!h->probe) HIPCK(h, hipStreamCreateWithFlags(&h->probe, hipStreamNonBlocking));
+    if (!h->d_probe) HIPCK(h, hipMalloc((void**)&h->d_probe, 64));
+    HIPCK(h, hipMemsetAsync(h->d_probe, 0, 64, h->probe));
+    HIPCK(h, launch_clock_probe(h->probe, (long long)microseconds * 100, h->d_probe));
+    return FSMG_OK;
+}
+int fsmg_debug_clock_end(fsmg_handle h, float* ghz) {
+    if (!h || !ghz) return FSMG_ERR_INVALID;
+    if (!h->probe || !h->d_probe) return fail(h, FSMG_ERR_STATE, "fsmg_debug_clock_end without fsmg_debug_clock_begin");
+    hipSetDevice(h->device);
+    unsigned long long v[2] = {0, 0};
+    HIPCK(h, hipStreamSynchronize(h->probe));
+    HIPCK(h, hipMemcpy(v, h->d_probe, sizeof(v), hipMemcpyDeviceToHost));
+    *ghz = v[1] ? (float)((double)v[0] / (double)v[1] * 0.1) : 0.0f;
     return FSMG_OK;
 }
 

@@ -313,6 +313,8 @@ hipError_t launch_step_increment(hipStream_t s, const StepIncArgs& a);
 // ce != nullptr: also *loss_out = sum(ce[0 .. ce_n)) / (ce_n + 1e-12) -- launch_loss_reduce with one group, same bits
 hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst, const int* flag_src = nullptr,
                                const float* ce = nullptr, int ce_n = 0, float* loss_out = nullptr);
+// one wave for `realtime_ticks` of the 100 MHz counter: out[0] = shader-clock ticks elapsed, out[1] = real-time ticks elapsed
+hipError_t launch_clock_probe(hipStream_t s, long long realtime_ticks, unsigned long long* out);
 // unigram baseline (reference src/models/unigram_model.py:26-39): counts[w] += 1 per word; out[0] = -mean(log(count[w] / sum(counts))),
 // out[1] = sum(counts); *out = argmax (lowest index on ties).  *err_flag |= 1 for a word outside [0, vocab)
 hipError_t launch_unigram_update(hipStream_t s, const int* words, long long n, unsigned* counts, int vocab, int* err_flag);

@@ -486,6 +486,298 @@ __global__ void k_repack_kh_xcd(const float* __restrict__ Kh, float* __restrict_
     repack_kh_xcd_body(Kh, fwd, bwd, blockIdx.x, gridDim.x);
 }
 
+// ================================================================ hidden size 256: two row slices per XCD (round 4)
+// The reference's own default is hidden_size 200 (src/config/lstm_baseline.yaml:17), which pads to 256 here.  K_h of 256 units is
+// 1 MiB: a copy fits the registers of 16 CUs (64 KiB each), so every XCD holds TWO copies and the batch is split SIXTEEN ways --
+// 3 rows per slice at B = 45, one row group.  The kernels are the hidden-512 ones (k_lstm_fwd_xcd / k_lstm_bwd_xcd) with a 64-wide
+// K range per wave (16 weight words instead of 32, one hand-off fragment per row group instead of two) and a hand-off that stays
+// inside 16 CUs of one XCD's L2:
+//   role      (xcd, ticket) -> slice 2 xcd + ticket / 16, CU ticket % 16 of the slice (hidden units 16 cu ..., 64 packed gate columns)
+//   HX        [T+1][16 slices][4 w][RG][64 lanes][4]: lane 4b+i, component e of (w, rg) = h[row 4rg+i][unit 64w + 16(b/4) + 4(b%4) + e];
+//             CU c writes lanes 16(c%4) .. +15 of w = c / 4
+//   KhS       [16 cu][4 w][16 words][64 lanes][4] per direction (k_repack_kh_slice)
+//   inbox     [2 slots][16 slices][16 dest][16 producers][RG][16 units][4 rows]
+constexpr int SH = 256, SG4 = 4 * SH, SCU = 16, NSL = 2 * NXCD;
+
+template <int RG>
+__global__ __launch_bounds__(256, 1) void k_lstm_fwd_slice(const LstmFwdXcdArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[2][RG][4][64 * 4];   // [step parity][row group][wave][cell lane][gate]
+    __shared__ int s_role[2];
+    __shared__ int s_fail;
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_fail = 0;
+    Role role;
+    if (!take_role(a.tickets, a.err_flag, s_role, role)) return;
+    const int slice = 2 * role.xcd + (role.cu >> 4), cu = role.cu & 15;
+    const int B = a.B;
+    const int rps = (B + NSL - 1) / NSL, row0 = slice * rps;
+    if (row0 >= B) return;
+
+    f32x4 W[16];
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.KhX) + ((size_t)(cu * 4 + wave) * 16) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) W[i] = wp[i * 64];
+    }
+    const int ci = lane >> 4, cbb = (lane >> 2) & 3, ce = lane & 3;
+    const int lrow = 4 * wave + ci, row = row0 + lrow, unit = 16 * cu + 4 * cbb + ce;
+    const bool cellw = wave < RG;
+    const bool act = cellw && lrow < rps && row < B;
+    float cp = act ? a.Cs[((size_t)a.t0 * B + row) * SH + unit] : 0.0f;
+    const size_t hx_step = (size_t)NSL * 4 * RG * 64;                       // f32x4 words per time index
+    const f32x4* hx_in = reinterpret_cast<const f32x4*>(a.HX) + (((size_t)slice * 4 + wave) * RG) * 64 + lane;
+    f32x4* hx_out = reinterpret_cast<f32x4*>(a.HX) + (((size_t)slice * 4 + (cu >> 2)) * RG + wave) * 64 + 16 * (cu & 3) + 4 * cbb + ci;
+    const int wofs = ((lane >> 4) * 4 + (lane & 3)) * 4 + ((lane >> 2) & 3);
+    float zq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float o_c = 0.f, o_hh = 0.f, o_g[4] = {0.f, 0.f, 0.f, 0.f};
+    bool o_have = false;
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (a.t0 + k < a.t1) {
+                const float* zn = a.Z + ((size_t)(a.t0 + k) * B + row) * SG4 + 64 * cu + 16 * cbb + ce;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) zq[k][g] = zn[4 * g];
+            }
+    }
+
+    for (int t = a.t0; t < a.t1; ++t) {
+        f32x4 av[RG];
+        {
+            const bool fail = !wait_all_fragments<RG>(hx_in + (size_t)t * hx_step, av, a.spin_limit, a.err_flag, (a.variant & XCD_NO_POLL_SLEEP) != 0);
+            if (fail && lane == 0) {
+                __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_fail = 1;
+            }
+        }
+        if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {              // outputs of the step before: behind a successful poll, under the MFMAs
+            a.Cs[((size_t)t * B + row) * SH + unit] = o_c;
+            a.Hs[((size_t)t * B + row) * SH + unit] = o_hh;
+            float* zo = a.Z + ((size_t)(t - 1) * B + row) * SG4 + 64 * cu + 16 * cbb + ce;
+            zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+        }
+        float zin[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { zin[g] = zq[0][g]; zq[0][g] = zq[1][g]; zq[1][g] = 0.0f; }
+        float* zp = a.Z + ((size_t)t * B + row) * SG4 + 64 * cu + 16 * cbb + ce;
+        if (act && t + 2 < a.t1) {           // (behind the poll, two steps ahead: the rules of k_lstm_fwd_xcd)
+            const float* zn = zp + 2 * (size_t)B * SG4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) zq[1][g] = zn[4 * g];
+        }
+        f32x4 acc[RG];
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define SLICE_FWD_B(B_)                                                                 \
+        _Pragma("unroll") for (int rg = 0; rg < RG; ++rg) { XCD_MFMA_B(B_, av[rg], W[B_], acc[rg]) }
+        SLICE_FWD_B(0) SLICE_FWD_B(1) SLICE_FWD_B(2) SLICE_FWD_B(3) SLICE_FWD_B(4) SLICE_FWD_B(5) SLICE_FWD_B(6) SLICE_FWD_B(7)
+        SLICE_FWD_B(8) SLICE_FWD_B(9) SLICE_FWD_B(10) SLICE_FWD_B(11) SLICE_FWD_B(12) SLICE_FWD_B(13) SLICE_FWD_B(14) SLICE_FWD_B(15)
+#undef SLICE_FWD_B
+        {
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) {
+                float* rp = &red[t & 1][rg][wave][0] + wofs;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rp[64 * i] = acc[rg][i];
+            }
+        }
+        __syncthreads();
+        if (s_fail) return;
+
+        if (cellw) {
+            float hn = 0.0f, g_si = 0.f, g_tj = 0.f, g_sf = 0.f, g_so = 0.f;
+            if (act) {
+                const f32x4* rsrc = reinterpret_cast<const f32x4*>(&red[t & 1][wave][0][0]) + lane;
+                const f32x4 r0 = rsrc[0], r1 = rsrc[64], r2 = rsrc[128], r3 = rsrc[192];
+                float zg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float zs = 0.0f;
+                    zs += r0[g]; zs += r1[g]; zs += r2[g]; zs += r3[g];
+                    zg[g] = zin[g] + zs;
+                }
+                const CellOut co = cell_forward(zg, cp);
+                hn = co.h; cp = co.c;
+                g_si = co.si; g_tj = co.tj; g_sf = co.sf; g_so = co.so;
+            }
+            f32x4 hv;
+            hv[0] = quad_bcast<0>(hn); hv[1] = quad_bcast<1>(hn); hv[2] = quad_bcast<2>(hn); hv[3] = quad_bcast<3>(hn);
+            if (ce == 0) store_l2(hx_out + (size_t)(t + 1) * hx_step, hv);
+            if (a.variant & XCD_DEFER_OUTPUTS) {
+                o_c = cp; o_hh = hn; o_g[0] = g_si; o_g[1] = g_tj; o_g[2] = g_sf; o_g[3] = g_so; o_have = true;
+            } else if (act) {
+                a.Cs[((size_t)(t + 1) * B + row) * SH + unit] = cp;
+                a.Hs[((size_t)(t + 1) * B + row) * SH + unit] = hn;
+                zp[0] = g_si; zp[4] = g_tj; zp[8] = g_sf; zp[12] = g_so;
+            }
+        }
+    }
+    if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {
+        a.Cs[((size_t)a.t1 * B + row) * SH + unit] = o_c;
+        a.Hs[((size_t)a.t1 * B + row) * SH + unit] = o_hh;
+        float* zo = a.Z + ((size_t)(a.t1 - 1) * B + row) * SG4 + 64 * cu + 16 * cbb + ce;
+        zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+    }
+}
+
+template <int RG>
+__global__ __launch_bounds__(256, 1) void k_lstm_bwd_slice(const LstmBwdXcdArgs a) {
+    constexpr int NG = 4 / RG;                    // lane groups of a wave that read different producers of one row group
+    constexpr int LPW = RG;                       // inbox words per lane: 4 producers x RG x 16 units / 64 lanes
+    __shared__ __attribute__((aligned(16))) float psum[4 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float dzA[RG][64][4];
+    __shared__ int s_role[2];
+    __shared__ int s_fail;
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_fail = 0;
+    Role role;
+    if (!take_role(a.tickets, a.err_flag, s_role, role)) return;
+    const int slice = 2 * role.xcd + (role.cu >> 4), cu = role.cu & 15;
+    const int B = a.B;
+    const int rps = (B + NSL - 1) / NSL, row0 = slice * rps;
+    if (row0 >= B) return;
+
+    f32x4 W[16];          // component e' of word i = weight register k = 4i + e': Kh[64w + lane][64cu + k]
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.KhXb) + ((size_t)(cu * 4 + wave) * 16) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) W[i] = wp[i * 64];
+    }
+    const int ci = lane >> 4, cbb = (lane >> 2) & 3, ce = lane & 3;
+    const int lrow = 4 * wave + ci, row = row0 + lrow, unit = 16 * cu + 4 * cbb + ce;
+    const bool cellw = wave < RG;
+    const bool act = cellw && lrow < rps && row < B;
+    const size_t hi = (size_t)row * SH + unit;
+    float dcv = act ? a.dc[hi] : 0.0f;
+    const size_t slot_w = (size_t)NSL * SCU * SCU * RG * 16;                // f32x4 words per slot
+    f32x4* const inbox = reinterpret_cast<f32x4*>(a.inbox);
+    // consumer side: this block's 16 x RG x 16 words; wave w takes producers 4w .. 4w+3, LPW words per lane
+    const size_t in_base = (((size_t)slice * SCU + cu) * SCU + 4 * wave) * RG * 16 + lane;
+    // producer side: lane l -> destination CU 4w + l/16, word (dest, producer = cu, rg, l%16)
+    const size_t out_ofs = ((((size_t)slice * SCU + 4 * wave + (lane >> 4)) * SCU + cu) * RG) * 16 + (lane & 15);
+    const f32x4 fill = f32x4{__uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu)};
+
+    float n_si = 0.f, n_tj = 0.f, n_sf = 0.f, n_so = 0.f, n_ct = 0.f, n_cp = 0.f, n_dh = 0.f;
+    if (act && a.t1 > a.t0) {
+        const int t = a.t1 - 1;
+        const float* gp = a.Z + ((size_t)t * B + row) * SG4 + 64 * cu + 16 * cbb + ce;
+        n_si = gp[0]; n_tj = gp[4]; n_sf = gp[8]; n_so = gp[12];
+        n_ct = a.Cs[(size_t)(t + 1) * B * SH + hi]; n_cp = a.Cs[(size_t)t * B * SH + hi];
+        n_dh = a.dH[(size_t)t * B * SH + hi];
+    }
+
+    for (int t = a.t1 - 1; t >= a.t0; --t) {
+        const float si = n_si, tj = n_tj, sf = n_sf, so = n_so, ct = n_ct, cpv = n_cp, dht = n_dh;
+        float* gp = a.Z + ((size_t)t * B + row) * SG4 + 64 * cu + 16 * cbb + ce;
+        // ---- A: consume
+        f32x4 wsum = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < a.T) {
+            f32x4* in = inbox + (size_t)((t + 1) & 1) * slot_w + in_base;
+            f32x4 v[LPW];
+            bool fail = false;
+            for (int spins = 0;; ++spins) {
+#pragma unroll
+                for (int k = 0; k < LPW; ++k) v[k] = load_sc1(in + k * 64);
+                drain_vmem();
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < LPW; ++k) { asm volatile("" : "+v"(v[k])); ok &= frag_ready(v[k]); }
+                if (__all(ok)) break;
+                if (!(a.variant & XCD_NO_POLL_SLEEP)) __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
+                if (spins >= a.spin_limit || ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) { fail = true; break; }
+            }
+            if (fail && lane == 0) {
+                __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_fail = 1;
+            }
+#pragma unroll
+            for (int k = 0; k < LPW; ++k) {
+                store_l2(in + k * 64, fill);
+                wsum = (k == 0) ? v[0] : wsum + v[k];
+            }
+        }
+        *reinterpret_cast<f32x4*>(&psum[(wave * 64 + lane) * 4]) = wsum;
+        __syncthreads();
+        if (s_fail) return;
+
+        // ---- B: gate gradients (wave rg < RG: lane = 16 i + 4 bb + e)
+        float di = 0.f, dj = 0.f, df = 0.f, dg = 0.f;
+        if (cellw) {
+            if (act) {
+                float dh_rec = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int grp = 0; grp < NG; ++grp)
+                        dh_rec += psum[(w * 64 + (grp * RG + wave) * 16 + 4 * cbb + ce) * 4 + ci];
+                const CellGrad cg = cell_backward(si, tj, sf, so, ct, cpv, dcv, dht + dh_rec);
+                di = cg.di; dj = cg.dj; df = cg.df; dg = cg.dg;
+                gp[0] = di; gp[4] = dj; gp[8] = df; gp[12] = dg;          // row-major dz for the weight-gradient GEMMs
+                dcv = cg.dc_out;
+            }
+            float* f = &dzA[wave][4 * ce + ci][cbb];
+            f[0] = di; f[16 * 4] = dj; f[32 * 4] = df; f[48 * 4] = dg;
+        }
+        __syncthreads();
+        drain_vmem();                      // the resets of phase A and the dz stores: landed before this block publishes anything
+        if (act && t > a.t0) {             // prefetch for iteration t-1 (hidden by the MFMAs below)
+            const float* gn = a.Z + ((size_t)(t - 1) * B + row) * SG4 + 64 * cu + 16 * cbb + ce;
+            n_si = gn[0]; n_tj = gn[4]; n_sf = gn[8]; n_so = gn[12];
+            n_ct = cpv; n_cp = a.Cs[(size_t)(t - 1) * B * SH + hi];
+            n_dh = a.dH[(size_t)(t - 1) * B * SH + hi];
+        }
+
+        // ---- C: produce the partials of dh_{t-1}
+        if (t > 0) {
+            f32x4 av[RG];
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) av[rg] = *reinterpret_cast<const f32x4*>(&dzA[rg][lane][0]);
+            f32x4 acc[RG];
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // k = 16 v + b: A register av[rg][v], broadcast block b; weight register k = word 4v + b/4, component b%4
+#define SLICE_BWD_B(B_)                                                                                 \
+            _Pragma("unroll") for (int rg = 0; rg < RG; ++rg)                                           \
+                acc[rg] = mfma44<B_>(av[rg][v], W[4 * v + (B_ >> 2)][B_ & 3], acc[rg]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                SLICE_BWD_B(0) SLICE_BWD_B(1) SLICE_BWD_B(2) SLICE_BWD_B(3) SLICE_BWD_B(4) SLICE_BWD_B(5) SLICE_BWD_B(6) SLICE_BWD_B(7)
+                SLICE_BWD_B(8) SLICE_BWD_B(9) SLICE_BWD_B(10) SLICE_BWD_B(11) SLICE_BWD_B(12) SLICE_BWD_B(13) SLICE_BWD_B(14) SLICE_BWD_B(15)
+            }
+#undef SLICE_BWD_B
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // MFMA result -> VMEM store data: wait states by hand (inline-asm stores)
+            f32x4* out = inbox + (size_t)(t & 1) * slot_w;
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) store_l2(out + out_ofs + rg * 16, acc[rg]);
+        }
+    }
+    if (act) a.dc[hi] = dcv;
+}
+
+// Kh [256][1024] (packed gate columns) -> the register images of the slice kernels:
+//   fwd word b (< 16), component e of (cu, w), lane l:  Kh[64w + 16(b/4) + 4(b%4) + e][64cu + l]
+//   bwd word i, component e' of (cu, w), lane l, k = 4i + e':  Kh[64w + l][64cu + k]
+__device__ __forceinline__ void repack_kh_slice_body(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd, int b, int nb) {
+    const int total = SCU * 4 * 16 * 64;            // f32x4 words per copy
+    for (int idx = b * blockDim.x + threadIdx.x; idx < total; idx += nb * blockDim.x) {
+        const int l = idx & 63, i = (idx >> 6) & 15, w = (idx >> 10) & 3, cu = idx >> 12;
+        {
+            const int k0 = 64 * w + 16 * (i >> 2) + 4 * (i & 3);
+            const float* src = Kh + (size_t)k0 * SG4 + 64 * cu + l;
+            float4 v;
+            v.x = src[0]; v.y = src[SG4]; v.z = src[2 * (size_t)SG4]; v.w = src[3 * (size_t)SG4];
+            reinterpret_cast<float4*>(fwd)[idx] = v;
+        }
+        reinterpret_cast<float4*>(bwd)[idx] = *reinterpret_cast<const float4*>(Kh + (size_t)(64 * w + l) * SG4 + 64 * cu + 4 * i);
+    }
+}
+__global__ void k_repack_kh_slice(const float* __restrict__ Kh, float* __restrict__ fwd, float* __restrict__ bwd) {
+    repack_kh_slice_body(Kh, fwd, bwd, blockIdx.x, gridDim.x);
+}
+
 // ================================================================ hidden size 512 on the bf16 matrix pipe (round 3)
 // The recurrent product of the kernels above runs at the fp32 MFMA rate and pays for 4-row groups: a 6-row slice (B = 45) costs
 // 2 x 128 `4x4x1` MFMAs = 2048 cycles per step and wave, 13 rows (B = 100) cost 4096.  The dense GEMMs of the step already
@@ -1744,7 +2036,8 @@ __global__ void k_repack_kh_all(const RepackAllArgs a, const StepIncArgs inc) {
     const int l = blockIdx.y >> 1, kind = blockIdx.y & 1;
     if (kind == 0) { repack_kh_chunked(a.Kh[l], a.cf[l], a.cb[l], a.Hp, blockIdx.x, gridDim.x); return; }
     if (a.xf[l] == nullptr) return;
-    if (a.Hp == PH) repack_kh_pair_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
+    if (a.Hp == SH) repack_kh_slice_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
+    else if (a.Hp == PH) repack_kh_pair_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
     else if (a.bx3) repack_kh_xcd16_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
     else repack_kh_xcd_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
 }
@@ -1754,7 +2047,7 @@ __global__ void k_repack_kh_all(const RepackAllArgs a, const StepIncArgs inc) {
 hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a, const StepIncArgs* inc) {
     if (a.n <= 0) return hipSuccess;
     if (a.n > REPACK_MAX_LAYERS) return hipErrorInvalidValue;
-    for (int l = 0; l < a.n; ++l) if (a.xf[l] != nullptr && !(a.Hp == XH || a.Hp == PH)) return hipErrorInvalidValue;
+    for (int l = 0; l < a.n; ++l) if (a.xf[l] != nullptr && !(a.Hp == XH || a.Hp == PH || a.Hp == SH)) return hipErrorInvalidValue;
     const long long total = (long long)a.Hp * 4 * a.Hp / 4;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
     if (a.bx3 && a.Hp != XH) return hipErrorInvalidValue;
@@ -1776,21 +2069,27 @@ static int xcd_row_groups_packed(int B, int rpx) {
 }
 static int xcd_row_groups(int B, int Hp) {
     if (Hp == PH) return ((B + PGRP - 1) / PGRP + 3) / 4;
+    if (Hp == SH) return ((B + NSL - 1) / NSL + 3) / 4;         // sixteen slices; 1 or 2 row groups up to 128 rows
     const int rpx = (B + NXCD - 1) / NXCD;
     const int rg = (rpx + 3) / 4;
     return rg == 3 ? 4 : rg;
 }
 
-bool lstm_xcd_supported(int B, int Hp) { return (Hp == XH || Hp == PH) && B >= 1 && xcd_row_groups(B, Hp) <= 4; }
-int lstm_xcd_max_rows(int Hp) { return Hp == PH ? 16 * PGRP : (Hp == XH ? 16 * NXCD : 0); }
+bool lstm_xcd_supported(int B, int Hp) {
+    if (Hp == SH) return B >= 1 && xcd_row_groups(B, Hp) <= 2;
+    return (Hp == XH || Hp == PH) && B >= 1 && xcd_row_groups(B, Hp) <= 4;
+}
+int lstm_xcd_max_rows(int Hp) { return Hp == PH ? 16 * PGRP : (Hp == XH ? 16 * NXCD : (Hp == SH ? 8 * NSL : 0)); }
 
 long long lstm_xcd_hx_floats(int B, int T, int Hp, bool bx3, int rpx) {
     if (Hp == PH) return (long long)(T + 1) * PGRP * 4 * xcd_row_groups(B, Hp) * PNQ * 64 * 4;
+    if (Hp == SH) return (long long)(T + 1) * NSL * 4 * xcd_row_groups(B, Hp) * 64 * 4;
     if (bx3) return (long long)(T + 1) * (4 * xcd_row_groups_packed(B, rpx)) * NXCD * HXW16 * 4;      // rows x XCDs x 3 KiB, see k_lstm_fwd_xcd16
     return (long long)(T + 1) * NXCD * 4 * xcd_row_groups_packed(B, rpx) * 2 * 64 * 4;
 }
 long long lstm_xcd_inbox_floats(int B, int Hp, int rpx) {
     if (Hp == PH) return 2LL * PGRP * PCU * xcd_row_groups(B, Hp) * PCU * 16 * 4;
+    if (Hp == SH) return 2LL * NSL * SCU * SCU * xcd_row_groups(B, Hp) * 16 * 4;
     return 2LL * NXCD * NCU * NCU * xcd_row_groups_packed(B, rpx) * 16 * 4;
 }
 // the bf16-split kernels take up to 16 rows per XCD at the same MFMA cost: the fewest XCDs that hold B rows, rows spread evenly
@@ -1804,7 +2103,8 @@ bool lstm_xcd_bx3_pays(int B, int Hp) { return Hp == XH && xcd_row_groups(B) >= 
 // ceil(B / rows) XCDs and the others are free for another stream's GEMMs (B = 45: 8 rows on 6 XCDs instead of 6 on 8).
 int lstm_xcd_packed_rows(int B) { return 4 * xcd_row_groups(B); }
 hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp, bool bx3) {
-    if (Hp == PH) hipLaunchKernelGGL(k_repack_kh_pair, dim3(2048), dim3(256), 0, s, Kh, fwd, bwd);
+    if (Hp == SH) hipLaunchKernelGGL(k_repack_kh_slice, dim3(256), dim3(256), 0, s, Kh, fwd, bwd);
+    else if (Hp == PH) hipLaunchKernelGGL(k_repack_kh_pair, dim3(2048), dim3(256), 0, s, Kh, fwd, bwd);
     else if (bx3) hipLaunchKernelGGL(k_repack_kh_xcd16, dim3(512), dim3(256), 0, s, Kh, fwd, bwd);
     else hipLaunchKernelGGL(k_repack_kh_xcd, dim3(1024), dim3(256), 0, s, Kh, fwd, bwd);
     return hipGetLastError();
@@ -1824,12 +2124,22 @@ int lstm_xcd_default_variant(int B, bool forward, int Hp, int rpx) {
         return XCD_NO_POLL_SLEEP;
     }
     if (!forward) return XCD_NO_POLL_SLEEP;
+    if (Hp == SH) return XCD_DEFER_OUTPUTS | XCD_NO_POLL_SLEEP;
     return xcd_row_groups_packed(B, rpx) <= 2 ? (XCD_DEFER_OUTPUTS | XCD_NO_POLL_SLEEP) : XCD_NO_POLL_SLEEP;
 }
 
 hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {
     if (a.t1 <= a.t0) return hipSuccess;
     const dim3 grid(NXCD * NCU), block(256);
+    if (a.Hp == SH) {
+        if (a.prof || a.bx3 || a.rpx || a.progress) return hipErrorInvalidValue;
+        switch (xcd_row_groups(a.B, SH)) {
+            case 1: hipLaunchKernelGGL((k_lstm_fwd_slice<1>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((k_lstm_fwd_slice<2>), grid, block, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (a.Hp == PH) {
         const int rg = xcd_row_groups(a.B, PH);
         if (a.prof && !((a.variant & XCD_CHAINS) && rg >= 2)) return hipErrorInvalidValue;
@@ -1881,6 +2191,15 @@ hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {
 hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a) {
     if (a.t1 <= a.t0) return hipSuccess;
     const dim3 grid(NXCD * NCU), block(256);
+    if (a.Hp == SH) {
+        if (a.prof || a.bx3 || a.rpx) return hipErrorInvalidValue;
+        switch (xcd_row_groups(a.B, SH)) {
+            case 1: hipLaunchKernelGGL((k_lstm_bwd_slice<1>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((k_lstm_bwd_slice<2>), grid, block, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (a.Hp == PH) {
         const int rg = xcd_row_groups(a.B, PH);
         if (a.prof && !((a.variant & XCD_CHAINS) && rg >= 2)) return hipErrorInvalidValue;

@@ -91,6 +91,8 @@ SIGNATURES = {
     'fsmg_debug_read': (C.c_int, [_P, C.c_char_p, _F32P, C.c_int64]),
     'fsmg_debug_dims': (C.c_int, [_P, _I32P]),
     'fsmg_debug_set': (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    'fsmg_debug_clock_begin': (C.c_int, [_P, C.c_int32]),
+    'fsmg_debug_clock_end': (C.c_int, [_P, _F32P]),
     'fsmg_unigram_create': (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_P)]),
     'fsmg_unigram_destroy': (C.c_int, [_P]),
     'fsmg_unigram_last_error': (C.c_char_p, [_P]),
@@ -440,6 +442,15 @@ class FsmgModel(object):
     def debug_set(self, what, value):
         """run-time knob of the handle (include/fsmg.h: chain_spin_limit, fallback_steps, eager)"""
         self._ck(self._lib.fsmg_debug_set(self._h, what.encode(), int(value)))
+
+    def clock_begin(self, microseconds):
+        """start the shader-clock probe (its own stream); issue the work to be measured next, then clock_end()"""
+        self._ck(self._lib.fsmg_debug_clock_begin(self._h, int(microseconds)))
+
+    def clock_end(self):
+        ghz = C.c_float()
+        self._ck(self._lib.fsmg_debug_clock_end(self._h, C.byref(ghz)))
+        return float(ghz.value)
 
     def debug_read(self, what, count):
         out = np.empty(int(count), np.float32)

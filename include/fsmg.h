@@ -287,6 +287,11 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
  *                       recurrent kernels are issued eagerly (default)
  * Synchronises the stream and drops the captured graphs. */
 int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value);
+/* shader clock the chip sustains while the handle works: _begin starts a one-wave probe on a stream of its own that compares the
+ * shader-clock counter with the constant 100 MHz real-time counter for `microseconds`; issue the work to be measured behind it;
+ * _end waits for the probe and returns GHz (bench.py: roofline.clock_ghz -- peaks are quoted at the 2.4 GHz spec clock) */
+int fsmg_debug_clock_begin(fsmg_handle h, int32_t microseconds);
+int fsmg_debug_clock_end(fsmg_handle h, float* ghz);
 /* padded sizes: writes Ep, Hp, V1p, last B, T */
 int fsmg_debug_dims(fsmg_handle h, int32_t dims[5]);
 /* diagnostics: run ONE instrumented recurrent step kernel (which = 0 forward, 1 backward) at t = T/2 on the

@@ -34,6 +34,10 @@ SHAPES = [
     (dict(hidden_size=1024, embedding_size=16, input_size=60, max_len=4, n_layers=2), 2, 1, 1),   # Hp = 1024 (cfg-C's): 8 per wave, forward per step
     (dict(hidden_size=16, embedding_size=8, input_size=12500, max_len=4), 2, 1, 1),   # vocab rows > 12288 floats: 3-pass CE kernel
     (dict(hidden_size=16, embedding_size=8, input_size=7000, max_len=4), 2, 1, 1),    # 6144 < row <= 12288: 12-register CE kernel
+    (dict(hidden_size=256, embedding_size=16, input_size=70, max_len=6), 5, 5, 4),    # Hp = 256: two row slices per XCD (k_lstm_*_slice), 45 rows = 3 per slice, 1 row group
+    (dict(hidden_size=256, embedding_size=16, input_size=70, max_len=5), 20, 1, 4),   # ... 100 rows = 7 per slice: 2 row groups
+    (dict(hidden_size=200, embedding_size=24, input_size=90, max_len=7), 5, 5, 4),    # the reference's default hidden size: padded to 256 inside, same kernels
+    (dict(hidden_size=256, embedding_size=16, input_size=70, max_len=5, n_layers=2), 2, 2, 1),   # ... stacked, 6 rows on 6 slices
 ]
 
 
@@ -942,7 +946,8 @@ def test_ten_consecutive_train_losses_on_the_bf16_split_chain_at_cfg_d_rows():
 
 
 FORCED = [(env, i) for env in ({'FSMG_XCD_BX3': '1'}, {'FSMG_GEMM_H': '2'}, {'FSMG_XCD_OVERLAP': '0'}) for i in (2, 4, 9, 10, 11, 12)] + \
-         [({'FSMG_XCD_OVERLAP': '1'}, i) for i in (9, 10)]      # ... and the XCD-partitioned order at shapes AUTO finds too small for it
+         [({'FSMG_XCD_OVERLAP': '1'}, i) for i in (9, 10)] + \
+         [({'FSMG_XCD': '0'}, i) for i in (8, 16)]              # ... the XCD-partitioned order at shapes AUTO finds too small for it; the column-split persistent kernels at hidden 256 / 512
 
 
 @pytest.mark.parametrize('env,idx', FORCED, ids=['%s-%d' % (next(iter(e)) + '=' + next(iter(e.values())), i) for e, i in FORCED])
