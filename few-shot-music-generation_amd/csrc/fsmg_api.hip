@@ -861,9 +861,10 @@ inline bool xov_fits(const GemmArgs& g) { return 4 + gemm_items(g) <= fsmg_model
 inline void xov_gate(fsmg_model* h, GemmArgs& g, int B) {     // the projection's A rows arrive time step by time step
     const int rpx = lstm_xcd16_packed_rows(B);
     g.gate = h->xov_prog; g.gate_expect = lstm_xcd_active_blocks(B, rpx); g.gate_rows = B; g.gate_last = h->T - 1;       // (blocks below xcd_first join when the CHAIN is over)
-    // a tile waits for its rows for a fraction of the chain's 0.4 ms; 20 ms of ~1 us polls without them means the two launches are
-    // not running side by side (a profiler or debugger that serialises dispatches): give up like any timed-out hand-off
-    g.gate_err = h->d_err; g.gate_spin = h->chain_spin_limit > 0 ? 20000 : 0; g.gate_every = h->xov_pub;
+    // a tile waits for its rows for a fraction of the chain's 0.4 ms; 0.2 s of ~1 us polls without them (a host that was descheduled
+    // between the two launches is back long before that) means the launches are not running side by side -- a profiler or debugger
+    // that serialises dispatches: give up like any timed-out hand-off
+    g.gate_err = h->d_err; g.gate_spin = h->chain_spin_limit > 0 ? 200000 : 0; g.gate_every = h->xov_pub;
 }
 int gemm_restricted(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int first, int* ctl) {
     g.bx3 = 3; g.xcd_first = first; g.work = ctl; g.stop = ctl + 2; g.claim = ctl + 4; g.work_limit = gemm_items(g);
