@@ -1757,28 +1757,27 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (env) { h->overlap = env[0] != '0'; h->overlap_forced = true; }
         if (const char* e = std::getenv("FSMG_GEMM")) h->bx3 = std::strcmp(e, "f32") != 0;
         if (const char* e = std::getenv("FSMG_XCD_OVERLAP")) h->xov = std::atoi(e) != 0;
-        if (const char* e = std::getenv("FSMG_XOV_DW_SPLIT")) h->xov_dw_split = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("FSMG_XOV_PARTS")) h->xov_parts = std::max(1, std::min(3, std::atoi(e)));
-        if (const char* e = std::getenv("FSMG_XOV_PUB")) h->xov_pub = std::max(1, std::min(64, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_EAGER")) h->eager = (e[0] != '0');
-#ifdef FSMG_EXPERIMENTS         // settled A/Bs: experiment builds only
-        if (const char* e = std::getenv("FSMG_FILL_EARLY")) h->fill_early = (e[0] != '0');
-        if (const char* e = std::getenv("FSMG_FILLS_LATE")) h->fills_late = (e[0] != '0');
-        if (const char* e = std::getenv("FSMG_XOV_TAIL")) h->xov_tail = std::max(0, std::min(64, std::atoi(e)));
-#endif
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
         h->persist_cfg = h->persist;
         if (const char* e = std::getenv("FSMG_FALLBACK_STEPS")) h->fallback_steps = std::max(1, std::atoi(e));
-        if (const char* e = std::getenv("FSMG_BWD_RS")) h->bwd_rs = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XCD")) h->xcd = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_XCD_PAIR")) h->pair_mode = std::max(0, std::min(2, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_FWD_RT")) h->force_fwd_rt = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_CHAIN_SPIN_LIMIT")) h->chain_spin_limit = std::max(0, std::atoi(e));
+#ifdef FSMG_EXPERIMENTS         // settled A/Bs: tuning values and rejected alternatives, experiment builds only
+        if (const char* e = std::getenv("FSMG_XOV_DW_SPLIT")) h->xov_dw_split = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("FSMG_XOV_PUB")) h->xov_pub = std::max(1, std::min(64, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_FILL_EARLY")) h->fill_early = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_FILLS_LATE")) h->fills_late = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_XOV_TAIL")) h->xov_tail = std::max(0, std::min(64, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_BWD_RS")) h->bwd_rs = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_DP_SPLIT")) h->dp_split = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_XCD_VARIANT")) h->xcd_variant = std::atoi(e);
-        if (const char* e = std::getenv("FSMG_XCD_PAIR")) h->pair_mode = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_XCD_MAX_ROWS")) h->xcd_max_rows = std::max(1, std::min(128, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_PERSIST_FWD")) h->persist_fwd = (e[0] != '0');
-        if (const char* e = std::getenv("FSMG_FWD_RT")) h->force_fwd_rt = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_PERSIST_BWD")) h->persist_bwd = (e[0] != '0');
-        if (const char* e = std::getenv("FSMG_CHAIN_SPIN_LIMIT")) h->chain_spin_limit = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("FSMG_NCHUNK")) h->nchunk = h->nchunk_persist = std::max(1, std::min((int)fsmg_model::NCHUNK, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_CHUNK_STEPS")) {      // e.g. "12,36,34,34,12": must add up to max_len
             std::vector<int> edges{0};
@@ -1789,6 +1788,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
             }
         }
         if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) { h->aux_blocks_per_cu = h->aux_blocks_persist = std::max(1, std::min(4, std::atoi(e))); h->aux_blocks_from_env = true; }
+#endif
         int least = 0, greatest = 0;
         hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, least) != hipSuccess) return bail(FSMG_ERR_HIP, "aux stream create failed");
