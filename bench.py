@@ -582,6 +582,12 @@ def main():
                           % (cell_kernel, int(steps_per_launch['lstm_fwd'])),
                 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
                 'traffic': hbm_traffic()[0], 'traffic_source': hbm_traffic()[1], 'launches': tot_n, 'avg_launch_ms': tot_ms / max(tot_n, 1),
+                # what one launch has to move (per direction, mean of the two): forward reads Z and writes the four gates, c and h; backward reads
+                # gates, c and dH and writes dZ -- 4H + 4H + 2H floats per row and time step either way
+                'algorithmic_bytes_per_launch': 4.0 * B * T * 10 * cfg['hidden_size'] * cfg['n_layers'] / max(cell['lstm_fwd'][1] / max(args.steps, 1), 1),
+                'traffic_note': ('forward = its algorithmic bytes; the bf16-split backward hands dh over as a reduce-scatter (32 partial [16 x 512] tiles per '
+                                 'XCD and time step, 1 MB, plus the sentinel refill): about a third of those L2 writes are written back (WRITE_SIZE 334 MB against '
+                                 '47 MB of dZ) = 0.7 TB/s during a latency-bound chain (DESIGN.md 9.3)') if cell_bx3 else None,
                 'algorithmic_gflop_per_launch': gf['lstm_fwd'] / max(cell['lstm_fwd'][1] / max(args.steps, 1), 1),
                 'forward': {'avg_launch_ms': cell['lstm_fwd'][0] / max(cell['lstm_fwd'][1], 1), 'us_per_time_step': 1e3 * cell['lstm_fwd'][0] / (T * cfg['n_layers'] * args.steps),
                             'frac': gf['lstm_fwd'] * args.steps / cell['lstm_fwd'][0] / PEAK_F32_MFMA_TFLOPS},
