@@ -240,7 +240,7 @@ def self_launch(args):
             result = lines.pop(i)
             break
     for line in lines:
-        print(line)
+        print(line, file=sys.stderr)
     if result is None:
         raise SystemExit('bench.py --gpus %d: the ranks printed no result line (exit code %d)' % (args.gpus, proc.returncode))
     sys.stdout.flush()
@@ -259,6 +259,13 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
         sys.exit(self_launch(args))
+    # stdout carries the result line and nothing else: what the plugins print on the way (recover_or_init's "Initializing vars")
+    # goes to stderr with the progress log
+    # (at the descriptor level too: gloo / RCCL print their connection banners from C++)
+    sys.stdout.flush()
+    result_stream = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
 
     import torch
     import torch.distributed as dist
@@ -743,8 +750,9 @@ def main():
         out['cpu_baseline'] = None
     if rank == 0:
         out['extras_failed'] = extras_failed
-        sys.stdout.flush()
-        print(json.dumps(out))
+        sys.stderr.flush()
+        print(json.dumps(out), file=result_stream)
+        result_stream.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

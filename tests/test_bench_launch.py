@@ -33,8 +33,9 @@ def test_bench_starts_its_own_ranks_and_reports_every_schedule():
                            '--no-cpu-baseline', '--no-breakdown'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                           universal_newlines=True, timeout=900, env=_clean_env(FSMG_BENCH_SAME_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', FSMG_BENCH_REPEATS='2'))
     assert proc.returncode == 0, (proc.stdout[-2000:], proc.stderr[-4000:])
-    last = proc.stdout.strip().splitlines()[-1]
-    out = json.loads(last)                                  # ONE JSON line, the last line of stdout
+    printed = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(printed) == 1, printed[:5]                   # ONE JSON line on stdout: progress and the plugins' prints go to stderr
+    out = json.loads(printed[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['scaling'] == 'weak'
     assert out['world']['size'] == 2 and out['world']['launcher'] == 'bench.py self-launch'
     assert out['world']['backend'] == 'gloo' and out['world']['same_gpu_dry_run'] is True
@@ -53,3 +54,22 @@ def test_bench_starts_its_own_ranks_and_reports_every_schedule():
         assert g['expected'] == 3 * 2 and 'timeouts' in g and 'fallback_steps_left' in g and 'rearmed' in g
     assert set(out['comm']['exposed_ms']) == set(out['schedules']) and out['comm']['ms_per_step_without_exchange'] > 0
     assert out['comm']['bytes'] > 0 and out['comm']['allreduce_ms_standalone'] > 0
+
+
+@pytest.mark.gpu
+def test_single_gpu_bench_prints_one_json_line_with_the_contract_keys():
+    """`python bench.py --steps K --warmup W` as the driver runs it at N = 1 (short, without the CPU leg): stdout is ONE JSON line."""
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '2', '--no-cpu-baseline'],
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900, env=_clean_env(FSMG_BENCH_REPEATS='2'))
+    assert proc.returncode == 0, (proc.stdout[-2000:], proc.stderr[-4000:])
+    printed = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(printed) == 1, printed[:5]
+    out = json.loads(printed[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+                'config', 'roofline', 'cpu_baseline'):
+        assert key in out, key
+    assert out['n_gpus'] == 1 and out['steps'] == 4 and out['warmup'] == 2 and out['unit'] == 'episodes/s' and out['dtype'] == 'f32'
+    assert abs(out['value'] - 1e3 / out['ms_per_step']) < 1e-6 * out['value']
+    r = out['roofline']
+    assert r['bound'] == 'mfma' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['achieved'] > 0
+    assert out['guard']['ok'], out['guard']
