@@ -152,6 +152,7 @@ struct fsmg_model {
     int aux_blocks_per_cu = 2;          // occupancy cap of the overlapped GEMMs (FSMG_AUX_BLOCKS); swept: 8 x 2 is best at cfg-B
     hipEvent_t ev_chunk[NCHUNK] = {};   // main -> aux (forward) / aux -> main (backward): chunk ready
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool merge_dk = true;               // dKx and dKh of a layer as one GEMM with a two-part A (FSMG_MERGE_DK=0: two GEMMs)
     hipEvent_t ev_bucket[2] = {};       // [0] softmax gradients final, [1] backward complete
     bool overlap = true;                // FSMG_OVERLAP=0 disables the two-stream schedule
     bool overlap_forced = false;        // FSMG_OVERLAP was set: no per-call decision
@@ -497,9 +498,9 @@ int ensure_scratch(fsmg_model* h, int B) {
         // the slab sums of these are deferred (OpBatch): each needs its own slabs until the batch is flushed
         auto keep = [&](int64_t M, int64_t N, int64_t K) { arena_need += round_up(worst(M, N, K), 64) + round_up((int64_t)MAX_SPLIT * N, 64); };
         need(rows, Hp, h->V1p); need(Hp, h->V1p, rows); need(Hp, G4, rows);
-        need(h->Ep, G4, rows); need(rows, h->Ep, G4); need(rows, Hp, G4); need(rows, G4, h->Ep); need(rows, G4, Hp);
+        need(h->Ep, G4, rows); need(h->Ep + Hp, G4, rows); need(2 * Hp, G4, rows); need(rows, h->Ep, G4); need(rows, Hp, G4); need(rows, G4, h->Ep); need(rows, G4, Hp);
         keep(rows, Hp, h->V1p); keep(Hp, h->V1p, rows);
-        for (int l = 0; l < h->L; ++l) { keep(Hp, G4, rows); keep(h->in_dim[l], G4, rows); keep(rows, h->in_dim[l], G4); }
+        for (int l = 0; l < h->L; ++l) { keep(Hp, G4, rows); keep(h->in_dim[l], G4, rows); keep(h->in_dim[l] + Hp, G4, rows); keep(rows, h->in_dim[l], G4); }
     }
     // chunked dH GEMMs of the overlap schedule have their own (smaller) shapes
     for (int nc : {h->nchunk, h->nchunk_persist})
@@ -598,7 +599,7 @@ bool use_ws_gemm(fsmg_model* h, int amode, int bmode, const GemmArgs& g, const L
 bool use_h_gemm(fsmg_model* h, int amode, int bmode, const GemmArgs& g, const Lane& ln) {
     static const int mode = std::getenv("FSMG_GEMM_H") ? std::atoi(std::getenv("FSMG_GEMM_H")) : 1;
     if (!h->bx3 || mode == 0 || ln.lds_pad != 0 || g.xcd_first != 0) return false;
-    if (amode == OP_XC && g.gather != nullptr) return false;
+    if (amode == OP_XC && g.gather != nullptr && g.m_split == 0) return false;
     if (mode == 2) return true;
     // measured in the cfg-B step (profiles/r03p_bench_h*.json, ms per launch incl. the slab sums, without / with): dH 0.349 /
     // 0.296, dW 0.375 / 0.316, projection 0.318 / 0.310, dKh + dKx 0.154 / 0.147; zx 0.047 / 0.051, dx 0.050 / 0.057
@@ -1288,6 +1289,21 @@ int backward(fsmg_model* h, int B, int part = 0) {
         PHASE(5);
         {
             ScopedTimer tm(h, "gemm_dk");
+            // dKx and dKh are one matrix of the flat gradient (the [in | h_prev] rows of `kernel_l`) and contract the same dZ over the
+            // same rows: where the 256 x 256-tile kernel takes the shape they are ONE GEMM with a two-part A (GemmArgs::m_split) --
+            // one K split and one set of slabs instead of two (cfg-B: 63 MB of slabs instead of 100), no 128-tile launch for dKx
+            GemmArgs m{};
+            if (l == 0) { m.A = h->P + h->off_emb; m.lda = h->Ep; m.gather = h->X; }
+            else { m.A = h->Hs[l - 1] + (size_t)B * Hp; m.lda = Hp; }
+            m.A2 = h->Hs[l]; m.lda2 = Hp; m.m_split = in_p;
+            m.B = h->Z[l]; m.ldb = G4; m.C = h->G + h->off_kx[l]; m.ldc = G4; m.M = in_p + Hp; m.N = G4; m.K = (int)rows;
+            m.colsum = h->G + h->off_b[l]; m.ksplit = 1;
+            const bool merged = h->merge_dk && in_p % 256 == 0 && Hp % 4 == 0 && h->off_kh[l] == h->off_kx[l] + (int64_t)in_p * G4 &&
+                                (l > 0 || 4LL * h->V1 * h->Ep < 0xfffff000LL) && 4LL * Hp * rows < 0xfffff000LL && 4LL * G4 * rows < 0xfffff000LL &&
+                                (((uintptr_t)m.A | (uintptr_t)m.A2 | (uintptr_t)m.B) & 15) == 0 && gemm_dma_enabled() && use_h_gemm(h, OP_XC, OP_XC, m, mainl);
+            if (merged) {
+                GEMMCK(gemm(h, mainl, OP_XC, OP_XC, m, d_late));
+            } else {
             GemmArgs g{};                     // dKh = Hprev^T * dZ, db = colsum(dZ)
             g.A = h->Hs[l]; g.lda = Hp; g.B = h->Z[l]; g.ldb = G4;
             g.C = h->G + h->off_kh[l]; g.ldc = G4; g.M = Hp; g.N = G4; g.K = (int)rows;
@@ -1299,6 +1315,7 @@ int backward(fsmg_model* h, int B, int part = 0) {
             k.B = h->Z[l]; k.ldb = G4; k.C = h->G + h->off_kx[l]; k.ldc = G4;
             k.M = in_p; k.N = G4; k.K = (int)rows; k.ksplit = 1;
             GEMMCK(gemm(h, mainl, OP_XC, OP_XC, k, d_late));
+            }
         }
         {
             ScopedTimer tm(h, "gemm_dx");     // d_in = dZ * Kx^T
@@ -1759,6 +1776,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_XCD_OVERLAP")) h->xov = std::atoi(e) != 0;
         if (const char* e = std::getenv("FSMG_XOV_PARTS")) h->xov_parts = std::max(1, std::min(3, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_EAGER")) h->eager = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_MERGE_DK")) h->merge_dk = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
         h->persist_cfg = h->persist;
         if (const char* e = std::getenv("FSMG_FALLBACK_STEPS")) h->fallback_steps = std::max(1, std::atoi(e));

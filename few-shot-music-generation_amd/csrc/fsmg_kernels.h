@@ -50,6 +50,11 @@ struct GemmArgs {
     int group_m;                // bf16-split kernels: tile order, see tile_coords (gemm.hip); 0 = row tiles fastest
     unsigned long long* prof;   // diagnostics (tools/gemm_bench PROF=1, bx3 only): [blocks][waves][8] stamps, see k_gemm_bx3
     int dbg;                    // diagnostics, stamped instantiation only (k_gemm_bx3w): ablation bits, results are wrong
+    // Two-part op(A) of an XC x XC product on the 256 x 256-tile kernel (the merged weight gradient [x | h_prev]^T dZ of a layer: one
+    // launch, one K split, one set of slabs for what were two GEMMs over the same dZ).  m_split > 0: rows [0, m_split) of op(A) are
+    // the columns of A -- K rows gathered through `gather` when it is set (the caller guarantees the gathered table < 4 GiB) --,
+    // rows [m_split, M) the columns of A2 (never gathered).  m_split is a multiple of 256.
+    const float* A2; int lda2; int m_split;
 };
 // amode/bmode in {OP_KC, OP_XC}. Supported combinations: (KC,XC) (XC,XC) (KC,KC)
 hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, int lds_pad = 0);
@@ -58,6 +63,7 @@ int gemm_lds_pad_for(int blocks_per_cu);
 // resident 128x128 blocks the chip holds at once (256 CUs x blocks per CU): the split-K policy's slot count
 int gemm_block_slots();
 int gemm_tile_m();   // rows of a block tile (128 or 256)
+bool gemm_dma_enabled();   // the 256-tile kernel stages x-contiguous operands through LDS-DMA (FSMG_GEMM_DMA=0: registers; A/B runs)
 // out[i] = sum_z slabs[z][i]  (fixed order -> deterministic split-K)
 hipError_t launch_reduce_slabs(hipStream_t s, const float* slabs, long long slab_stride, int nslab,
                                float* out, long long n);

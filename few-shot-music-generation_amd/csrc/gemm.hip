@@ -742,7 +742,7 @@ struct BxStager {
 // touches the region, so the only synchronisation is the wave's own vmcnt / lgkmcnt; the prefetched tile costs no registers.
 // Needs ld % 4 == 0, X % 4 == 0, a 16-byte aligned base and the operand below 4 GiB (launch_t checks).
 typedef __attribute__((address_space(3))) void* bx_lds_ptr_t;
-template <int XT>
+template <int XT, bool GATHER = false>
 struct BxDmaXC {
     static constexpr int KH = XT * 16, PLANE = 2 * KH;
     __amdgpu_buffer_rsrc_t rs;
@@ -750,15 +750,31 @@ struct BxDmaXC {
     unsigned char* raw;        // the wave's 2 KiB region (wave-uniform)
     int rd_ofs, lds_ofs, kvalid;
     float v[8];
-    __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int*, int kb, int tid, int = 0, unsigned char* raw_ = nullptr) {
+    // GATHER (the two-part A of GemmArgs::m_split): row k of the operand is row gidx[k] of the table (gidx == nullptr: row k).  The row
+    // ids of the NEXT tile are requested right behind this tile's DMA loads and are in by the time the following fetch() needs them
+    // (load()'s vmcnt(0) sits in between); rows past the K range are clamped to its last row here and zeroed in load() as always.
+    const int* gidx; int gk[2], gend; unsigned xofs, gnext[2];
+    __device__ __forceinline__ unsigned grow(int i) { const int k = min(gk[i], gend); gk[i] += 16; return gidx ? (unsigned)gidx[k] : (unsigned)k; }
+    __device__ __forceinline__ void init(const float* src, int ld, int X, int x0, const int* gather, int kb, int tid, int = 0, unsigned char* raw_ = nullptr, int kend = 0) {
         const int lane = tid & 63, wave = tid >> 6;
         raw = raw_;
         const int xcol = min(x0 + 32 * wave + 4 * (lane & 7), X - 4), krow = lane >> 3;
         ldb = (unsigned)ld * 4u;
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)0xfffffffcu, 0x00020000);
+        if constexpr (GATHER) {
+            gidx = gather; gend = kend - 1; xofs = (unsigned)xcol * 4u;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) vo[i] = (unsigned)(kb + 8 * i + krow) * ldb + (unsigned)xcol * 4u;
-        so = 0; sstep = 16u * ldb;
+            for (int i = 0; i < 2; ++i) gk[i] = kb + 8 * i + krow;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) vo[i] = grow(i) * ldb + xofs;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gnext[i] = grow(i);
+            so = 0; sstep = 0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) vo[i] = (unsigned)(kb + 8 * i + krow) * ldb + (unsigned)xcol * 4u;
+            so = 0; sstep = 16u * ldb;
+        }
         rd_ofs = ((lane >> 5) * 256 + (lane & 31)) * 4;
         lds_ofs = (lane >> 5) * KH + (32 * wave + (lane & 31)) * 16;
         kvalid = 16;
@@ -767,10 +783,20 @@ struct BxDmaXC {
         const unsigned s0 = __builtin_amdgcn_readfirstlane(so);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (bx_lds_ptr_t)raw, 16, vo[0], s0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (bx_lds_ptr_t)(raw + 1024), 16, vo[1], s0, 0, 0);
-        so += sstep;
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { vo[i] = gnext[i] * ldb + xofs; gnext[i] = grow(i); }
+        } else {
+            so += sstep;
+        }
     }
     // last tile of a K range: rows from kend on are read from row kend - 1 and zeroed in load()
     __device__ __forceinline__ void fetch_partial(int k0, int kend, int tid) {
+        if constexpr (GATHER) {
+            fetch();                        // (clamped to row kend - 1 when the row ids were requested)
+            kvalid = kend - k0;
+            return;
+        }
         const int krow = (tid & 63) >> 3;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {         // vo[i] + so addresses row k0 + 8 i + krow: step back to row kend - 1 from beyond it
@@ -800,8 +826,8 @@ struct BxDmaXC {
             *reinterpret_cast<uint4*>(tile + pl * PLANE + lds_ofs) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
     }
 };
-template <bool DMA, int MODE, int XT, int NT, bool BUF> struct BxStagerSel { typedef BxStager<MODE, XT, NT, BUF> type; };
-template <int XT, int NT, bool BUF> struct BxStagerSel<true, OP_XC, XT, NT, BUF> { typedef BxDmaXC<XT> type; };
+template <bool DMA, int MODE, int XT, int NT, bool BUF, bool GATHER = false> struct BxStagerSel { typedef BxStager<MODE, XT, NT, BUF> type; };
+template <int XT, int NT, bool BUF, bool GATHER> struct BxStagerSel<true, OP_XC, XT, NT, BUF, GATHER> { typedef BxDmaXC<XT, GATHER> type; };
 
 // PROF (tools/gemm_bench PROF=1): per (block, wave) s_memtime stamps -> g.prof[(block * 4 + wave) * 8 + ...]:
 //   [0] entry, [1] first loop iteration, [2] sum over k tiles of (fragment reads + MFMA issue), [3] sum of (wait for the
@@ -1094,7 +1120,8 @@ __global__ __launch_bounds__(256 * (MT + 1), MT == 1 ? 2 : 1) void k_gemm_bx3w(c
 // QUEUE (GemmArgs::xcd_first != 0): the tile comes from the work queue of k_gemm_queue instead of blockIdx -- a restricted launch
 // (xcd_first > 0) lets only blocks on XCDs >= xcd_first draw, only items below work_limit and only while *stop == 0; the clean-up
 // launch (xcd_first < 0) takes what nobody claimed.  Which block computes an item never changes the item.
-template <int AMODE, int BMODE, bool PROF = false, int BUFM = 0, bool QUEUE = false>
+// AG: two-part op(A) (GemmArgs::m_split; x-contiguous operands through LDS-DMA only)
+template <int AMODE, int BMODE, bool PROF = false, int BUFM = 0, bool QUEUE = false, bool AG = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     constexpr int XT = 256;
     constexpr int PLANE = 2 * XT * 16, OPER = 3 * PLANE, STAGE = 2 * OPER;            // 8 KiB, 24 KiB, 48 KiB
@@ -1191,8 +1218,14 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     const int nk = (ke > kb) ? (ke - kb + 15) / 16 : 0;
     const int nfull = (ke > kb) ? (ke - kb) / 16 : 0;
 
-    typename BxStagerSel<DMA, AMODE, XT, 512, (BUFM >= 2)>::type sa;      // 512 threads cover 256 rows / columns, 8 values each
+    typename BxStagerSel<DMA, AMODE, XT, 512, (BUFM >= 2), AG>::type sa;      // 512 threads cover 256 rows / columns, 8 values each
     typename BxStagerSel<DMA, BMODE, XT, 512, (BUFM >= 1)>::type sb;
+    if constexpr (AG) {                                   // which part of op(A) this row tile belongs to
+        static_assert(!AG || (DMA && AMODE == OP_XC), "two-part A: LDS-DMA staged x-contiguous operand");
+        const bool first = m0 < g.m_split;
+        sa.init(first ? g.A : g.A2, first ? g.lda : g.lda2, first ? g.m_split : g.M - g.m_split, first ? m0 : m0 - g.m_split,
+                first ? g.gather : nullptr, kb, tid, g.K, smem + 2 * STAGE + wave * 2048, ke);
+    } else
     if constexpr (DMA && AMODE == OP_XC) sa.init(g.A, g.lda, g.M, m0, nullptr, kb, tid, g.K, smem + 2 * STAGE + wave * 2048);
     else sa.init(g.A, g.lda, g.M, m0, g.gather, kb, tid, g.K);
 #ifdef FSMG_EXPERIMENTS
@@ -1353,8 +1386,20 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
 #endif
     if (g.bx3 == 3) {        // 256 x 256 tile
         dim3 grid3(((g.M + 255) / 256) * ((g.N + 255) / 256), g.ksplit > 1 ? g.ksplit : 1);
+        if (g.m_split > 0) {    // two-part op(A): [gathered or plain | plain], both parts and B through LDS-DMA
+            if constexpr (AMODE == OP_XC && BMODE == OP_XC) {
+                const bool ok = g.m_split % 256 == 0 && g.m_split < g.M && g.A2 != nullptr && g.prof == nullptr && b_buf &&
+                                g.lda % 4 == 0 && g.lda2 % 4 == 0 && (g.M - g.m_split) % 4 == 0 && g.ldb % 4 == 0 && g.N % 4 == 0 &&
+                                (((uintptr_t)g.A | (uintptr_t)g.A2 | (uintptr_t)g.B) & 15) == 0 && 4LL * g.lda2 * g.K < 0xfffff000LL &&
+                                (g.gather != nullptr || 4LL * g.lda * g.K < 0xfffff000LL);
+                if (!ok) return hipErrorInvalidValue;
+                hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 3, false, true>), grid3, dim3(512), lds_pad, s, g);
+                return hipGetLastError();
+            }
+            return hipErrorInvalidValue;
+        }
         // x-contiguous operands through LDS-DMA where their shape allows 16-byte row pieces (BxDmaXC)
-        static const bool dma_off = std::getenv("FSMG_GEMM_DMA") && std::atoi(std::getenv("FSMG_GEMM_DMA")) == 0;
+        const bool dma_off = !gemm_dma_enabled();
         const bool a_dma = AMODE != OP_XC || (g.lda % 4 == 0 && g.M % 4 == 0 && ((uintptr_t)g.A & 15) == 0);
         const bool b_dma = BMODE != OP_XC || (g.ldb % 4 == 0 && g.N % 4 == 0 && ((uintptr_t)g.B & 15) == 0);
         // (measured: 4760 -> 3880 cycles per k tile with two x-contiguous operands, 16 -> 4 loads per thread and tile; with one,
@@ -1429,6 +1474,10 @@ __global__ void k_reduce_slabs2(const float* __restrict__ slabs, long long strid
 
 int gemm_block_slots() { return 256 * ((BK == 16 ? 4 : 2) * 256 / NTHREADS); }
 int gemm_tile_m() { return BM; }
+bool gemm_dma_enabled() {
+    static const bool off = std::getenv("FSMG_GEMM_DMA") && std::atoi(std::getenv("FSMG_GEMM_DMA")) == 0;
+    return !off;
+}
 // dynamic-LDS padding that caps the resident blocks per CU (160 KiB LDS) when a GEMM runs beside the recurrent-step
 // kernels on the auxiliary stream.  The padded block is just too big for blocks_per_cu + 1 of them to fit, NOT
 // 1/blocks_per_cu of the LDS: the first version of this cap handed the GEMM blocks all 160 KiB, so a step-kernel

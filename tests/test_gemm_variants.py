@@ -51,6 +51,8 @@ def test_every_bf16_split_gemm_variant_gives_the_same_bits():
     assert all(x == x and x > 0 for x in base['losses'])
     for over in (dict(FSMG_GEMM_WS='2', FSMG_GEMM_H='0', FSMG_GEMM_BUF='0'), dict(FSMG_GEMM_WS='0', FSMG_GEMM_H='0', FSMG_GEMM_BUF='1'),
                  dict(FSMG_GEMM_WS='2', FSMG_GEMM_H='0', FSMG_GEMM_BUF='1'), dict(FSMG_GEMM_H='2', FSMG_GEMM_BUF='0'),
-                 dict(FSMG_GEMM_H='2', FSMG_GEMM_BUF='1'), dict(FSMG_GEMM_H='2', FSMG_GEMM_DMA='0'), dict()):
+                 dict(FSMG_GEMM_H='2', FSMG_GEMM_BUF='1'), dict(FSMG_GEMM_H='2', FSMG_GEMM_DMA='0'),
+                 dict(FSMG_GEMM_H='2', FSMG_MERGE_DK='0'),      # dKx and dKh as two GEMMs instead of one with a two-part A (GemmArgs::m_split)
+                 dict()):
         got = _run(**over)
         assert got == base, (over, got, base)

@@ -1,7 +1,8 @@
-# scratch job script for `gpurun -- 'bash tools/_gpu_job.sh'` (overwritten per experiment): the round-end checks
+# scratch job script for `gpurun -- 'bash tools/_gpu_job.sh'` (overwritten per experiment): merged dK GEMM
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-timeout 3000 python -m pytest tests -m gpu -q -x ${PYTEST_K:+-k "$PYTEST_K"} > $O/r04x_pytest.log 2>&1; tail -4 $O/r04x_pytest.log | head -2
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py > $O/r04x_bench.json 2> $O/r04x_bench.err; wc -l $O/r04x_bench.json; python -c "
-import json; d=json.loads(open('$O/r04x_bench.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['guard']['ok'], d.get('extras_failed'))"
+timeout 1500 python -m pytest tests/test_gemm_variants.py -m gpu -q -x > $O/r04x_pytest_a.log 2>&1; tail -3 $O/r04x_pytest_a.log | head -2
+run() { echo -n "${CFG:-cfg-B} $* : "; env "$@" python bench.py --config ${CFG:-cfg-B} --steps 100 --warmup 20 --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['ms_per_step'],4), d['guard']['ok'], round(d['final_loss'],6))"; }
+for i in 1 2; do run FSMG_MERGE_DK=0; run FSMG_MERGE_DK=1; done
+for c in cfg-C cfg-D cfg-E ref-default; do CFG=$c run FSMG_MERGE_DK=0; CFG=$c run FSMG_MERGE_DK=1; done
+timeout 2500 python -m pytest tests -m gpu -q -x > $O/r04x_pytest.log 2>&1; tail -4 $O/r04x_pytest.log | head -2
