@@ -38,6 +38,7 @@ SHAPES = [
     (dict(hidden_size=256, embedding_size=16, input_size=70, max_len=5), 20, 1, 4),   # ... 100 rows = 7 per slice: 2 row groups
     (dict(hidden_size=200, embedding_size=24, input_size=90, max_len=7), 5, 5, 4),    # the reference's default hidden size: padded to 256 inside, same kernels
     (dict(hidden_size=256, embedding_size=16, input_size=70, max_len=5, n_layers=2), 2, 2, 1),   # ... stacked, 6 rows on 6 slices
+    (dict(hidden_size=320, embedding_size=250, input_size=300, max_len=6), 5, 5, 4),  # E = 250 pads to one 256-row tile: with FSMG_GEMM_H=2, dKx + dKh as ONE GEMM whose A is [gathered embedding rows | h_prev] and whose last row tile is partial
 ]
 
 
@@ -945,7 +946,7 @@ def test_ten_consecutive_train_losses_on_the_bf16_split_chain_at_cfg_d_rows():
     assert model.step == 10 and st['timeouts'] == 0 and st['xcd_launches'] > 0
 
 
-FORCED = [(env, i) for env in ({'FSMG_XCD_BX3': '1'}, {'FSMG_GEMM_H': '2'}, {'FSMG_XCD_OVERLAP': '0'}) for i in (2, 4, 9, 10, 11, 12)] + \
+FORCED = [(env, i) for env in ({'FSMG_XCD_BX3': '1'}, {'FSMG_GEMM_H': '2'}, {'FSMG_XCD_OVERLAP': '0'}) for i in (2, 4, 9, 10, 11, 12)] + [({'FSMG_GEMM_H': '2'}, 20)] + \
          [({'FSMG_XCD_OVERLAP': '1'}, i) for i in (9, 10)] + \
          [({'FSMG_XCD': '0'}, i) for i in (8, 16)]              # ... the XCD-partitioned order at shapes AUTO finds too small for it; the column-split persistent kernels at hidden 256 / 512
 
