@@ -500,15 +500,16 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                     LstmFwdXcdArgs a{};
                     a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
                     a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
-                    CK(launch_lstm_fwd_xcd(s, a));
+                    CK(hipEventRecord(e0, s)); CK(launch_lstm_fwd_xcd(s, a)); CK(hipEventRecord(e1, s));
                 } else {
                     bwd_xcd(T, 0);
                     LstmBwdXcdArgs a{};
                     a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
                     a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
-                    CK(launch_lstm_bwd_xcd(s, a));
+                    CK(hipEventRecord(e0, s)); CK(launch_lstm_bwd_xcd(s, a)); CK(hipEventRecord(e1, s));
                 }
                 CK(hipStreamSynchronize(s));
+                float ms_prof = 0.0f; CK(hipEventElapsedTime(&ms_prof, e0, e1));
                 CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
                 const char* names_f0[5] = {"wait h_t", "MFMA", "LDS+barrier", "cell->store", "rest"};
                 const char* names_b0[5] = {"wait inbox", "psum+barrier", "cell+dzA+barrier", "LDS read+MFMA", "drain+stores+rest"};
@@ -520,7 +521,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                     printf("[4] %s phase ticks per step, waves %d-%d:", dir ? "bwd" : "fwd", 2 * wc, 2 * wc + 1);
                     double tot = 0;
                     for (int i = 0; i < 5; ++i) { printf("  %s %.0f", dir ? names_b[i] : names_f[i], m[i] / 512 / T); tot += m[i] / 512 / T; }
-                    printf("  | total %.0f\n", tot);
+                    printf("  | total %.0f  (stamped launch: %.3f us per step -> %.3f GHz shader clock)\n", tot, 1e3 * ms_prof / T, tot / (1e3 * ms_prof / T) / 1e3);
                 }
             }
             hipFree(prof);
