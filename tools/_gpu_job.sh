@@ -5,3 +5,5 @@ timeout 3000 python -m pytest tests -m gpu -q -x > $O/r04x_pytest.log 2>&1; grep
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py > $O/r04x_bench.json 2> $O/r04x_bench.err; wc -l < $O/r04x_bench.json; python -c "
 import json; d=json.loads(open('$O/r04x_bench.json').read()); print(d['value'], d['ms_per_step'], d['guard']['ok'], d.get('extras_failed'))"
+python bench.py --config cfg-E --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_bench_cfg-E.json; python -c "
+import json; d=json.loads(open('$O/r04_bench_cfg-E.json').read()); print('cfg-E', d['value'], d['ms_per_step'], d['guard']['ok'])"
