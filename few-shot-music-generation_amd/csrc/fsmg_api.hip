@@ -2578,9 +2578,10 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
     };
     int l;
     if (!std::strcmp(what, "xcd_bx3")) { host[0] = h->xcd_bx3 ? 1.0f : 0.0f; return FSMG_OK; }      // a host-side fact: which XCD-local kernel family this handle runs
-    if (!std::strcmp(what, "xcd_partitioned")) {      // ... and whether its train passes take the XCD-partitioned order: [0] yes / no, [1] XCDs the chains occupy
+    if (!std::strcmp(what, "xcd_partitioned")) {      // ... and whether its train passes take the XCD-partitioned order: [0] yes / no, [1] XCDs the chains occupy, [2] the last pass
         host[0] = h->xov ? 1.0f : 0.0f;
         if (count > 1) { const int b = h->lastB > 0 ? h->lastB : 45, rpx = lstm_xcd16_packed_rows(b); host[1] = (h->xov && rpx > 0) ? (float)((b + rpx - 1) / rpx) : 8.0f; }
+        if (count > 2) host[2] = h->xov_last ? 1.0f : 0.0f;       // [2] whether the LAST train pass took it (its row count decides per call)
         return FSMG_OK;
     }
     if (!std::strcmp(what, "logits")) { src = h->logits; cap = rows * h->V1p; }

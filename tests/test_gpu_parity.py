@@ -764,6 +764,35 @@ def test_xcd_partitioned_schedule_gives_the_same_bits(monkeypatch):
     assert all(st['timeouts'] == 0 and st['xcd_launches'] > 0 for _, _, st in out)
 
 
+def test_partitioned_order_with_episode_shapes_that_change_from_call_to_call(monkeypatch):
+    """The plugin contract lets N, K, Q differ from call to call (the reference's placeholders have a free batch dimension).  One
+    handle created for cfg-B's 45 sequences then sees 45, 18, 30, 6, 60 (more than it was sized for: buffers grow), 45 rows: calls whose
+    row count the packed chains take run the XCD-partitioned order, the others fall to the serial one -- same losses as a handle that
+    never leaves the serial order (the forward is bit-identical per call; dW's K split differs, so later losses agree to rounding),
+    no time-out, no stale queue words or progress counters from a call of another shape."""
+    over, N, K, Q = FULL['cfg-B']
+    cfg = small_config(**dict(over, max_len=48))
+    shapes = [(5, 5, 4), (2, 5, 4), (5, 3, 3), (3, 1, 1), (6, 5, 5), (5, 5, 4), (2, 5, 4), (5, 5, 4)]
+    eps = [O.synthetic_episodes(1, n, k, q, cfg['max_len'], cfg['input_size'], seed=40 + i)[0] for i, (n, k, q) in enumerate(shapes)]
+    runs = {}
+    for xov in ('0', '1'):
+        monkeypatch.setenv('FSMG_XCD_OVERLAP', xov)
+        model = new_model(cfg, max_sequences=45)
+        losses, used = [], []
+        for s_, q_ in eps:
+            losses.append(model.train_step(s_, q_))
+            used.append(int(model.debug_read('xcd_partitioned', 3)[2]))
+        runs[xov] = (losses, used, model.stats(), {k: model.get_param(k) for k in model.param_shapes})
+        model.close()
+    assert all(np.isfinite(runs['1'][0])) and runs['1'][2]['timeouts'] == 0 and runs['0'][2]['timeouts'] == 0
+    assert not any(runs['0'][1]) and runs['1'][1][0] == 1 and runs['1'][1][5] == 1, runs['1'][1]      # 45 rows: partitioned; the serial handle never
+    assert runs['1'][0][0] == runs['0'][0][0]                                                          # first call: same bits
+    np.testing.assert_allclose(runs['1'][0], runs['0'][0], rtol=2e-6)
+    for k in runs['0'][3]:
+        # (Adam's m / sqrt(v) amplifies last-bit gradient differences on rarely touched embedding rows: a few elements move by 1e-4 of the largest)
+        np.testing.assert_allclose(runs['1'][3][k], runs['0'][3][k], rtol=0, atol=1e-3 * max(np.abs(runs['0'][3][k]).max(), 1e-3))
+
+
 def test_fresh_handles_reproduce_each_other_bit_for_bit_at_cfg_b():
     """Race screen (tools/race_hunt2.py in small): 100 fresh handles, two train steps each on DIFFERENT episodes (so a
     stale buffer of the previous handle or step would carry different data), every gradient and parameter identical
