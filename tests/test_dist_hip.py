@@ -51,8 +51,14 @@ def test_two_ranks_on_the_hip_engine_equal_one_rank_on_the_concatenated_batch(hi
                       '(needs >= 2 visible GPUs)' % backend)
 
 
-def test_train_steps_beside_a_cu_hogging_workload_keep_their_numbers():
+@pytest.mark.parametrize('order', ['serial', 'xcd_partitioned'])
+def test_train_steps_beside_a_cu_hogging_workload_keep_their_numbers(order, monkeypatch):
+    """What a collective kernel of an overlapped exchange does to the step: another stream keeps every CU busy with matmuls while train
+    steps run.  The XCD-local chains (and, order = xcd_partitioned, the gated pair of chain and work-queue GEMM, which additionally needs
+    its two launches resident side by side) either run as usual -- same bits -- or time out, fall back and repeat the step: never a hang,
+    never a wrong number."""
     import torch
+    monkeypatch.setenv('FSMG_XCD_OVERLAP', '1' if order == 'xcd_partitioned' else '0')
     cfg = small_config(hidden_size=512, embedding_size=64, input_size=2000, max_len=32)
     eps = O.synthetic_episodes(12, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=51)
     quiet = new_model(cfg)
@@ -73,6 +79,7 @@ def test_train_steps_beside_a_cu_hogging_workload_keep_their_numbers():
     torch.cuda.synchronize()
     stats = busy.stats()
     assert busy.step == len(eps) and stats['steps_skipped_token_range'] == 0
+    assert int(quiet.debug_read('xcd_partitioned', 3)[2]) == (1 if order == 'xcd_partitioned' else 0)
     if stats['timeouts'] == 0:
         assert got == want                               # same kernels, same order: same bits
     else:                                                # a recovered time-out repeats the step on per-step launches

@@ -1,3 +1,7 @@
-# scratch job script: one test
+# scratch job script for `gpurun -- 'bash tools/_gpu_job.sh'` (overwritten per experiment): the round-end checks
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "change_from_call_to_call" 2>&1 | tail -30
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+timeout 3000 python -m pytest tests -m gpu -q -x > $O/r04x_pytest.log 2>&1; grep -n "passed\|failed" $O/r04x_pytest.log | tail -1
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > $O/r04x_bench.json 2> $O/r04x_bench.err; wc -l < $O/r04x_bench.json; python -c "
+import json; d=json.loads(open('$O/r04x_bench.json').read()); print(d['value'], d['ms_per_step'], d['guard']['ok'], d.get('extras_failed'))"
