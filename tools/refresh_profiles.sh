@@ -2,16 +2,17 @@
 # Regenerates the round artefacts on the GPU box into gpurun_out/ (copy the ones to keep into profiles/).
 #   gpurun -- tools/refresh_profiles.sh [tag]
 TAG=${1:-r04}
+# every profiler invocation runs under `timeout`: in call 47 of round 4 a --pmc FETCH_SIZE pass never returned and spent the rest of the round's GPU budget
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
-rm -rf /tmp/prof_st; rocprofv3 --kernel-trace --stats -d /tmp/prof_st -o st -- python $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprofv3.json
+rm -rf /tmp/prof_st; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_st -o st -- python $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprofv3.json
 python $R/tools/rocpd_stats.py $(find /tmp/prof_st -name "*.db" | head -1) > $O/${TAG}_bench_rocprofv3_kernel_stats.txt 2>&1
 python $R/tools/step_timeline.py $(find /tmp/prof_st -name "*.db" | head -1) 30 > $O/${TAG}_step_timeline.txt 2>&1
 # the hidden-1024 configurations (BASELINE.json configs[2], configs[4]) and cfg-D (100 rows: the bf16-split XCD-local recurrence): bench line, per-kernel statistics, device timeline
 for c in cfg-C cfg-E cfg-D; do
   t=$(echo $c | tr -d '-')
-  rm -rf /tmp/prof_$t; rocprofv3 --kernel-trace --stats -d /tmp/prof_$t -o st -- python $R/bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_${t}_bench_under_rocprofv3.json
+  rm -rf /tmp/prof_$t; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$t -o st -- python $R/bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_${t}_bench_under_rocprofv3.json
   python $R/tools/rocpd_stats.py $(find /tmp/prof_$t -name "*.db" | head -1) > $O/${TAG}_${t}_bench_rocprofv3_kernel_stats.txt 2>&1
   python $R/tools/step_timeline.py $(find /tmp/prof_$t -name "*.db" | head -1) 30 > $O/${TAG}_${t}_step_timeline.txt 2>&1
 done
@@ -22,7 +23,7 @@ done
 # counters: separate passes (SQ block 8 slots; FETCH_SIZE and WRITE_SIZE do not fit one TCC pass), kernel-trace only
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   n=$(echo $set | cut -d' ' -f1)
-  rm -rf /tmp/prof_$n; rocprofv3 --pmc $set --kernel-trace -f csv -d /tmp/prof_$n -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-breakdown > /dev/null 2>&1
+  rm -rf /tmp/prof_$n; timeout 600 rocprofv3 --pmc $set --kernel-trace -f csv -d /tmp/prof_$n -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-breakdown > /dev/null 2>&1
   f=$(find /tmp/prof_$n -name "*counter_collection.csv" | head -1)
   python $R/tools/pmc_summary.py $f > $O/${TAG}_pmc_$n.txt 2>&1
   cp $f $O/${TAG}_pmc_$n.csv 2>/dev/null
@@ -60,8 +61,8 @@ cd /tmp
 python $R/bench.py --config ref-default --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_ref-default.json
 FSMG_HP_ALIGN=16 python $R/bench.py --config ref-default --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_ref-default_hp208.json
 FSMG_XCD_OVERLAP=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_serial_order.json
-rm -rf /tmp/prof_ser; FSMG_XCD_OVERLAP=0 rocprofv3 --kernel-trace --stats -d /tmp/prof_ser -o st -- python $R/bench.py --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > /dev/null
+rm -rf /tmp/prof_ser; FSMG_XCD_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_ser -o st -- python $R/bench.py --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > /dev/null
 python $R/tools/step_timeline.py $(find /tmp/prof_ser -name "*.db" | head -1) 150 > $O/${TAG}_step_timeline_serial_order.txt 2>&1
-rm -rf /tmp/prof_rd; rocprofv3 --kernel-trace --stats -d /tmp/prof_rd -o st -- python $R/bench.py --config ref-default --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > /dev/null
+rm -rf /tmp/prof_rd; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_rd -o st -- python $R/bench.py --config ref-default --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > /dev/null
 python $R/tools/step_timeline.py $(find /tmp/prof_rd -name "*.db" | head -1) 150 > $O/${TAG}_refdefault_step_timeline.txt 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/prof_rd -name "*.db" | head -1) > $O/${TAG}_refdefault_rocprofv3_kernel_stats.txt 2>&1
