@@ -225,9 +225,11 @@ __global__ void k_gather_rows(const int* __restrict__ table, const int* __restri
 // One 256-thread block per logits row; pass 1 row max, pass 2 sum exp (second read is an L2 hit).
 // With dlogits != nullptr a third pass (the row is cache-hot) also writes the loss gradient
 // dlogits = (softmax - onehot) * inv_n for the two backward projection GEMMs, zero in the pad columns.
-__global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ logits, int ld, int n_vocab,
+// dlogits may BE logits (the train pass writes the gradient over the logits it has just read, fsmg_model::inplace_dlogits): neither
+// pointer is `restrict`, and a thread writes only elements it has itself read before.
+__global__ __launch_bounds__(256) void k_ce_rows(const float* logits, int ld, int n_vocab,
                                                  const int* __restrict__ tgt, float* __restrict__ lse,
-                                                 float* __restrict__ ce, float* __restrict__ dlogits, float inv_n) {
+                                                 float* __restrict__ ce, float* dlogits, float inv_n) {
     __shared__ float sh[4];
     __shared__ float s_lse;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ logit
         s_lse = l;
     }
     if (dlogits == nullptr) return;
-    __syncthreads();
+    __syncthreads();                                     // (also: row[t] has been read before anybody overwrites it in place)
     const float l = s_lse;
     float* drow = dlogits + (long long)r * ld;
     for (int v = 4 * tid; v < ld; v += 1024) {          // ld is a multiple of 4 and >= n_vocab
@@ -281,9 +283,9 @@ __global__ __launch_bounds__(256) void k_ce_rows(const float* __restrict__ logit
 // re-reads 40 KB rows that have long left the L2 when thousands of rows are in flight (0.141 -> see DESIGN.md).
 // softmax = exp(x - max) / sum instead of exp(x - lse): the same value to ~1 ulp.
 template <int NV, bool NT>
-__global__ __launch_bounds__(256) void k_ce_rows_reg(const float* __restrict__ logits, int ld, int n_vocab,
+__global__ __launch_bounds__(256) void k_ce_rows_reg(const float* logits, int ld, int n_vocab,
                                                      const int* __restrict__ tgt, float* __restrict__ lse,
-                                                     float* __restrict__ ce, float* __restrict__ dlogits, float inv_n) {
+                                                     float* __restrict__ ce, float* dlogits, float inv_n) {     // dlogits may be logits: the whole row is in registers behind the barriers
     __shared__ float sh[8];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = logits + (long long)r * ld;
@@ -465,8 +467,15 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
     __shared__ float s_scale, s_alpha;
     // the gradients of a step whose persistent recurrent kernel timed out are garbage, and a batch with an out-of-range
     // token is rejected as a whole (the reference would fail the feed): keep the parameters
-    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f || a.tail[4] != 0.0f) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.consume != nullptr) {             // second launch of a split update: what the first one decided
+        if (a.consume[0] == 0.0f) return;
+        if (tid == 0) { s_scale = a.consume[1]; s_alpha = a.consume[2]; }
+    } else {
+    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f || a.tail[4] != 0.0f) {
+        if (a.publish != nullptr && blockIdx.x == 0 && tid == 0) a.publish[0] = 0.0f;
+        return;
+    }
     double s = 0.0;
     for (int i = tid; i < a.n_partials; i += 256) s += a.partials[i];
     s = wave_sum_d(s);
@@ -483,6 +492,8 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
         const double lr_s = (double)a.lr * pow(0.5, (double)step / (double)a.n_decay);
         s_alpha = (float)(lr_s * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
         if (a.gnorm_out != nullptr && blockIdx.x == 0) *a.gnorm_out = (float)gnorm;
+        if (a.publish != nullptr && blockIdx.x == 0) { a.publish[0] = 1.0f; a.publish[1] = s_scale; a.publish[2] = s_alpha; }
+    }
     }
     __syncthreads();
     const float scale = s_scale, alpha = s_alpha;
@@ -594,6 +605,27 @@ __global__ void k_clock_probe(long long ticks, unsigned long long* out) {
     while ((long long)(r1 - r0) < ticks) { __builtin_amdgcn_s_sleep(64); r1 = __builtin_amdgcn_s_memrealtime(); }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+
+// Self-check of the XCD-partitioned order (api_forward.hip: xov_selfcheck): the logits of the gated work-queue projection against the same
+// GEMM recomputed behind the chain, word for word.  A difference is counted per wave (one system-scope atomic) and raises the flag.
+__global__ __launch_bounds__(256) void k_compare_words(const uint4* __restrict__ a, const uint4* __restrict__ b, long long n4, int* err_flag,
+                                                       unsigned long long* counter) {
+    if (*err_flag != 0) return;         // the step is being skipped already (a gate or a chain timed out: the logits are incomplete by design)
+    unsigned bad = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const uint4 x = a[i], y = b[i];
+        bad += (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+    }
+    const unsigned long long votes = __ballot(bad != 0);
+    if (votes == 0) return;
+    unsigned total = bad;
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    if ((threadIdx.x & 63) == __ffsll((long long)votes) - 1) {
+        atomicAdd_system(counter, (unsigned long long)total);
+        *err_flag = 2;
+        __threadfence_system();
+    }
 }
 
 // ---------------------------------------------------------------- unigram baseline
@@ -738,7 +770,9 @@ hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, c
 hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt,
                           float* lse, float* ce, float* dlogits, float inv_n) {
     if (rows <= 0) return hipSuccess;
-    const int nt = 1;      // non-temporal dlogits stores (A/B settled in round 3: the regular-store instantiations stay for the record)
+    // non-temporal dlogits stores (A/B settled in round 3 for a separate dlogits buffer; FSMG_CE_NT=0: regular stores -- the A/B of
+    // round 5 for the in-place form, where the lines being written are the lines just read)
+    static const int nt = std::getenv("FSMG_CE_NT") ? (std::atoi(std::getenv("FSMG_CE_NT")) != 0) : 1;
     if (ld <= 6 * 1024) {
         if (nt) hipLaunchKernelGGL((k_ce_rows_reg<6, true>), dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
         else hipLaunchKernelGGL((k_ce_rows_reg<6, false>), dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
@@ -847,6 +881,13 @@ hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, flo
 
 hipError_t launch_clock_probe(hipStream_t s, long long realtime_ticks, unsigned long long* out) {
     hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, realtime_ticks, out);
+    return hipGetLastError();
+}
+hipError_t launch_compare_words(hipStream_t s, const void* a, const void* b, long long n_words, int* err_flag, long long* counter) {
+    const long long n4 = n_words >> 2;
+    if (n4 <= 0) return hipSuccess;
+    const int blocks = (int)std::min<long long>((n4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_compare_words, dim3(blocks), dim3(256), 0, s, (const uint4*)a, (const uint4*)b, n4, err_flag, (unsigned long long*)counter);
     return hipGetLastError();
 }
 hipError_t launch_unigram_update(hipStream_t s, const int* words, long long n, unsigned* counts, int vocab, int* err_flag) {

@@ -282,6 +282,10 @@ struct UpdateArgs {
     const long long* step;                        // global_step BEFORE this update (device)
     float* gnorm_out;                             // optional: pre-clip global norm
     const int* err_flag;                          // optional: *err_flag != 0 (a persistent step kernel gave up / a token id was out of range) -> no update
+    // launch_adam_update in two launches over two ranges of the flat buffers (the second one on another stream, later): the first
+    // writes publish[0..2] = (go ? 1 : 0, clip scale, alpha) from thread 0 of block 0, the second (consume != nullptr) reads them
+    // instead of deriving them -- flags, tail and step counter may have moved on by then
+    float* publish; const float* consume;
 };
 hipError_t launch_adam_update(hipStream_t s, const UpdateArgs& a);
 // p <- p - a.lr * clip_by_global_norm(g): the inner-loop step of cfg-E (m, v, step, n_decay, grad_scale unused)
@@ -319,6 +323,9 @@ hipError_t launch_step_increment(hipStream_t s, const StepIncArgs& a);
 // ce != nullptr: also *loss_out = sum(ce[0 .. ce_n)) / (ce_n + 1e-12) -- launch_loss_reduce with one group, same bits
 hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, float* dst, const int* flag_src = nullptr,
                                const float* ce = nullptr, int ce_n = 0, float* loss_out = nullptr);
+// a[0 .. n_words) against b[0 .. n_words) as 32-bit words (n_words a multiple of 4, both 16-byte aligned): every differing 16-byte
+// word adds 1 to *counter (host-mapped) and sets *err_flag = 2 -- the step is then skipped like a timed-out one
+hipError_t launch_compare_words(hipStream_t s, const void* a, const void* b, long long n_words, int* err_flag, long long* counter);
 // one wave for `realtime_ticks` of the 100 MHz counter: out[0] = shader-clock ticks elapsed, out[1] = real-time ticks elapsed
 hipError_t launch_clock_probe(hipStream_t s, long long realtime_ticks, unsigned long long* out);
 // unigram baseline (reference src/models/unigram_model.py:26-39): counts[w] += 1 per word; out[0] = -mean(log(count[w] / sum(counts))),

@@ -12,7 +12,7 @@ from fsmg.build import LIB
 
 FSMG_GRAD_TAIL = 16
 CLIP_MODES = {'tf1_slices': 0, 'dense': 1}
-FSMG_CONFIG_VERSION = 3
+FSMG_CONFIG_VERSION = 4
 GEMM_KINDS = {'auto': 0, 'bx3': 1, 'f32': 2}
 SCHEDULES = {'auto': 0, 'single_stream': 1, 'two_stream': 2, 'xcd_partitioned': 3}
 RECURRENCES = {'auto': 0, 'per_step': 1, 'column_split': 2, 'xcd_local': 3}
@@ -40,7 +40,8 @@ class FsmgConfig(C.Structure):
 class FsmgStats(C.Structure):
     _fields_ = [('timeouts', C.c_int64), ('steps_skipped_timeout', C.c_int64), ('steps_skipped_token_range', C.c_int64),
                 ('xcd_launches', C.c_int64), ('persistent_launches', C.c_int64), ('step_launches', C.c_int64),
-                ('persistent_path', C.c_int32), ('fallback_steps_left', C.c_int32), ('steps_skipped_peer_failure', C.c_int64)]
+                ('persistent_path', C.c_int32), ('fallback_steps_left', C.c_int32), ('steps_skipped_peer_failure', C.c_int64),
+                ('xov_selfcheck_mismatches', C.c_int64)]
 
 
 _P = C.c_void_p
@@ -440,7 +441,8 @@ class FsmgModel(object):
         return dict(Ep=d[0], Hp=d[1], V1p=d[2], B=d[3], T=d[4])
 
     def debug_set(self, what, value):
-        """run-time knob of the handle (include/fsmg.h: chain_spin_limit, fallback_steps, eager)"""
+        """run-time knob of the handle (include/fsmg.h: chain_spin_limit, fallback_steps, persistent, eager, inplace_dlogits,
+        upd_split, xov_selfcheck, xov_selfcheck_fault)"""
         self._ck(self._lib.fsmg_debug_set(self._h, what.encode(), int(value)))
 
     def clock_begin(self, microseconds):

@@ -35,8 +35,13 @@
 extern "C" {
 #endif
 
-#define FSMG_VERSION 400 /* 0.4.0 */
-#define FSMG_CONFIG_VERSION 3 /* layout of struct fsmg_config; fsmg_create rejects any other value in .config_version */
+#define FSMG_VERSION 500 /* 0.5.0 */
+/* layout of struct fsmg_config AND of every other struct / flat-buffer layout a caller may hold (struct fsmg_stats, the padded
+ * sizes fsmg_debug_dims reports): fsmg_create rejects any other value in .config_version, so a caller built against an older
+ * header fails at create time instead of being overrun later.  4 (0.5.0): fsmg_stats grew (steps_skipped_peer_failure in 0.4.0,
+ * xov_selfcheck_mismatches now); hidden sizes that no persistent kernel takes at a multiple of 16 pad to a multiple of 64
+ * (200 -> 256, not 208: every padded offset behind fsmg_debug_read / fsmg_debug_dims moved in 0.4.0 without a version bump). */
+#define FSMG_CONFIG_VERSION 4
 
 enum {
     FSMG_OK = 0,
@@ -268,6 +273,9 @@ typedef struct fsmg_stats {
     int32_t persistent_path;            /* 1: persistent kernels are in force right now                              */
     int32_t fallback_steps_left;
     int64_t steps_skipped_peer_failure; /* train steps every rank skipped because one rank failed before the exchange (library-owned exchange) */
+    int64_t xov_selfcheck_mismatches;   /* XCD-partitioned order: 16-byte words of the gated projection's logits that differed from the
+                                           same GEMM recomputed on the serial path (the self-check of a handle's first passes);
+                                           non-zero = that step was skipped and repeated, the handle keeps the serial order        */
 } fsmg_stats;
 int fsmg_get_stats(fsmg_handle h, fsmg_stats* out);
 
@@ -285,6 +293,13 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
  *   "persistent"        0: one launch per time step instead of the persistent recurrent kernels, 1: back (buffers permitting)
  *   "eager"             0: passes are replayed from hipGraphs wherever fsmg_config.use_graph allows, 1: passes on the persistent
  *                       recurrent kernels are issued eagerly (default)
+ *   "inplace_dlogits"   1 (default): a train pass's cross entropy writes dlogits over the logits it has just read ("logits" then
+ *                       reads back as dlogits after a train pass), 0: two buffers
+ *   "upd_split"         1 (default): clip + Adam of an eager pass as two launches, the softmax half on the auxiliary stream beside
+ *                       the next step's input phase (bit-identical), 0: one launch
+ *   "xov_selfcheck"     XCD-partitioned order: the next `value` train passes recompute the gated projection on the serial path and
+ *                       compare the words (default: the first 2 passes of a handle)
+ *   "xov_selfcheck_fault" 1: the comparison runs against a buffer that is NOT the recomputed logits (tests of the recovery path)
  * Synchronises the stream and drops the captured graphs. */
 int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value);
 /* shader clock the chip sustains while the handle works: _begin starts a one-wave probe on a stream of its own that compares the
