@@ -91,12 +91,26 @@ def synthetic_episodes(n_episodes, N, K, Q, T, vocab, seed):
             for _ in range(n_episodes)]
 
 
-def hbm_traffic():
+def hbm_traffic(variant=None):
     """(bytes, source): HBM bytes per launch of the fused-cell kernels as RECORDED by the committed rocprofv3 PMC passes
-    (tools/refresh_profiles.sh: raw FETCH_SIZE + WRITE_SIZE, separate passes) -- counters cannot be read from inside this
-    process, so this is not a measurement of this run.  No x2 on FETCH_SIZE: the guide's gfx950 correction is calibrated for
-    16-B/lane streaming loads, and these kernels' raw FETCH_SIZE (47.7 MB forward) already equals their algorithmic read
-    (Z: 47.2 MB).  (None, None) when no record exists."""
+    (tools/pmc_passes.sh -> profiles/r05_pmc.json: raw FETCH_SIZE + WRITE_SIZE per kernel INSTANTIATION, separate passes) -- counters
+    cannot be read from inside this process, so this is not a measurement of this run; `variant` (e.g. 'xcd16<4', 'xcd16<2', 'xcd<2')
+    selects the record of the kernel family the timed region ran (the round-4 record averaged two instantiations).
+    No x2 on FETCH_SIZE: the guide's gfx950 correction is calibrated for 16-B/lane streaming loads, and these kernels' raw
+    FETCH_SIZE (47.7 MB forward) already equals their algorithmic read (Z: 47.2 MB).  (None, None) when no record exists."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r05_pmc.json')) as f:
+            rec = json.load(f)['kernels']
+        per = {}
+        for d in ('fwd', 'bwd'):
+            hits = [v for k, v in rec.items() if ('k_lstm_%s_%s' % (d, variant)) in k and v.get('FETCH_SIZE_KB') is not None and v.get('WRITE_SIZE_KB') is not None]
+            if hits:
+                per[d] = 1024.0 * (hits[0]['FETCH_SIZE_KB'] + hits[0]['WRITE_SIZE_KB'])
+        if variant and len(per) == 2:
+            return sum(per.values()) / 2, ('recorded (profiles/r05_pmc.json, k_lstm_*_%s...>: raw FETCH_SIZE + WRITE_SIZE per launch, mean of forward '
+                                           '%.1f MB and backward %.1f MB)' % (variant, per['fwd'] / 1e6, per['bwd'] / 1e6))
+    except Exception:
+        pass
     for name in ('r04_lstm_cell_pmc.json', 'r03_lstm_cell_pmc.json', 'r02_lstm_cell_pmc.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
@@ -128,11 +142,99 @@ def step_roofline(cfg, B, gf, ms_per_step):
     gemm_gf = sum(v for k, v in gf.items() if k.startswith('gemm_'))
     cell_gf = gf['lstm_fwd'] + gf['lstm_bwd']
     P = V1 * E + sum(((E if l == 0 else H) + H) * 4 * H + 4 * H for l in range(L)) + H * V1 + V1
-    by = 2 * 4 * n * V1 + 7 * 4 * P + 2 * (6 * L * H + E) * 4 * n
-    t_gemm, t_cell, t_hbm = gemm_gf / PEAK_BX3_TFLOPS, cell_gf / PEAK_F32_MFMA_TFLOPS, by / (HBM_ACHIEVABLE_TBPS * 1e9)
-    return {'bound_ms': t_gemm + t_cell + t_hbm, 'frac': (t_gemm + t_cell + t_hbm) / ms_per_step,
-            'gemm_ms_at_bf16_peak_over_6': t_gemm, 'cell_ms_at_fp32_mfma_peak': t_cell, 'hbm_ms_at_%.1f_TBps' % HBM_ACHIEVABLE_TBPS: t_hbm,
-            'hbm_bytes': by, 'note': 'sum of the three bounds (no overlap assumed) over the measured ms_per_step'}
+    # SURVEY.md 8(d)'s algorithmic bytes: parameters read once forward and once backward, the optimizer's 7 P floats, the tokens,
+    # the saved activations written and read once.  The logits are NOT in it ("never materialise logits"): the step
+    # does materialise them -- written by the projection, read by the cross entropy, dlogits written (in place since round 5) and
+    # read by both projection-gradient GEMMs -- which is listed beside it, not priced as necessary
+    by_alg = 2 * 4 * P + 7 * 4 * P + 2 * 4 * n + 2 * (6 * L * H + E) * 4 * n
+    by_logits = 5 * 4 * n * V1
+    t_gemm, t_cell, t_hbm = gemm_gf / PEAK_BX3_TFLOPS, cell_gf / PEAK_F32_MFMA_TFLOPS, by_alg / (HBM_ACHIEVABLE_TBPS * 1e9)
+    out = {'bound_ms': t_gemm + t_cell + t_hbm, 'frac': (t_gemm + t_cell + t_hbm) / ms_per_step,
+           'gemm_ms_at_bf16_peak_over_6': t_gemm, 'cell_ms_at_fp32_mfma_peak': t_cell, 'hbm_ms_at_%.1f_TBps' % HBM_ACHIEVABLE_TBPS: t_hbm,
+           'hbm_bytes': by_alg, 'hbm_bytes_algorithmic': by_alg,
+           'hbm_bytes_logits_round_trips': by_logits,
+           'hbm_bytes_moved_model': by_alg + by_logits,
+           'frac_r04_definition': (t_gemm + t_cell + (2 * 4 * n * V1 + 7 * 4 * P + 2 * (6 * L * H + E) * 4 * n) / (HBM_ACHIEVABLE_TBPS * 1e9)) / ms_per_step,
+           'note': 'sum of the three bounds (no overlap assumed) over the measured ms_per_step; hbm_bytes = SURVEY.md 8(d) algorithmic bytes (no logits); '
+                   'hbm_bytes_moved_model adds what the step materialises around the vocabulary projection (logits written + read, dlogits written + read twice; '
+                   'split-K slabs not included); frac_r04_definition = the round-4 figure, whose HBM term counted one logits round trip as necessary'}
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r05_pmc.json')) as f:
+            rec = json.load(f)
+        if rec.get('step_hbm_bytes_measured') and rec.get('workload', '').startswith('cfg-B') and (E, H, L, T) == (250, 512, 1, 128):
+            out['hbm_bytes_measured_recorded'] = rec['step_hbm_bytes_measured']
+            out['hbm_bytes_measured_source'] = 'profiles/r05_pmc.json: sum over the kernels of one train step of FETCH_SIZE + WRITE_SIZE (separate --pmc passes), recorded -- not a measurement of this run'
+    except Exception:
+        pass
+    return out
+
+
+def other_configs(torch, device, log, steps=20, warmup=5):
+    """cfg-C, cfg-D's per-rank workload (20-way 1-shot, 100 rows), cfg-E (MAML-style step) and the reference's default dims for `steps`
+    train steps each, plus cfg-B in the SERIAL order (fsmg_config.schedule = single_stream: the fp32 XCD-local fused cell chip-wide,
+    the number the north star's >= 0.30 is about) with the cell kernels event-timed.  Each leg: value, ms_per_step, guard.ok,
+    roofline_step.frac."""
+    from fsmg.dist import EpisodeParallel
+    from models.lstm_baseline import LSTMBaseline
+    from models.maml_lstm import MAMLLSTM
+    legs = [(n, OTHER[n], {}) for n in ('cfg-C', 'cfg-D', 'cfg-E', 'ref-default')] + [('cfg-B-serial-order', (dict(CFG_B), 5, 5, 4), {'schedule': 'single_stream'})]
+    res = {}
+    for name, (base, N, K, Q), over in legs:
+        t_leg = time.perf_counter()
+        cfg = dict(base, device=device)
+        B, T = N * (K + Q), cfg['max_len']
+        maml = (cfg['inner_steps'], cfg['inner_lr']) if name == 'cfg-E' else None
+        pool = synthetic_episodes(32, N, K, Q, T, cfg['input_size'], seed=4321)
+        d_sup = torch.from_numpy(np.stack([s for s, _ in pool])).cuda()
+        d_qry = torch.from_numpy(np.stack([q for _, q in pool])).cuda()
+        ss, qs = d_sup[0].numel() * 4, d_qry[0].numel() * 4
+        m = (MAMLLSTM if maml else LSTMBaseline)(dict(cfg, max_sequences=B, **over))
+        m.recover_or_init('')
+        par, eng = EpisodeParallel(m), m.engine
+        kw = dict(maml=maml) if maml else {}
+
+        def step(i):
+            e = i % len(pool)
+            par.train_step(d_sup.data_ptr() + e * ss, d_qry.data_ptr() + e * qs, want_loss=False, shape=(N, K, Q), **kw)
+        s0 = eng.step
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        s1 = eng.step
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = eng.stats()
+        ms = 1e3 * dt / steps
+        r = {'value': steps / dt, 'unit': 'episodes/s', 'ms_per_step': ms, 'steps': steps, 'rows_per_episode': B,
+             'guard': {'ok': bool(eng.step - s1 == steps and s1 - s0 == warmup and st['timeouts'] == 0 and st['steps_skipped_timeout'] == 0
+                                  and st['steps_skipped_token_range'] == 0 and st['xov_selfcheck_mismatches'] == 0),
+                       'advanced_by': eng.step - s1, 'timeouts': st['timeouts'], 'persistent_path': bool(st['persistent_path'])}}
+        gf = algorithmic_gflop(cfg, B)
+        if not maml:
+            r['roofline_step'] = {'frac': step_roofline(cfg, B, gf, ms)['frac']}
+        if name == 'cfg-B-serial-order':          # the fused cell in the serial order: HIP events around its two launches per step
+            cell = {}
+            for cls in CELL_CLASSES:
+                eng.timing_select(cls); eng.timing_enable(True); eng.timing_reset()
+                for i in range(steps):
+                    step(i)
+                cell[cls] = eng.timing_read(cls)
+                eng.timing_enable(False)
+            tot_ms = sum(x for x, _ in cell.values())
+            ach = sum(gf[c] for c in cell) * steps / tot_ms
+            r['fused_cell'] = {'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+                               'bf16_split_kernels': bool(eng.debug_read('xcd_bx3', 1)[0]),
+                               'us_per_time_step': {c: 1e3 * cell[c][0] / (T * steps) for c in cell},
+                               'note': 'fp32 XCD-local kernels (k_lstm_fwd_xcd / k_lstm_bwd_xcd, v_mfma_f32_4x4x1) on the whole chip, serial order: '
+                                       'the north star\'s fused-cell fraction; the headline step runs the bf16-split chains packed on 3 XCDs beside the GEMMs (roofline)'}
+        r['leg_s'] = time.perf_counter() - t_leg
+        res[name] = r
+        log('other_configs: %s %.1f episodes/s (%.3f ms/step, guard %s)' % (name, r['value'], ms, r['guard']['ok']))
+        del m, par, eng, d_sup, d_qry
+    return res
 
 
 T_START = time.time()
@@ -203,11 +305,72 @@ def cpu_baseline(cfg, pool, shape, budget_s=18.0):
     except Exception as e:                                 # not built on this box: the torch variant stands alone
         log('cpu_baseline[cxx]: unavailable (%s)' % str(e)[:80])
     best = max(variants, key=lambda v: v['train_episodes_per_s'])
-    return {'value': best['train_episodes_per_s'], 'unit': 'episodes/s', 'cores': best['threads'], 'kind': 'port',
+    honest = None
+    try:
+        honest = cpu_honest_line(cfg, shape, variants[0], cores, avail, torch)
+    except Exception as e:                                 # noqa: BLE001 -- extra information only
+        log('cpu_baseline[honest line]: failed (%s)' % str(e)[:120])
+    return {'value': best['train_episodes_per_s'], 'unit': 'episodes/s', 'cores': best['threads'], 'kind': 'port', 'honest_line': honest,
             'cores_used': best['threads'], 'cores_available': avail, 'cores_of': '%d of %d' % (best['threads'], avail), 'variants': variants,
             'train_eps': n, 'eval_eps': ne, 'first_eval_nll': float(first_eval),
             'sample': '%d train + %d eval episodes of the same %d-way %d-shot workload (fp32 CPU restatement of the reference '
                       'graph, best of %s; %.1f s)' % (n, ne, shape[0], shape[1], '/'.join(v['name'] for v in variants), dt + de)}
+
+
+def host_peak_model(avail):
+    """fp32 peak of the host the CPU leg runs on, from what the OS says: physical cores x 64 FLOP/cycle (two 512-bit FMA pipes) x max clock.
+    A model (the inputs are reported), good to the factor that matters for `host_peak_frac`."""
+    import re
+    import subprocess
+    mhz, tpc, model = None, 1, ''
+    try:
+        txt = subprocess.run(['lscpu'], stdout=subprocess.PIPE, universal_newlines=True, timeout=10).stdout
+        m = re.search(r'CPU max MHz:\s*([0-9.]+)', txt) or re.search(r'CPU MHz:\s*([0-9.]+)', txt)
+        mhz = float(m.group(1)) if m else None
+        m = re.search(r'Thread\(s\) per core:\s*(\d+)', txt)
+        tpc = int(m.group(1)) if m else 1
+        m = re.search(r'Model name:\s*(.+)', txt)
+        model = m.group(1).strip() if m else ''
+    except Exception:                                      # noqa: BLE001
+        pass
+    if not mhz:
+        try:
+            mhz = max(float(l.split(':')[1]) for l in open('/proc/cpuinfo') if l.startswith('cpu MHz'))
+        except Exception:                                  # noqa: BLE001
+            mhz = 3000.0
+    cores = max(1, avail // max(tpc, 1))
+    return {'model': model, 'physical_cores_available': cores, 'threads_per_core': tpc, 'clock_mhz': mhz, 'flop_per_cycle_per_core': 64,
+            'peak_tflops': cores * 64 * mhz * 1e6 / 1e12}
+
+
+def cpu_honest_line(cfg, shape, torch_variant, cores, avail, torch):
+    """the CPU proxy is capped at 16 threads because the RECURRENCE stops scaling there -- but 77 % of the step's
+    FLOPs are the three contractions over the vocabulary (logits, dH, dW), which do scale.  Those three are timed alone at the
+    proxy's thread count and at every available core; `composed` = the measured step with its three big contractions re-priced at
+    all cores (an estimate of a per-op thread policy, labelled as such), and host_peak_frac says how far either is from the host."""
+    N, K, Q = shape
+    n, H, V1 = N * (K + Q) * cfg['max_len'], cfg['hidden_size'], cfg['input_size'] + 1
+    a = torch.randn(n, H); w = torch.randn(H, V1); g = torch.randn(n, V1)
+
+    def big3():
+        t0 = time.perf_counter()
+        for _ in range(2):
+            _ = a @ w; _ = g @ w.t(); _ = a.t() @ g
+        return (time.perf_counter() - t0) / 2
+    old = torch.get_num_threads()
+    torch.set_num_threads(cores); big3(); t_few = big3()
+    torch.set_num_threads(avail); big3(); t_all = big3()
+    torch.set_num_threads(old)
+    gflop3 = 3 * 2.0 * n * H * V1 / 1e9
+    t_step = 1.0 / torch_variant['train_episodes_per_s']
+    t_comp = max(t_step - t_few + t_all, 1e-9)
+    gf_step = 3 * 2.0 * n * ((cfg['embedding_size'] + H) * 4 * H + (cfg['n_layers'] - 1) * 2 * H * 4 * H + H * V1) / 1e9
+    peak = host_peak_model(avail)
+    return {'big3_gflop': gflop3, 'big3_s_at_%d_threads' % cores: t_few, 'big3_s_at_%d_threads' % avail: t_all,
+            'big3_tflops_all_cores': gflop3 / t_all / 1e3, 'step_s_measured_at_%d_threads' % cores: t_step,
+            'composed_episodes_per_s': 1.0 / t_comp, 'composed_note': 'measured torch-CPU step with its three vocabulary contractions re-priced at all cores (estimate)',
+            'host_peak': peak, 'host_peak_frac_measured': gf_step / t_step / 1e3 / peak['peak_tflops'],
+            'host_peak_frac_composed': gf_step / t_comp / 1e3 / peak['peak_tflops']}
 
 
 def self_launch(args):
@@ -255,6 +418,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true')
     ap.add_argument('--config', default='cfg-B', choices=['cfg-B', 'cfg-C', 'cfg-D', 'cfg-Bx4', 'cfg-Bx8', 'cfg-E', 'ref-default'])
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
@@ -588,7 +752,7 @@ def main():
                 'kernel': 'fused LSTM cell: %s + gate nonlinearities / gate gradients + state update, %d dependent time steps per launch)'
                           % (cell_kernel, int(steps_per_launch['lstm_fwd'])),
                 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
-                'traffic': hbm_traffic()[0], 'traffic_source': hbm_traffic()[1], 'launches': tot_n, 'avg_launch_ms': tot_ms / max(tot_n, 1),
+                'launches': tot_n, 'avg_launch_ms': tot_ms / max(tot_n, 1),
                 # what one launch has to move (per direction, mean of the two): forward reads Z and writes the four gates, c and h; backward reads
                 # gates, c and dH and writes dZ -- 4H + 4H + 2H floats per row and time step either way
                 'algorithmic_bytes_per_launch': 4.0 * B * T * 10 * cfg['hidden_size'] * cfg['n_layers'] / max(cell['lstm_fwd'][1] / max(args.steps, 1), 1),
@@ -613,6 +777,9 @@ def main():
                 xp = eng.debug_read('xcd_partitioned', 2)
             except Exception:                  # noqa: BLE001
                 xp = [0.0, 8.0]
+            variant = ('xcd16<4' if xp[0] else 'xcd16<2') if cell_bx3 else ('xcd<2' if cfg['hidden_size'] == 512 else None)
+            out['roofline']['traffic'], out['roofline']['traffic_source'] = hbm_traffic(variant)
+            out['roofline']['kernel_variant'] = variant
             if xp[0]:
                 # XCD-partitioned order: the chains run on a few XCDs BESIDE the projection / dW GEMMs, slower per step than alone on
                 # the whole chip -- by design.  Both ways of pricing them: against the whole chip's peak (frac) and against the peak
@@ -621,6 +788,14 @@ def main():
                 out['roofline'].update({'schedule': 'xcd_partitioned', 'xcds_occupied': nx,
                                         'frac_of_occupied_xcds_peak': ach / (PEAK_F32_MFMA_TFLOPS * nx / 8.0),
                                         'frac_bf16_split_of_occupied_xcds': ach / (PEAK_BX3_TFLOPS * nx / 8.0)})
+    if rank == 0 and world == 1 and args.config == 'cfg-B' and not args.no_other_configs:
+        # the other BASELINE.json configurations and the serial-order fused cell on the driver's record -- 20 steps
+        # each on fresh handles inside this run (one timed region between two synchronisations; a diagnostic, never the headline)
+        try:
+            out['other_configs'] = other_configs(torch, local, log)
+        except Exception as e:                 # noqa: BLE001
+            log('other_configs leg failed: %r' % (e,))
+            extras_failed['other_configs'] = repr(e)
     if rank == 0 and not maml:
         try:
             # the other half of BASELINE.json's metric: the validation path (query-only forward, batched 16 episodes

@@ -92,8 +92,12 @@ int backward(fsmg_model* h, int B, int part) {
     h->last_bwd_xcd = xcd;
     FillBatch fills(h);                     // embedding-gradient zero + the top layer's BPTT buffers: one launch
     OpBatch late(h);
+    OpBatch late2(h);                       // tail_aside: the bottom layer's weight-gradient sums, on the main stream behind the join
     OpBatch* const d_now = defer_ok ? &fills : nullptr;
     OpBatch* const d_late = defer_ok ? &late : nullptr;
+    // (eager passes only: a captured pass would have to join the auxiliary stream inside the graph; event timing wants one stream)
+    const bool aside = h->tail_aside && defer_ok && h->eager_call && h->aux != nullptr && !h->timing && !ov;
+    h->side_pending = false;
     if (part != 2) GEMMCK(fills.add(h->G + h->off_emb, 0u, (long long)h->V1 * h->Ep));
     if (ov) GEMMCK(fills.flush());          // (two-stream order: the auxiliary stream forks right below)
     if (part == 2) {
@@ -128,6 +132,33 @@ int backward(fsmg_model* h, int B, int part) {
         GEMMCK(dw_gemm(h, mainl, B, d_late));
     }
     if (part == 1 && cut && !cut_late) return fills.flush();
+    // the bandwidth-bound tail of the pass on stream `ts`: the deferred slab sums + the mean loss (one launch), the embedding gradient,
+    // the embedding-slice norm.  ts == aux: forked behind what has been issued on the main stream so far, joined by ev_side.
+    auto tail_kernels = [&](hipStream_t ts) -> int {
+        ScopedTimer tm(h, "embed_grad");
+        if (ts != s) {
+            HIPCK(h, hipEventRecord(h->ev_side_fork, s));
+            HIPCK(h, hipStreamWaitEvent(ts, h->ev_side_fork, 0));
+            late.s = ts;
+        }
+        // tail[1] = the mean loss of the pass: nobody reads it before the step's last kernels, so it rides with the slab sums (one
+        // block of a launch that keeps the rest of the chip busy) instead of costing a launch behind the cross entropy
+        const bool loss_in_batch = late.r.count > 0;
+        if (loss_in_batch) GEMMCK(late.mean(h->ce, rows, h->G + h->n_flat + 1));
+        GEMMCK(late.flush());
+        HIPCK(h, launch_embed_grad(ts, h->X, (int)rows, h->dXemb, h->Ep, h->G + h->off_emb, h->tok_first, h->tok_count));
+        h->tok_table_open = false;
+        const int nb = sqnorm_blocks(rows * h->Ep);
+        if (!dx_sq_done) HIPCK(h, launch_sqnorm_partials(ts, h->dXemb, rows * h->Ep, h->partials));
+        // tail[0] = squared norm of the embedding-slice gradients, tail[1] = mean loss of the pass, tail[2] / tail[3] = time-out /
+        // token-range indicators
+        HIPCK(h, launch_sum_partials(ts, h->partials, nb, h->G + h->n_flat + 0, h->d_err, loss_in_batch ? nullptr : h->ce, (int)rows, h->G + h->n_flat + 1));
+        if (ts != s) {
+            HIPCK(h, hipEventRecord(h->ev_side, ts));
+            h->side_pending = true;
+        }
+        return FSMG_OK;
+    };
     for (int l = h->L - 1; l >= 0; --l) {
         const bool top = l == h->L - 1;
         if (part == 2 && cut_late && l > 0) continue;                       // done in part 1
@@ -207,63 +238,70 @@ int backward(fsmg_model* h, int B, int part) {
         if (part == 1 && cut_late && l == 0) return FSMG_OK;                // bucket 0 travels beside what follows
         const int in_p = h->in_dim[l];
         PHASE(5);
-        {
-            ScopedTimer tm(h, "gemm_dk");
-            // dKx and dKh are one matrix of the flat gradient (the [in | h_prev] rows of `kernel_l`) and contract the same dZ over the
-            // same rows: where the 256 x 256-tile kernel takes the shape they are ONE GEMM with a two-part A (GemmArgs::m_split) --
-            // one K split and one set of slabs instead of two (cfg-B: 63 MB of slabs instead of 100), no 128-tile launch for dKx
-            GemmArgs m{};
-            if (l == 0) { m.A = h->P + h->off_emb; m.lda = h->Ep; m.gather = h->X; }
-            else { m.A = h->Hs[l - 1] + (size_t)B * Hp; m.lda = Hp; }
-            m.A2 = h->Hs[l]; m.lda2 = Hp; m.m_split = in_p;
-            m.B = h->Z[l]; m.ldb = G4; m.C = h->G + h->off_kx[l]; m.ldc = G4; m.M = in_p + Hp; m.N = G4; m.K = (int)rows;
-            m.colsum = h->G + h->off_b[l]; m.ksplit = 1;
-            const bool merged = h->merge_dk && in_p % 256 == 0 && Hp % 4 == 0 && h->off_kh[l] == h->off_kx[l] + (int64_t)in_p * G4 &&
-                                (l > 0 || 4LL * h->V1 * h->Ep < 0xfffff000LL) && 4LL * Hp * rows < 0xfffff000LL && 4LL * G4 * rows < 0xfffff000LL &&
-                                (((uintptr_t)m.A | (uintptr_t)m.A2 | (uintptr_t)m.B) & 15) == 0 && gemm_dma_enabled() && use_h_gemm(h, OP_XC, OP_XC, m, mainl);
-            if (merged) {
-                GEMMCK(gemm(h, mainl, OP_XC, OP_XC, m, d_late));
-            } else {
-            GemmArgs g{};                     // dKh = Hprev^T * dZ, db = colsum(dZ)
-            g.A = h->Hs[l]; g.lda = Hp; g.B = h->Z[l]; g.ldb = G4;
-            g.C = h->G + h->off_kh[l]; g.ldc = G4; g.M = Hp; g.N = G4; g.K = (int)rows;
-            g.colsum = h->G + h->off_b[l]; g.ksplit = 1;
-            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, g, d_late));
-            GemmArgs k{};                     // dKx = in^T * dZ
-            if (l == 0) { k.A = h->P + h->off_emb; k.lda = h->Ep; k.gather = h->X; }
-            else { k.A = h->Hs[l - 1] + (size_t)B * Hp; k.lda = Hp; }
-            k.B = h->Z[l]; k.ldb = G4; k.C = h->G + h->off_kx[l]; k.ldc = G4;
-            k.M = in_p; k.N = G4; k.K = (int)rows; k.ksplit = 1;
-            GEMMCK(gemm(h, mainl, OP_XC, OP_XC, k, d_late));
+        // dK_l (weight gradient) and dx_l (input gradient) contract the same dZ and do not depend on each other.  Layer 0 with the tail
+        // moved aside: dx first, so that its slab sum, the embedding gradient and the other deferred sums run on the auxiliary stream
+        // beside the dK GEMM (below); everywhere else dK first (the layer below waits for dx only).
+        OpBatch* const dk_defer = (aside && l == 0) ? &late2 : d_late;
+        auto dk_gemm = [&]() -> int {
+            {
+                ScopedTimer tm(h, "gemm_dk");
+                // dKx and dKh are one matrix of the flat gradient (the [in | h_prev] rows of `kernel_l`) and contract the same dZ over the
+                // same rows: where the 256 x 256-tile kernel takes the shape they are ONE GEMM with a two-part A (GemmArgs::m_split) --
+                // one K split and one set of slabs instead of two (cfg-B: 63 MB of slabs instead of 100), no 128-tile launch for dKx
+                GemmArgs m{};
+                if (l == 0) { m.A = h->P + h->off_emb; m.lda = h->Ep; m.gather = h->X; }
+                else { m.A = h->Hs[l - 1] + (size_t)B * Hp; m.lda = Hp; }
+                m.A2 = h->Hs[l]; m.lda2 = Hp; m.m_split = in_p;
+                m.B = h->Z[l]; m.ldb = G4; m.C = h->G + h->off_kx[l]; m.ldc = G4; m.M = in_p + Hp; m.N = G4; m.K = (int)rows;
+                m.colsum = h->G + h->off_b[l]; m.ksplit = 1;
+                const bool merged = h->merge_dk && in_p % 256 == 0 && Hp % 4 == 0 && h->off_kh[l] == h->off_kx[l] + (int64_t)in_p * G4 &&
+                                    (l > 0 || 4LL * h->V1 * h->Ep < 0xfffff000LL) && 4LL * Hp * rows < 0xfffff000LL && 4LL * G4 * rows < 0xfffff000LL &&
+                                    (((uintptr_t)m.A | (uintptr_t)m.A2 | (uintptr_t)m.B) & 15) == 0 && gemm_dma_enabled() && use_h_gemm(h, OP_XC, OP_XC, m, mainl);
+                if (merged) {
+                    GEMMCK(gemm(h, mainl, OP_XC, OP_XC, m, dk_defer));
+                } else {
+                GemmArgs g{};                     // dKh = Hprev^T * dZ, db = colsum(dZ)
+                g.A = h->Hs[l]; g.lda = Hp; g.B = h->Z[l]; g.ldb = G4;
+                g.C = h->G + h->off_kh[l]; g.ldc = G4; g.M = Hp; g.N = G4; g.K = (int)rows;
+                g.colsum = h->G + h->off_b[l]; g.ksplit = 1;
+                GEMMCK(gemm(h, mainl, OP_XC, OP_XC, g, dk_defer));
+                GemmArgs k{};                     // dKx = in^T * dZ
+                if (l == 0) { k.A = h->P + h->off_emb; k.lda = h->Ep; k.gather = h->X; }
+                else { k.A = h->Hs[l - 1] + (size_t)B * Hp; k.lda = Hp; }
+                k.B = h->Z[l]; k.ldb = G4; k.C = h->G + h->off_kx[l]; k.ldc = G4;
+                k.M = in_p; k.N = G4; k.K = (int)rows; k.ksplit = 1;
+                GEMMCK(gemm(h, mainl, OP_XC, OP_XC, k, dk_defer));
+                }
             }
-        }
-        {
-            ScopedTimer tm(h, "gemm_dx");     // d_in = dZ * Kx^T
-            GemmArgs g{};
-            g.A = h->Z[l]; g.lda = G4; g.B = h->P + h->off_kx[l]; g.ldb = G4;
-            g.C = (l == 0) ? h->dXemb : h->dH; g.ldc = in_p;
-            g.M = (int)rows; g.N = in_p; g.K = G4; g.ksplit = 1;
-            // layer 0: the sum rides with the weight gradients' and leaves the squared-norm partials of dXemb behind;
-            // above: the layer below reads dH next, the sum goes out with that layer's fills
-            if (l == 0) GEMMCK(gemm(h, mainl, OP_KC, OP_KC, g, d_late, h->partials, &dx_sq_done));
-            else GEMMCK(gemm(h, mainl, OP_KC, OP_KC, g, d_now));
+            return FSMG_OK;
+        };
+        auto dx_gemm = [&]() -> int {
+            {
+                ScopedTimer tm(h, "gemm_dx");     // d_in = dZ * Kx^T
+                GemmArgs g{};
+                g.A = h->Z[l]; g.lda = G4; g.B = h->P + h->off_kx[l]; g.ldb = G4;
+                g.C = (l == 0) ? h->dXemb : h->dH; g.ldc = in_p;
+                g.M = (int)rows; g.N = in_p; g.K = G4; g.ksplit = 1;
+                // layer 0: the sum rides with the weight gradients' and leaves the squared-norm partials of dXemb behind;
+                // above: the layer below reads dH next, the sum goes out with that layer's fills
+                if (l == 0) GEMMCK(gemm(h, mainl, OP_KC, OP_KC, g, d_late, h->partials, &dx_sq_done));
+                else GEMMCK(gemm(h, mainl, OP_KC, OP_KC, g, d_now));
+            }
+            return FSMG_OK;
+        };
+        if (aside && l == 0) {
+            GEMMCK(dx_gemm());
+            GEMMCK(tail_kernels(h->aux));
+            GEMMCK(dk_gemm());
+            HIPCK(h, hipStreamWaitEvent(s, h->ev_side, 0));
+            h->side_pending = false;
+            GEMMCK(late2.flush());
+        } else {
+            GEMMCK(dk_gemm());
+            GEMMCK(dx_gemm());
         }
     }
-    {
-        ScopedTimer tm(h, "embed_grad");
-        // tail[1] = the mean loss of the pass: nobody reads it before the step's last kernels, so it rides with the slab sums (one
-        // block of a launch that keeps the rest of the chip busy) instead of costing a launch behind the cross entropy
-        const bool loss_in_batch = late.r.count > 0;
-        if (loss_in_batch) GEMMCK(late.mean(h->ce, rows, h->G + h->n_flat + 1));
-        GEMMCK(late.flush());
-        HIPCK(h, launch_embed_grad(s, h->X, (int)rows, h->dXemb, h->Ep, h->G + h->off_emb, h->tok_first, h->tok_count));
-        h->tok_table_open = false;
-        const int nb = sqnorm_blocks(rows * h->Ep);
-        if (!dx_sq_done) HIPCK(h, launch_sqnorm_partials(s, h->dXemb, rows * h->Ep, h->partials));
-        // tail[0] = squared norm of the embedding-slice gradients, tail[1] = mean loss of the pass, tail[2] / tail[3] = time-out /
-        // token-range indicators
-        HIPCK(h, launch_sum_partials(s, h->partials, nb, h->G + h->n_flat + 0, h->d_err, loss_in_batch ? nullptr : h->ce, (int)rows, h->G + h->n_flat + 1));
-    }
+    if (!aside) GEMMCK(tail_kernels(s));
     if (ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));     // dW / dd landed
     PHASE(6);
     h->have_grads = true;

@@ -91,6 +91,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_EAGER")) h->eager = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_MERGE_DK")) h->merge_dk = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_UPD_SPLIT")) h->upd_split = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_TAIL_ASIDE")) h->tail_aside = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_INPLACE_DLOGITS")) h->inplace_dlogits = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XOV_SELFCHECK")) h->xov_selfcheck_left = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
@@ -133,6 +134,8 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
             hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_upd_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_side_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return bail(FSMG_ERR_HIP, "event create failed");
     }
     const int64_t sb = state_bytes_for(h->n_flat);
@@ -233,6 +236,8 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev_upd_fork) hipEventDestroy(h->ev_upd_fork);
     if (h->ev_upd) hipEventDestroy(h->ev_upd);
+    if (h->ev_side_fork) hipEventDestroy(h->ev_side_fork);
+    if (h->ev_side) hipEventDestroy(h->ev_side);
     comm_destroy(h);
     if (h->probe) { hipStreamSynchronize(h->probe); hipStreamDestroy(h->probe); }
     if (h->d_probe) hipFree(h->d_probe);
@@ -332,6 +337,7 @@ int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value) {
     else if (!std::strcmp(what, "persistent")) { h->persist = h->persist_cfg = value != 0; h->fallback_left = 0; }
     else if (!std::strcmp(what, "inplace_dlogits")) h->inplace_dlogits = value != 0;
     else if (!std::strcmp(what, "upd_split")) h->upd_split = value != 0;
+    else if (!std::strcmp(what, "tail_aside")) h->tail_aside = value != 0;
     else if (!std::strcmp(what, "xov_selfcheck")) h->xov_selfcheck_left = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (!std::strcmp(what, "xov_selfcheck_fault")) h->xov_selfcheck_fault = value != 0;
     else return fail(h, FSMG_ERR_NAME, std::string("unknown knob '") + what + "'");

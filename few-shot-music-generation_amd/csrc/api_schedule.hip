@@ -84,6 +84,10 @@ int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g, OpBatc
     // not deferred: this GEMM writes the lane's own slabs -- if a batch still holds a REDUCE over them (the XCD-partitioned order's
     // dW sums wait in `late`), that sum goes out first (an arena that is too small must not cost a gradient)
     if (!deferred && slabs == h->slabs && h->slabs_owner != nullptr) GEMMCK(h->slabs_owner->flush());
+    if (!deferred && slabs == h->slabs && h->side_pending) {       // ... or is going out on the auxiliary stream right now (backward(): tail_aside)
+        HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_side, 0));
+        h->side_pending = false;
+    }
     float* C = g.C; float* colsum = g.colsum;
     g.C = slabs; g.c_slab = mn; g.ksplit = S;
     if (colsum) { g.colsum = cslabs; g.colsum_slab = g.N; }

@@ -219,6 +219,13 @@ struct fsmg_model {
     // exceeds the 256 MB memory-side cache); fsmg_debug_read("logits") of a train pass then returns dlogits -- FSMG_INPLACE_DLOGITS=0
     // or fsmg_debug_set("inplace_dlogits", 0) keeps both
     bool inplace_dlogits = true;
+    // the bandwidth-bound tail of a backward pass -- the deferred slab sums (dW / dd, the upper layers' weight gradients, dx), the mean
+    // loss, k_embed_grad, the embedding-slice norm -- on the auxiliary stream BESIDE the bottom layer's weight-gradient GEMM, which is
+    // issued behind dx instead of in front of it (the two do not depend on each other); the main stream waits for it right behind that
+    // GEMM.  Same kernels on the same operands: same bits.  FSMG_TAIL_ASIDE=0 / fsmg_debug_set("tail_aside", 0): everything in line.
+    bool tail_aside = true;
+    bool side_pending = false;          // the auxiliary stream may still be reading the main lane's slabs (gemm() waits before it reuses them)
+    hipEvent_t ev_side_fork = nullptr, ev_side = nullptr;
     std::string err;
     bool timing = false;
     std::string timing_only;
@@ -348,7 +355,8 @@ int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g, OpBatc
 struct OpBatch {
     MultiOps r{};
     fsmg_model* h;
-    explicit OpBatch(fsmg_model* h_) : h(h_) { r.count = 0; }
+    hipStream_t s;                      // where flush() launches (the main stream unless the caller moves the batch aside)
+    explicit OpBatch(fsmg_model* h_) : h(h_), s(h_->stream) { r.count = 0; }
     ~OpBatch() { if (h->slabs_owner == this) h->slabs_owner = nullptr; }
     OpBatch(const OpBatch&) = delete;
     OpBatch& operator=(const OpBatch&) = delete;
@@ -378,7 +386,7 @@ struct OpBatch {
     int flush() {
         if (h->slabs_owner == this) h->slabs_owner = nullptr;      // the sums that were waiting for the main lane's slabs go out now
         if (r.count == 0) return FSMG_OK;
-        HIPCK(h, launch_multi_op(h->stream, r));
+        HIPCK(h, launch_multi_op(s, r));
         r.count = 0;
         return FSMG_OK;
     }

@@ -67,6 +67,20 @@ def evaluate(model, episode_sampler, n_episodes):
     return total / n_episodes
 
 
+def sharded_validate(model, sampler, n, rank=0, world=1, parallel=None):
+    """Mean NLL over exactly n fresh episodes of `sampler`'s stream (train.py:27-33 with the episodes dealt over the ranks).
+    The n episodes are dealt round-robin: rank r takes ceil((n - r) / world) of them, every rank contributes the SUM of its NLLs,
+    so the mean is over exactly n episodes whatever n % world is; a rank that got one episode fewer than the busiest rank skips
+    one position, so every rank's copy of the stream ends at the same place."""
+    mine = (n - rank + world - 1) // world if world > 1 else n
+    nll = evaluate(model, sampler, mine) if mine > 0 else 0.0
+    if world > 1 and mine < (n + world - 1) // world:
+        sampler.next_indices()          # keep every rank's copy of the stream at the same position
+    if world > 1 and parallel:
+        return parallel.mean_scalar(nll * mine) * world / n
+    return nll
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     rank = int(os.environ.get('RANK', '0'))
@@ -114,16 +128,7 @@ def main(argv=None):
     model.recover_or_init(args.init_dir)
 
     def validate(split, n):
-        # the n episodes are dealt round-robin to the ranks: rank r takes ceil((n - r) / world) of them, every rank contributes the
-        # SUM of its NLLs and its count, so the mean is over exactly n episodes whatever n % world is
-        mine = (n - rank + world - 1) // world if world > 1 else n
-        nll = evaluate(model, episode_sampler[split], mine) if mine > 0 else 0.0
-        if world > 1 and mine < (n + world - 1) // world:
-            episode_sampler[split].next_indices()          # keep every rank's copy of the stream at the same position
-        parallel = getattr(model, '_parallel', None)
-        if world > 1 and parallel:
-            return parallel.mean_scalar(nll * mine) * world / n
-        return nll
+        return sharded_validate(model, episode_sampler[split], n, rank, world, getattr(model, '_parallel', None))
 
     say('Iter: %d, val-nll: %.3e' % (0, validate('val', n_val)))
 

@@ -106,16 +106,17 @@ def test_rebuild_from_raw_text_reproduces_sidecars_and_vocab(tmp_path, golden_di
             assert (row[n:] == 0).all()
 
 
-def test_sharded_sampler_deals_one_stream_round_robin(dataset_root, golden_dir):
+@pytest.mark.parametrize('world', [2, 8])
+def test_sharded_sampler_deals_one_stream_round_robin(dataset_root, golden_dir, world):
     cfg = _cfg(dataset_root, 'train', 2, golden_dir)
     base = load_sampler_from_config(cfg)
-    want = [base.get_episode() for _ in range(6)]
-    for rank in range(2):
-        sh = ShardedEpisodeSampler(load_sampler_from_config(cfg), rank, 2)
+    want = [base.get_episode() for _ in range(3 * world)]
+    for rank in range(world):
+        sh = ShardedEpisodeSampler(load_sampler_from_config(cfg), rank, world)
         for step in range(3):
             ep = sh.get_episode()
-            np.testing.assert_array_equal(ep.support, want[step * 2 + rank].support)
-            np.testing.assert_array_equal(ep.query, want[step * 2 + rank].query)
+            np.testing.assert_array_equal(ep.support, want[step * world + rank].support)
+            np.testing.assert_array_equal(ep.query, want[step * world + rank].query)
         assert sh.get_num_unique_words() == 300
 
 

@@ -126,3 +126,98 @@ def test_single_process_group_is_a_passthrough():
     params = O.glorot_init(CFG, 5, np.float64)
     opt = O.new_opt_state(params)
     assert abs(par.train_step(sup, qry) - O.train_step(params, opt, sup, qry, CFG)) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# R = 8 (the north star is 8 ranks; nothing had exercised the host logic beyond world 2)
+class _TimeoutEngine(OracleEngine):
+    """OracleEngine + libfsmg's time-out contract: a rank whose (simulated) persistent kernel timed out raises tail[2]; after the
+    exchange EVERY rank sees the indicator, skips the update, reports it and has fallen back -- the driver repeats the step."""
+    def __init__(self, cfg, params, timeout_at=()):
+        super(_TimeoutEngine, self).__init__(cfg, params)
+        self.timeout_at, self.calls, self.skipped = set(timeout_at), 0, 0
+
+    def forward_backward(self, support, query, **kw):
+        super(_TimeoutEngine, self).forward_backward(support, query, **kw)
+        if self.calls in self.timeout_at:
+            self.grad_tensor[-self.TAIL + 2] = 1.0           # this rank's gradients are garbage
+            self.grad_tensor[:-self.TAIL] = float('nan')
+        self.calls += 1
+
+    def apply_update(self, grad_scale=1.0, want_loss=True):
+        if float(self.grad_tensor[-self.TAIL + 2]) != 0.0:
+            self.skipped += 1
+            raise RuntimeError('FSMG_ERR_HIP: persistent recurrent kernel timed out waiting for a peer block')
+        return super(_TimeoutEngine, self).apply_update(grad_scale, want_loss)
+
+
+class _StreamSampler(object):
+    """an episode stream whose items are their own position (what ShardedEpisodeSampler wraps)"""
+    def __init__(self):
+        self.pos = 0
+
+    def episode_indices(self):
+        self.pos += 1
+        return (self.pos - 1, None)
+
+    def gather(self, a, b):
+        return a
+
+
+class _PosModel(object):
+    def eval(self, episode):
+        return float(episode) ** 2 + 1.0
+
+
+def _worker8(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    'few-shot-music-generation_amd', 'src'))
+    from data.episode import ShardedEpisodeSampler
+    from fsmg.dist import EpisodeParallel
+    from train.train import sharded_validate
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), FSMG_DP_BUCKETS='1')
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    # (a) one stream dealt round-robin over 8, then 3 steps with a time-out raised on rank 5 in step 1: all 8 skip, all 8 repeat
+    eng = _TimeoutEngine(CFG, O.glorot_init(CFG, 5, np.float64), timeout_at=({1} if rank == 5 else ()))
+    par = EpisodeParallel(eng)
+    stream = O.synthetic_episodes(world * STEPS, N, K, Q, CFG['max_len'], CFG['input_size'], seed=13)
+    losses = [par.train_step(*stream[s * world + rank]) for s in range(STEPS)]
+    # (b) validation over n_val = 13 episodes (not divisible by 8), twice in a row: the stream copies must stay aligned
+    sh = ShardedEpisodeSampler(_StreamSampler(), rank, world)
+    v1 = sharded_validate(_PosModel(), sh, 13, rank, world, par)
+    v2 = sharded_validate(_PosModel(), sh, 13, rank, world, par)
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), losses=np.array(losses), skipped=eng.skipped, calls=eng.calls,
+             v1=v1, v2=v2, pos=sh.sampler.pos, **eng.params)
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_one_stream_timeout_on_one_rank_and_ragged_validation(tmp_path):
+    world = 8
+    port = free_port()
+    mp.spawn(_worker8, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in range(world)]
+    for r in rs[1:]:
+        np.testing.assert_array_equal(r['losses'], rs[0]['losses'])              # replicas see the same mean loss ...
+        for k in ('embedding', 'kernel_0', 'softmax_w'):
+            np.testing.assert_array_equal(r[k], rs[0][k])                        # ... and stay bit-identical
+    # the time-out of rank 5 in step 1 was seen by every rank (the indicator travels in the reduced tail): one skipped update each,
+    # one repeated forward_backward each, in lock-step
+    assert [int(r['skipped']) for r in rs] == [1] * world and [int(r['calls']) for r in rs] == [STEPS + 1] * world
+    # 8 ranks x 1 episode == 1 rank on the 8-episode batch, three steps (the repeated step included once)
+    params = O.glorot_init(CFG, 5, np.float64)
+    opt = O.new_opt_state(params)
+    stream = O.synthetic_episodes(world * STEPS, N, K, Q, CFG['max_len'], CFG['input_size'], seed=13)
+    for s in range(STEPS):
+        sup = np.concatenate([stream[s * world + r][0] for r in range(world)])
+        qry = np.concatenate([stream[s * world + r][1] for r in range(world)])
+        want = O.train_step(params, opt, sup, qry, CFG)
+        assert abs(rs[0]['losses'][s] - want) <= 1e-12 * abs(want)
+    for k, v in params.items():
+        np.testing.assert_allclose(rs[0][k], v, rtol=1e-10, atol=1e-14, err_msg=k)
+    # validation: the mean over EXACTLY the first 13 (then the next 13 after the alignment gap) stream positions
+    want1 = np.mean([p ** 2 + 1.0 for p in range(13)])
+    want2 = np.mean([p ** 2 + 1.0 for p in range(16, 29)])                      # every copy of the stream advanced by ceil(13 / 8) * 8 = 16
+    for r in rs:
+        assert abs(float(r['v1']) - want1) < 1e-9 and abs(float(r['v2']) - want2) < 1e-9
+        assert int(r['pos']) == 32

@@ -78,6 +78,7 @@ def test_forward_backward_every_tensor(over, N, K, Q, gemm_kind):
     loss, cache, grads, aux = cached_oracle_step(('shape', repr(sorted(over.items())), N, K, Q), params, sup, qry, cfg)
     B, T = N * (K + Q), cfg['max_len']
 
+    model.debug_set('inplace_dlogits', 0)      # keep the logits: by default the cross entropy writes dlogits over them
     model.forward_backward(sup, qry)
     tail = model.debug_read('tail', 16)
     assert abs(tail[1] - loss) <= NLL_RTOL * abs(loss)
@@ -1023,6 +1024,7 @@ def test_non_finite_weights_give_nan_with_the_bf16_split_and_inf_with_the_fp32_m
     sup, qry = _episode(cfg, 3, 2, 2, seed=5)
     B, T, V1 = 3 * 4, cfg['max_len'], cfg['input_size'] + 1
     clean = new_model(cfg)
+    clean.debug_set('inplace_dlogits', 0)
     clean.forward_backward(sup, qry)
     V1p = clean.debug_dims()['V1p']
     ref = clean.debug_read('logits', B * T * V1p).reshape(B * T, V1p)[:, :V1].copy()
@@ -1032,6 +1034,7 @@ def test_non_finite_weights_give_nan_with_the_bf16_split_and_inf_with_the_fp32_m
         w[:, 7] = 0.0
         w[3, 7] = bad                                   # column 7 of the logits = bad * h[:, 3] (+ bias)
         model.set_param('softmax_w', w)
+        model.debug_set('inplace_dlogits', 0)
         model.forward_backward(sup, qry)
         logits = model.debug_read('logits', B * T * V1p).reshape(B * T, V1p)[:, :V1]
         col = logits[:, 7]
@@ -1094,3 +1097,94 @@ def test_split_backward_cut_points_give_the_same_gradients_and_updates(layers, h
             assert m.apply_update(1.0) == want_l[i]
         for k in ref.param_shapes:
             np.testing.assert_array_equal(m.get_param(k), ref.get_param(k))
+
+
+@pytest.mark.parametrize('over,N,K,Q', [
+    (dict(hidden_size=64, embedding_size=16, input_size=130, max_len=7), 3, 2, 2),      # three-pass cross entropy kernel? no: register kernel, 6 float4 per thread
+    (dict(hidden_size=32, embedding_size=16, input_size=7000, max_len=4), 2, 2, 1),     # 12 float4 per thread
+    (dict(hidden_size=32, embedding_size=16, input_size=13000, max_len=3), 2, 1, 1),    # rows past 12 * 1024 floats: the three-pass kernel
+])
+def test_inplace_dlogits_gives_the_same_bits(over, N, K, Q):
+    """Round 5: a train pass's cross entropy writes dlogits over the logits it has just read (one buffer instead of two; default).
+    Every row is in registers (or re-read by the thread that overwrites it) before the first store: dlogits and every gradient
+    carry the same bits as with two buffers, for each of the three cross-entropy kernels."""
+    cfg = small_config(**over)
+    sup, qry = _episode(cfg, N, K, Q, seed=11)
+    a, b = new_model(cfg), new_model(cfg)
+    b.debug_set('inplace_dlogits', 0)
+    a.forward_backward(sup, qry); b.forward_backward(sup, qry)
+    d = a.debug_dims()
+    n = N * (K + Q) * d['T'] * d['V1p']
+    np.testing.assert_array_equal(a.debug_read('dlogits', n), b.debug_read('dlogits', n))
+    np.testing.assert_array_equal(a.debug_read('logits', n), a.debug_read('dlogits', n))          # one buffer
+    assert not np.array_equal(b.debug_read('logits', n), b.debug_read('dlogits', n))              # two
+    for name in a.param_shapes:
+        np.testing.assert_array_equal(a.get_grad(name), b.get_grad(name))
+    assert a.apply_update(1.0) == b.apply_update(1.0)
+
+
+def test_split_update_gives_the_same_bits_and_every_reader_waits_for_it():
+    """Round 5: clip + Adam of an eager pass is two launches -- [embedding .. LSTM layers] on the main stream, [softmax_w, softmax_b]
+    on the auxiliary stream beside the next step's input phase; the first publishes (go, clip scale, alpha), the second consumes
+    them.  Same arithmetic: parameters, moments and losses are bit-identical to the single launch over six steps, a parameter read
+    straight after a step sees the finished update (fsmg_host::begin_call settles the pending half), a step whose batch is
+    rejected (token out of range) skips BOTH halves, and the episode-parallel pair forward_backward / apply_update splits too."""
+    cfg = small_config(hidden_size=512, embedding_size=32, input_size=300, max_len=10)
+    eps = O.synthetic_episodes(6, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=51)
+    a, b = new_model(cfg, max_sequences=45), new_model(cfg, max_sequences=45)
+    b.debug_set('upd_split', 0)
+    for i, (s_, q_) in enumerate(eps):
+        if i == 3:                                  # the split forward_backward / apply_update pair in the middle
+            a.forward_backward(s_, q_); b.forward_backward(s_, q_)
+            assert a.apply_update(1.0) == b.apply_update(1.0)
+        else:
+            assert a.train_step(s_, q_) == b.train_step(s_, q_)
+        if i in (0, 4):                             # read straight behind the step: no explicit synchronisation in between
+            np.testing.assert_array_equal(a.get_param('softmax_w'), b.get_param('softmax_w'))
+    bad = eps[0][0].copy(); bad[0, 0, 0] = cfg['input_size'] + 5
+    before = a.get_param('softmax_b')
+    with pytest.raises(Exception, match='TOKEN_RANGE'):
+        a.train_step(bad, eps[0][1])
+    np.testing.assert_array_equal(a.get_param('softmax_b'), before)                # the rejected batch touched neither half
+    assert a.step == b.step == 6
+    pa, pb = a.get_params(), b.get_params()
+    for k in pa:
+        np.testing.assert_array_equal(pa[k], pb[k])
+    for k in pa:
+        (ma, va), (mb, vb) = a.get_opt_state(k), b.get_opt_state(k)
+        np.testing.assert_array_equal(ma, mb); np.testing.assert_array_equal(va, vb)
+    assert abs(a.eval_step(eps[0][1]) - b.eval_step(eps[0][1])) == 0.0
+
+
+def test_xov_selfcheck_passes_on_this_runtime_and_a_fault_parks_the_order(monkeypatch):
+    """the gated projection of the XCD-partitioned order reads rows another XCD wrote mid-kernel with ordinary
+    loads behind a relaxed poll -- correct only while no stale line of those rows sits in the consumer's L2, a property of the
+    runtime, and a violation would be silent.  The first passes of every handle therefore recompute the logits on the serial path
+    and compare the words (api_forward.hip xov_selfcheck).  Here: (1) on this ROCm / firmware the check passes -- zero differing
+    words, the order stays on; (2) a forced fault (the comparison runs against a buffer that is not the recomputed logits) skips
+    the step, repeats it, tallies the words, parks the order for the handle -- and the losses and parameters are those of a handle
+    that ran the serial order all along on the same kernels."""
+    monkeypatch.setenv('FSMG_XCD_OVERLAP', '1')
+    cfg = small_config(hidden_size=512, embedding_size=32, input_size=3000, max_len=32)
+    eps = O.synthetic_episodes(5, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=36)
+    a = new_model(cfg, max_sequences=45)
+    assert a.debug_read('xcd_partitioned', 2)[0] == 1.0
+    a.debug_set('xov_selfcheck', 3)
+    la = [a.train_step(*e) for e in eps[:3]]
+    st = a.stats()
+    assert st['xov_selfcheck_mismatches'] == 0 and st['timeouts'] == 0 and a.debug_read('xcd_partitioned', 3)[2] == 1.0
+    a.debug_set('xov_selfcheck', 1); a.debug_set('xov_selfcheck_fault', 1); a.debug_set('fallback_steps', 1)
+    la.append(a.train_step(*eps[3]))                 # skipped, repeated on per-step launches
+    st = a.stats()
+    assert st['xov_selfcheck_mismatches'] > 0 and st['steps_skipped_timeout'] == 1 and a.step == 4
+    assert a.debug_read('xcd_partitioned', 1)[0] == 0.0                         # parked
+    la.append(a.train_step(*eps[4]))
+    assert int(a.debug_read('xcd_partitioned', 3)[2]) == 0
+    monkeypatch.setenv('FSMG_XCD_OVERLAP', '0'); monkeypatch.setenv('FSMG_XCD_BX3', '1')
+    b = new_model(cfg, max_sequences=45)
+    lb = [b.train_step(*e) for e in eps[:3]]
+    b.debug_set('persistent', 0); lb.append(b.train_step(*eps[3])); b.debug_set('persistent', 1)
+    lb.append(b.train_step(*eps[4]))
+    # forward passes are bit-identical across the orders; dW's K split differs under the partitioned order: later losses to rounding
+    assert la[0] == lb[0]
+    np.testing.assert_allclose(la, lb, rtol=2e-6)

@@ -19,6 +19,7 @@ for r in range(reps):
         saved = m.get_params()
         m.train_step(*eps[0]); m.train_step(*eps[1])          # previous passes leave their data in every buffer ...
         for k, v in saved.items(): m.set_param(k, v)          # ... but the compared pass starts from identical parameters
+    m.debug_set('inplace_dlogits', 0)       # the comparison reads the logits
     m.forward_backward(*eps[0])
     d = m.debug_dims(); T, Hp, V1p = d['T'], d['Hp'], d['V1p']
     cur = {'h': m.debug_read('h0', (T + 1) * B * Hp).reshape(T + 1, B, Hp), 'c': m.debug_read('c0', (T + 1) * B * Hp).reshape(T + 1, B, Hp),

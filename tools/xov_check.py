@@ -21,6 +21,7 @@ out = {}
 for name, env in (('serial', {'FSMG_XCD_OVERLAP': '0'}), ('xov', {'FSMG_XCD_OVERLAP': '1', 'FSMG_XOV_PARTS': os.environ.get('PARTS', '1')})):
     os.environ.update(env)
     m = new_model(cfg)
+    m.debug_set('inplace_dlogits', 0)       # the comparison reads the logits: keep them (round 5: dlogits overwrite them by default)
     rec = []
     for s, q in eps:
         if os.environ.get('FUSED', '1') == '1':
