@@ -1173,7 +1173,7 @@ def test_xov_selfcheck_passes_on_this_runtime_and_a_fault_parks_the_order(monkey
     la = [a.train_step(*e) for e in eps[:3]]
     st = a.stats()
     assert st['xov_selfcheck_mismatches'] == 0 and st['timeouts'] == 0 and a.debug_read('xcd_partitioned', 3)[2] == 1.0
-    a.debug_set('xov_selfcheck', 1); a.debug_set('xov_selfcheck_fault', 1); a.debug_set('fallback_steps', 1)
+    a.debug_set('xov_selfcheck', 1); a.debug_set('xov_selfcheck_fault', 1); a.debug_set('fallback_steps', 2)
     la.append(a.train_step(*eps[3]))                 # skipped, repeated on per-step launches
     st = a.stats()
     assert st['xov_selfcheck_mismatches'] > 0 and st['steps_skipped_timeout'] == 1 and a.step == 4
