@@ -62,6 +62,7 @@ int backward(fsmg_model* h, int B, int part) {
     const bool rs = !xcd && h->persist && h->persist_bwd && h->inbox != nullptr && lstm_bwd_rs_supported(B, Hp) && lstm_bwd_rs_inbox_floats(B, Hp) <= h->inbox_floats;
     const bool chain = xcd || rs || (h->persist && h->persist_bwd && h->dzF_all != nullptr && lstm_bwd_chain_supported(B, Hp) &&
                               (int64_t)T * ((B + 15) / 16 * 16) * G4 <= h->dzfa_floats);
+    if (!xcd && h->cs_stale) return fail(h, FSMG_ERR_STATE, "internal: backward pass on the column-split kernels with stale fragment copies of K_h (ensure_cs not called)");
     const int nch = ov ? (chain ? h->nchunk_persist : h->nchunk) : 1;
     const Lane auxl = aux_lane(h, false, chain);
     // XCD-partitioned schedule: dW's tiles are claimed by the free XCDs while the top layer's chain runs, the rest after it

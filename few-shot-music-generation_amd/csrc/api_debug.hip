@@ -76,6 +76,7 @@ int fsmg_debug_step_profile(fsmg_handle h, int32_t which, uint64_t* stamps, int6
                             int32_t* n_waves) {
     if (!h || !stamps || !n_blocks || !n_waves || h->lastB <= 0 || h->T < 3) return FSMG_ERR_INVALID;
     BEGIN_CALL(h);
+    { const int rc_cs = ensure_cs(h); if (rc_cs != FSMG_OK) return rc_cs; }
     const int B = h->lastB, Hp = h->Hp, G4 = h->G4, l = h->L - 1, t = h->T / 2;
     const int nb = which == 0 ? (G4 / 16) * ((B + 15) / 16) : (Hp / 16) * ((B + 15) / 16);
     const int nw = which == 0 ? 4 : 8;

@@ -133,6 +133,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     const bool chain1 = !xcd && h->persist && h->persist_fwd && !h->force_fwd_rt && lstm_fwd_chain_supported(B, Hp);
     const bool chain_rt = !xcd && h->persist && h->persist_fwd && !chain1 && lstm_fwd_chain_rt_supported(B, Hp);   // all row tiles per block
     const bool chain = chain1 || chain_rt;
+    if (!xcd && h->cs_stale) return fail(h, FSMG_ERR_STATE, "internal: forward pass on the column-split kernels with stale fragment copies of K_h (ensure_cs not called)");
     const int nch_ov = ov ? ((chain || xcd) ? h->nchunk_persist : h->nchunk) : 1;
     // XCD-partitioned schedule: the chain packed on the first XCDs publishes the time steps it has finished, the projection's
     // row tiles are drawn by the other XCDs as their rows arrive (and by the whole chip once the chain is over)

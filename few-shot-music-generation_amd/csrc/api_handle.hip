@@ -92,6 +92,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_MERGE_DK")) h->merge_dk = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_UPD_SPLIT")) h->upd_split = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_TAIL_ASIDE")) h->tail_aside = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_LAZY_CS")) h->lazy_cs = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_INPLACE_DLOGITS")) h->inplace_dlogits = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XOV_SELFCHECK")) h->xov_selfcheck_left = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');

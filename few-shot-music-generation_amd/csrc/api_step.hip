@@ -32,6 +32,7 @@ int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&
     // a wait on an event recorded outside the graph
     if (!h->eager_call && (rc = settle_pending(h)) != FSMG_OK) return rc;
     if ((rc = ensure_khf(h)) != FSMG_OK) return rc;
+    if (pass_reads_cs(h, B, true) && (rc = ensure_cs(h)) != FSMG_OK) return rc;
     if (h->tok_table_open && (rc = reset_tok_table(h)) != FSMG_OK) return rc;     // a pass that never reached its embed_grad
     h->tok_table_open = true;
     if ((rc = stage()) != FSMG_OK) return rc;
@@ -342,6 +343,7 @@ int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, i
         const int ne = std::min(chunk_eps, n_episodes - e0);
         const int B = ne * per;
         choose_schedule(h, B);
+        if (pass_reads_cs(h, B, false) && (rc = ensure_cs(h)) != FSMG_OK) return rc;
         const int32_t* q = queries + (size_t)e0 * per * h->T;
         if ((rc = stage_tokens(h, q, 0, q, B, tokens_on_device)) != FSMG_OK) return rc;
         rc = run_graphed(h, "ev:" + std::to_string(per) + ":" + std::to_string(ne), [&]() -> int {

@@ -25,6 +25,13 @@ int repack_recurrent_weights(fsmg_model* h, hipStream_t s, const StepIncArgs* in
     if (h->L <= REPACK_MAX_LAYERS && x_ok) {
         RepackAllArgs a{};
         a.n = h->L; a.Hp = h->Hp; a.bx3 = h->xcd_bx3 ? 1 : 0;
+        // the XCD-local kernels are this handle's recurrence: the column-split copies wait until somebody needs them (ensure_cs)
+        // (never from inside a graph capture: a replay would not run this host code, and cs_stale would lie -- the repack that closes a
+        // train step, inc != nullptr, is the one that can be captured; run_graphed's bypass condition says when it is not)
+        const bool captured = inc != nullptr && h->cfg.use_graph && !(h->timing || h->ov_call || h->xov_call || h->eager_call);
+        const bool lazy = h->lazy_cs && h->khx != nullptr && h->persist && h->xcd && !captured;
+        a.mode = lazy ? 1 : 0;
+        h->cs_stale = lazy;
         for (int l = 0; l < h->L; ++l) {
             a.Kh[l] = h->P + h->off_kh[l];
             a.cf[l] = h->khf + (size_t)(2 * l) * h->Hp * h->G4; a.cb[l] = h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4;
@@ -35,6 +42,7 @@ int repack_recurrent_weights(fsmg_model* h, hipStream_t s, const StepIncArgs* in
         if (inc_done) *inc_done = inc != nullptr;
         return FSMG_OK;
     }
+    h->cs_stale = false;
     for (int l = 0; l < h->L; ++l) {
         HIPCK(h, launch_repack_kh(s, h->P + h->off_kh[l], h->khf + (size_t)(2 * l) * h->Hp * h->G4,
                                   h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4, h->Hp));
@@ -44,6 +52,19 @@ int repack_recurrent_weights(fsmg_model* h, hipStream_t s, const StepIncArgs* in
     return FSMG_OK;
 }
 int repack_recurrent_weights(fsmg_model* h, hipStream_t s) { return repack_recurrent_weights(h, s, nullptr, nullptr); }
+
+int ensure_cs(fsmg_model* h) {
+    if (!h->cs_stale) return FSMG_OK;
+    RepackAllArgs a{};
+    a.n = h->L; a.Hp = h->Hp; a.bx3 = h->xcd_bx3 ? 1 : 0; a.mode = 2;
+    for (int l = 0; l < h->L; ++l) {
+        a.Kh[l] = h->P + h->off_kh[l];
+        a.cf[l] = h->khf + (size_t)(2 * l) * h->Hp * h->G4; a.cb[l] = h->khf + (size_t)(2 * l + 1) * h->Hp * h->G4;
+    }
+    HIPCK(h, launch_repack_kh_all(h->stream, a, nullptr));
+    h->cs_stale = false;
+    return FSMG_OK;
+}
 
 int apply_update(fsmg_model* h, float grad_scale) {
     ScopedRange rng_("fsmg.clip+adam");

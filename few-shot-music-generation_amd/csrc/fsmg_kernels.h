@@ -224,7 +224,8 @@ hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, floa
 constexpr int REPACK_MAX_LAYERS = 4;
 struct StepIncArgs;
 struct RepackAllArgs { int n; int Hp; const float* Kh[REPACK_MAX_LAYERS]; float* cf[REPACK_MAX_LAYERS]; float* cb[REPACK_MAX_LAYERS]; float* xf[REPACK_MAX_LAYERS]; float* xb[REPACK_MAX_LAYERS];
-                       int bx3; /* hidden 512: the XCD images as three bf16 planes (k_lstm_*_xcd16) */ };
+                       int bx3; /* hidden 512: the XCD images as three bf16 planes (k_lstm_*_xcd16) */
+                       int mode; /* 0: both layouts, 1: the XCD / XCD-pair images only, 2: the column-split fragment copies only */ };
 // inc != nullptr: thread 0 of block (0, 0) also closes the train step (step_increment_body: the repack is the last kernel of a step)
 hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a, const StepIncArgs* inc = nullptr);
 hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a);

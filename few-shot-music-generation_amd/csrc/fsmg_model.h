@@ -130,6 +130,11 @@ struct fsmg_model {
     int ticket_next = 0;
     int64_t n_timeouts = 0, n_persist_launches = 0, n_xcd_launches = 0, n_step_launches = 0;   // fsmg_get_stats
     bool khf_dirty = true;              // host wrote parameters since the last repack
+    // the column-split fragment copies (khf) are read by the column-split / per-step kernels only: a handle whose passes take the
+    // XCD-local kernels refreshes just the register images behind an update and leaves khf STALE until a pass is about to read it
+    // (a big validation batch, the fallback after a time-out: ensure_cs(), api_update.hip) -- 45 -> ~17 us per update at hidden 1024
+    bool lazy_cs = true;                // FSMG_LAZY_CS=0: every repack refreshes both layouts
+    bool cs_stale = false;
     float* slabs = nullptr;             // split-K partial outputs of the GEMMs on the main stream
     float* arena = nullptr;             // slabs of the GEMMs whose sums are deferred into one launch (gemm(..., defer)): bump-allocated per pass
     int64_t arena_cap = 0, arena_off = 0;
@@ -509,6 +514,11 @@ int backward(fsmg_model* h, int B, int part = 0);
 int repack_recurrent_weights(fsmg_model* h, hipStream_t s, const StepIncArgs* inc, bool* inc_done);
 int repack_recurrent_weights(fsmg_model* h, hipStream_t s);
 int ensure_khf(fsmg_model* h);
+int ensure_cs(fsmg_model* h);           // the column-split copies of K_h are current (call OUTSIDE a graph capture, before a pass that reads them)
+// a pass over B sequences reads the column-split copies: its recurrence does not take the XCD-local kernels in some direction
+inline bool pass_reads_cs(const fsmg_model* h, int B, bool train) {
+    return !(use_xcd(h, B) && h->persist_fwd) || (train && !(use_xcd(h, B, true) && h->persist_bwd));
+}
 int apply_update(fsmg_model* h, float grad_scale);
 int sgd_update(fsmg_model* h, float lr);
 int save_theta(fsmg_model* h);

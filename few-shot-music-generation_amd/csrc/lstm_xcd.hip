@@ -2034,8 +2034,8 @@ __global__ void k_repack_kh_pair(const float* __restrict__ Kh, float* __restrict
 __global__ void k_repack_kh_all(const RepackAllArgs a, const StepIncArgs inc) {
     if (inc.step != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_increment_body(inc);
     const int l = blockIdx.y >> 1, kind = blockIdx.y & 1;
-    if (kind == 0) { repack_kh_chunked(a.Kh[l], a.cf[l], a.cb[l], a.Hp, blockIdx.x, gridDim.x); return; }
-    if (a.xf[l] == nullptr) return;
+    if (kind == 0) { if (a.mode != 1) repack_kh_chunked(a.Kh[l], a.cf[l], a.cb[l], a.Hp, blockIdx.x, gridDim.x); return; }
+    if (a.xf[l] == nullptr || a.mode == 2) return;
     if (a.Hp == SH) repack_kh_slice_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
     else if (a.Hp == PH) repack_kh_pair_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
     else if (a.bx3) repack_kh_xcd16_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);

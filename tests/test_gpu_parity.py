@@ -1188,3 +1188,29 @@ def test_xov_selfcheck_passes_on_this_runtime_and_a_fault_parks_the_order(monkey
     # forward passes are bit-identical across the orders; dW's K split differs under the partitioned order: later losses to rounding
     assert la[0] == lb[0]
     np.testing.assert_allclose(la, lb, rtol=2e-6)
+
+
+@pytest.mark.parametrize('hidden,layers', [(512, 1), (1024, 2)])
+def test_lazy_column_split_copies_are_refreshed_before_anybody_reads_them(hidden, layers, monkeypatch):
+    """Round 5: a handle whose passes take the XCD-local kernels refreshes only their register images behind an update; the
+    column-split fragment copies of K_h go stale until a pass is about to read them (ensure_cs): a validation batch too large for
+    the XCD-local kernels, the per-step fallback, a forced column-split run.  Against a handle that refreshes both layouts every
+    time (FSMG_LAZY_CS=0): the same bits everywhere."""
+    cfg = small_config(hidden_size=hidden, embedding_size=16, input_size=60, max_len=5, n_layers=layers)
+    eps = O.synthetic_episodes(5, 3, 2, 2, cfg['max_len'], cfg['input_size'], seed=61)
+    a = new_model(cfg)
+    monkeypatch.setenv('FSMG_LAZY_CS', '0')
+    b = new_model(cfg)
+    monkeypatch.delenv('FSMG_LAZY_CS')
+    for e in eps[:2]:
+        assert a.train_step(*e) == b.train_step(*e)
+    assert a.stats()['xcd_launches'] > 0
+    big = np.random.RandomState(3).randint(0, cfg['input_size'], size=(16, 3, 3, cfg['max_len'])).astype(np.int32)      # 144 rows per pass
+    np.testing.assert_array_equal(a.eval_batch(big), b.eval_batch(big))                  # per-step / column-split kernels read khf
+    assert a.train_step(*eps[2]) == b.train_step(*eps[2])                                # stale again behind this update ...
+    a.debug_set('persistent', 0); b.debug_set('persistent', 0)
+    assert a.train_step(*eps[3]) == b.train_step(*eps[3])                                # ... and read by the per-step kernels
+    a.debug_set('persistent', 1); b.debug_set('persistent', 1)
+    assert a.train_step(*eps[4]) == b.train_step(*eps[4])
+    for k, v in b.get_params().items():
+        np.testing.assert_array_equal(a.get_param(k), v)
