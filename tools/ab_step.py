@@ -61,8 +61,9 @@ def go(r, n):
 
 
 for r in runs:
-    go(r, 8)
-torch.cuda.synchronize()
+    go(r, 12)
+    torch.cuda.synchronize()          # (handles must never run side by side: persistent kernels of two handles time each other out)
+    r['m'].engine.synchronize()
 for rnd in range(args.rounds):
     for r in (runs if rnd % 2 == 0 else runs[::-1]):
         torch.cuda.synchronize()
@@ -76,6 +77,7 @@ for r in runs:
     med = ms[len(ms) // 2]
     ref = ref or med
     st = r['m'].engine.stats()
+    print('   rounds: ' + ' '.join('%.3f' % x for x in r['ms']))
     print('%-14s %.4f ms/step (min %.4f max %.4f)  %7.1f episodes/s  %+5.1f %% vs %s   steps %d timeouts %d skipped %d selfcheck %d  %s'
           % (r['name'], med, ms[0], ms[-1], 1e3 / med, 100.0 * (ref / med - 1.0), runs[0]['name'], r['m'].engine.step, st['timeouts'],
              st['steps_skipped_timeout'], st['xov_selfcheck_mismatches'], ' '.join('%s=%s' % kv for kv in sorted(r['env'].items()))))
