@@ -359,16 +359,21 @@ def cpu_honest_line(cfg, shape, torch_variant, cores, avail, torch):
         return (time.perf_counter() - t0) / 2
     old = torch.get_num_threads()
     torch.set_num_threads(cores); big3(); t_few = big3()
-    torch.set_num_threads(avail); big3(); t_all = big3()
+    scan = {}
+    for nt in sorted({min(avail, x) for x in (32, 64, 128, avail // 2, avail)} - {cores}):
+        torch.set_num_threads(nt); big3(); scan[nt] = big3()
     torch.set_num_threads(old)
+    scan[cores] = t_few
+    best_nt = min(scan, key=scan.get)
+    t_all = scan[best_nt]
     gflop3 = 3 * 2.0 * n * H * V1 / 1e9
     t_step = 1.0 / torch_variant['train_episodes_per_s']
     t_comp = max(t_step - t_few + t_all, 1e-9)
     gf_step = 3 * 2.0 * n * ((cfg['embedding_size'] + H) * 4 * H + (cfg['n_layers'] - 1) * 2 * H * 4 * H + H * V1) / 1e9
     peak = host_peak_model(avail)
-    return {'big3_gflop': gflop3, 'big3_s_at_%d_threads' % cores: t_few, 'big3_s_at_%d_threads' % avail: t_all,
-            'big3_tflops_all_cores': gflop3 / t_all / 1e3, 'step_s_measured_at_%d_threads' % cores: t_step,
-            'composed_episodes_per_s': 1.0 / t_comp, 'composed_note': 'measured torch-CPU step with its three vocabulary contractions re-priced at all cores (estimate)',
+    return {'big3_gflop': gflop3, 'big3_s_by_threads': {str(k): v for k, v in sorted(scan.items())}, 'big3_best_threads': best_nt,
+            'big3_tflops_best': gflop3 / t_all / 1e3, 'step_s_measured_at_%d_threads' % cores: t_step,
+            'composed_episodes_per_s': 1.0 / t_comp, 'composed_note': 'measured torch-CPU step with its three vocabulary contractions re-priced at their best thread count (estimate)',
             'host_peak': peak, 'host_peak_frac_measured': gf_step / t_step / 1e3 / peak['peak_tflops'],
             'host_peak_frac_composed': gf_step / t_comp / 1e3 / peak['peak_tflops']}
 

@@ -208,7 +208,10 @@ struct fsmg_model {
     // launch publishes (go, clip scale, alpha) in d_decided, the second consumes them -- it runs while k_step_increment moves the
     // step counter and clears the flags.  upd_pending: the second launch may still be in flight; settle_pending() orders the main
     // stream behind it (fsmg_host::begin_call does that for every entry point, forward() right before the first recurrent chain).
-    bool upd_split = true;              // FSMG_UPD_SPLIT=0: one launch on the main stream
+    // MEASURED AND REJECTED as a default (round 5, profiles/r05_ab_step_variants.txt, r05_step_timeline_upd_split.txt): the second
+    // launch hides its 27 us, but beside it token_prep takes 9.9 instead of 4.9 us, the x-part GEMM 56.9 instead of 45.6 us, and the
+    // wait in front of the first chain adds ~5 us: cfg-B -1.1 %, cfg-C -0.5 %, cfg-E -0.8 %, cfg-D +0.4 %, ref-default +0.4 %.
+    bool upd_split = false;             // FSMG_UPD_SPLIT=1 / fsmg_debug_set("upd_split", 1): two launches
     bool upd_pending = false;
     hipEvent_t ev_upd_fork = nullptr, ev_upd = nullptr;
     float* d_decided = nullptr;         // [4]: go (1 / 0), clip scale, alpha, unused

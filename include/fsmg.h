@@ -295,8 +295,10 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
  *                       recurrent kernels are issued eagerly (default)
  *   "inplace_dlogits"   1 (default): a train pass's cross entropy writes dlogits over the logits it has just read ("logits" then
  *                       reads back as dlogits after a train pass), 0: two buffers
- *   "upd_split"         1 (default): clip + Adam of an eager pass as two launches, the softmax half on the auxiliary stream beside
- *                       the next step's input phase (bit-identical), 0: one launch
+ *   "upd_split"         1: clip + Adam of an eager pass as two launches, the softmax half on the auxiliary stream beside the next
+ *                       step's input phase (bit-identical; measured slower), 0 (default): one launch
+ *   "tail_aside"        1 (default): the bandwidth-bound tail of an eager backward pass (deferred slab sums, embedding gradient) on
+ *                       the auxiliary stream beside the bottom layer's weight-gradient GEMM (bit-identical), 0: in line
  *   "xov_selfcheck"     XCD-partitioned order: the next `value` train passes recompute the gated projection on the serial path and
  *                       compare the words (default: the first 2 passes of a handle)
  *   "xov_selfcheck_fault" 1: the comparison runs against a buffer that is NOT the recomputed logits (tests of the recovery path)

@@ -1124,7 +1124,7 @@ def test_inplace_dlogits_gives_the_same_bits(over, N, K, Q):
 
 
 def test_split_update_gives_the_same_bits_and_every_reader_waits_for_it():
-    """Round 5: clip + Adam of an eager pass is two launches -- [embedding .. LSTM layers] on the main stream, [softmax_w, softmax_b]
+    """Round 5 (fsmg_debug_set("upd_split", 1)): clip + Adam of an eager pass as two launches -- [embedding .. LSTM layers] on the main stream, [softmax_w, softmax_b]
     on the auxiliary stream beside the next step's input phase; the first publishes (go, clip scale, alpha), the second consumes
     them.  Same arithmetic: parameters, moments and losses are bit-identical to the single launch over six steps, a parameter read
     straight after a step sees the finished update (fsmg_host::begin_call settles the pending half), a step whose batch is
@@ -1132,6 +1132,7 @@ def test_split_update_gives_the_same_bits_and_every_reader_waits_for_it():
     cfg = small_config(hidden_size=512, embedding_size=32, input_size=300, max_len=10)
     eps = O.synthetic_episodes(6, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=51)
     a, b = new_model(cfg, max_sequences=45), new_model(cfg, max_sequences=45)
+    a.debug_set('upd_split', 1)                     # (not the default: measured slower, DESIGN.md 10 -- kept as a knob, and kept correct)
     b.debug_set('upd_split', 0)
     for i, (s_, q_) in enumerate(eps):
         if i == 3:                                  # the split forward_backward / apply_update pair in the middle
