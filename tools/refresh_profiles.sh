@@ -1,68 +1,26 @@
 #!/bin/bash
 # Regenerates the round artefacts on the GPU box into gpurun_out/ (copy the ones to keep into profiles/).
-#   gpurun -- tools/refresh_profiles.sh [tag]
-TAG=${1:-r04}
-# every profiler invocation runs under `timeout`: in call 47 of round 4 a --pmc FETCH_SIZE pass never returned and spent the rest of the round's GPU budget
+#   gpurun -- 'bash tools/refresh_profiles.sh r05'
+# Every profiler invocation runs under `timeout` (round 4, call 47: a --pmc pass never returned); the counter passes live in
+# tools/pmc_passes.sh (one counter set per run, on the bare train loop).
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
-rm -rf /tmp/prof_st; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_st -o st -- python $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprofv3.json
+rm -rf /tmp/prof_st; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_st -o st -- python $R/bench.py --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprofv3.json
 python $R/tools/rocpd_stats.py $(find /tmp/prof_st -name "*.db" | head -1) > $O/${TAG}_bench_rocprofv3_kernel_stats.txt 2>&1
-python $R/tools/step_timeline.py $(find /tmp/prof_st -name "*.db" | head -1) 30 > $O/${TAG}_step_timeline.txt 2>&1
-# the hidden-1024 configurations (BASELINE.json configs[2], configs[4]) and cfg-D (100 rows: the bf16-split XCD-local recurrence): bench line, per-kernel statistics, device timeline
-for c in cfg-C cfg-E cfg-D; do
+python $R/tools/step_timeline.py $(find /tmp/prof_st -name "*.db" | head -1) 40 > $O/${TAG}_step_timeline.txt 2>&1
+# the other BASELINE.json configurations: bench line (un-profiled), per-kernel statistics and device timeline (profiled)
+for c in cfg-C cfg-E cfg-D ref-default; do
   t=$(echo $c | tr -d '-')
-  rm -rf /tmp/prof_$t; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$t -o st -- python $R/bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_${t}_bench_under_rocprofv3.json
-  python $R/tools/rocpd_stats.py $(find /tmp/prof_$t -name "*.db" | head -1) > $O/${TAG}_${t}_bench_rocprofv3_kernel_stats.txt 2>&1
-  python $R/tools/step_timeline.py $(find /tmp/prof_$t -name "*.db" | head -1) 30 > $O/${TAG}_${t}_step_timeline.txt 2>&1
-done
-# un-profiled bench lines of the diagnostic workloads
-for c in cfg-C cfg-E cfg-D cfg-Bx8; do
   python $R/bench.py --config $c --steps 40 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_$c.json
+  rm -rf /tmp/prof_$t; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$t -o st -- python $R/bench.py --config $c --steps 20 --warmup 6 --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > /dev/null
+  python $R/tools/rocpd_stats.py $(find /tmp/prof_$t -name "*.db" | head -1) > $O/${TAG}_${t}_rocprofv3_kernel_stats.txt 2>&1
+  python $R/tools/step_timeline.py $(find /tmp/prof_$t -name "*.db" | head -1) 40 > $O/${TAG}_${t}_step_timeline.txt 2>&1
 done
-# counters: separate passes (SQ block 8 slots; FETCH_SIZE and WRITE_SIZE do not fit one TCC pass), kernel-trace only
-for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
-  n=$(echo $set | cut -d' ' -f1)
-  rm -rf /tmp/prof_$n; timeout 600 rocprofv3 --pmc $set --kernel-trace -f csv -d /tmp/prof_$n -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-breakdown > /dev/null 2>&1
-  f=$(find /tmp/prof_$n -name "*counter_collection.csv" | head -1)
-  python $R/tools/pmc_summary.py $f > $O/${TAG}_pmc_$n.txt 2>&1
-  cp $f $O/${TAG}_pmc_$n.csv 2>/dev/null
-done
-python - $O $TAG <<'PY'
-import csv, json, sys, collections
-O, TAG = sys.argv[1], sys.argv[2]
-def means(counter):
-    agg = collections.defaultdict(list)
-    try:
-        for r in csv.DictReader(open('%s/%s_pmc_%s.csv' % (O, TAG, counter))):
-            if r['Counter_Name'] == counter and ('k_lstm_fwd_xcd' in r['Kernel_Name'] or 'k_lstm_bwd_xcd' in r['Kernel_Name']):
-                agg['fwd' if 'fwd' in r['Kernel_Name'] else 'bwd'].append(float(r['Counter_Value']))
-    except Exception as e:
-        print('no', counter, e)
-    return {k: sum(v) / len(v) for k, v in agg.items()}
-f, w = means('FETCH_SIZE'), means('WRITE_SIZE')
-# rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB.  The guide's gfx950 correction (FETCH_SIZE x 2) is calibrated for wide coalesced
-# streaming reads (16 B per lane) ONLY; these kernels read scattered 4-byte words (x-part / gates: 4 x 16 B per row and lane quad).
-# Calibration in their own access pattern: the forward kernel's only HBM read is Z, T*B*4H*4 B = 47.2 MB at cfg-B, and its RAW
-# FETCH_SIZE is 47.7 MB -> no correction applies here; WRITE_SIZE 85.5 MB = 47.2 (gates) + 23.6 (h, c) +
-# 16.8 (HX hand-off buffer, written through L2).
-out = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --steps 4 --warmup 2`, means per launch',
-       'correction': 'none: raw FETCH_SIZE of k_lstm_fwd_xcd equals its algorithmic read (Z, 47.2 MB at cfg-B); the x2 of the guide is for 16-B/lane streaming loads',
-       'fetch_size_kb': f, 'write_size_kb': w}
-if f and w:
-    per = {k: f[k] * 1024 + w.get(k, 0.0) * 1024 for k in f}
-    out['traffic_bytes_per_launch_by_kernel'] = per
-    out['traffic_bytes_per_launch'] = sum(per.values()) / max(len(per), 1)
-json.dump(out, open('%s/%s_lstm_cell_pmc.json' % (O, TAG), 'w'), indent=1)
-print(json.dumps(out))
-PY
-# round 4: the reference's own default dims, the serial order beside the partitioned one (same box), ref-default timeline
-cd /tmp
-python $R/bench.py --config ref-default --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_ref-default.json
-FSMG_HP_ALIGN=16 python $R/bench.py --config ref-default --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_ref-default_hp208.json
-FSMG_XCD_OVERLAP=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_serial_order.json
-rm -rf /tmp/prof_ser; FSMG_XCD_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_ser -o st -- python $R/bench.py --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > /dev/null
-python $R/tools/step_timeline.py $(find /tmp/prof_ser -name "*.db" | head -1) 150 > $O/${TAG}_step_timeline_serial_order.txt 2>&1
-rm -rf /tmp/prof_rd; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_rd -o st -- python $R/bench.py --config ref-default --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > /dev/null
-python $R/tools/step_timeline.py $(find /tmp/prof_rd -name "*.db" | head -1) 150 > $O/${TAG}_refdefault_step_timeline.txt 2>&1
-python $R/tools/rocpd_stats.py $(find /tmp/prof_rd -name "*.db" | head -1) > $O/${TAG}_refdefault_rocprofv3_kernel_stats.txt 2>&1
+python $R/bench.py --config cfg-Bx8 --steps 40 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_cfg-Bx8.json
+# the serial order beside the partitioned one (same box)
+FSMG_XCD_OVERLAP=0 python $R/bench.py --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 > $O/${TAG}_bench_serial_order.json
+# N > 1 dry run on ONE GPU over gloo (launcher, exchange schedules, guards; the numbers mean nothing: four processes share the chip)
+FSMG_BENCH_SAME_GPU=1 FSMG_BENCH_REPEATS=2 timeout 600 python $R/bench.py --gpus 4 --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_same_gpu_4ranks.json 2> $O/${TAG}_bench_same_gpu_4ranks.err
+bash $R/tools/pmc_passes.sh $TAG
