@@ -141,11 +141,11 @@ int save_theta(fsmg_model* h) {
         if (hipMalloc((void**)&h->P_saved, sizeof(float) * (size_t)h->n_flat) != hipSuccess)
             return fail(h, FSMG_ERR_NOMEM, "hipMalloc(saved parameters) failed");
     }
-    HIPCK(h, hipMemcpyAsync(h->P_saved, h->P, sizeof(float) * (size_t)h->n_flat, hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, launch_copy_words(h->stream, h->P_saved, h->P, h->n_flat));        // (n_flat is a multiple of FLAT_ALIGN = 64 floats)
     return FSMG_OK;
 }
 int restore_theta(fsmg_model* h) {
-    HIPCK(h, hipMemcpyAsync(h->P, h->P_saved, sizeof(float) * (size_t)h->n_flat, hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, launch_copy_words(h->stream, h->P, h->P_saved, h->n_flat));
     h->khf_dirty = true;
     return ensure_khf(h);
 }

@@ -607,6 +607,10 @@ __global__ void k_clock_probe(long long ticks, unsigned long long* out) {
     if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
 }
 
+__global__ __launch_bounds__(256) void k_copy_words(uint4* __restrict__ dst, const uint4* __restrict__ src, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
 // Self-check of the XCD-partitioned order (api_forward.hip: xov_selfcheck): the logits of the gated work-queue projection against the same
 // GEMM recomputed behind the chain, word for word.  A difference is counted per wave (one system-scope atomic) and raises the flag.
 __global__ __launch_bounds__(256) void k_compare_words(const uint4* __restrict__ a, const uint4* __restrict__ b, long long n4, int* err_flag,
@@ -881,6 +885,12 @@ hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, flo
 
 hipError_t launch_clock_probe(hipStream_t s, long long realtime_ticks, unsigned long long* out) {
     hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, realtime_ticks, out);
+    return hipGetLastError();
+}
+hipError_t launch_copy_words(hipStream_t s, void* dst, const void* src, long long n_words) {
+    const long long n4 = n_words >> 2;
+    if (n4 <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_words, dim3((int)std::min<long long>((n4 + 255) / 256, 4096)), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, n4);
     return hipGetLastError();
 }
 hipError_t launch_compare_words(hipStream_t s, const void* a, const void* b, long long n_words, int* err_flag, long long* counter) {
