@@ -93,6 +93,8 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_UPD_SPLIT")) h->upd_split = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_TAIL_ASIDE")) h->tail_aside = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_LAZY_CS")) h->lazy_cs = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_CE_TAIL")) h->ce_tail = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_CE_TAIL_BLOCKS")) h->ce_tail_blocks = std::max(1, std::min(4096, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_INPLACE_DLOGITS")) h->inplace_dlogits = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XOV_SELFCHECK")) h->xov_selfcheck_left = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
@@ -128,6 +130,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         int least = 0, greatest = 0;
         hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, least) != hipSuccess) return bail(FSMG_ERR_HIP, "aux stream create failed");
+        if (hipStreamCreateWithPriority(&h->aux2, hipStreamNonBlocking, least) != hipSuccess) return bail(FSMG_ERR_HIP, "aux2 stream create failed");
         for (int c = 0; c < fsmg_model::NCHUNK; ++c)
             if (hipEventCreateWithFlags(&h->ev_chunk[c], hipEventDisableTiming) != hipSuccess) return bail(FSMG_ERR_HIP, "event create failed");
         if (hipEventCreateWithFlags(&h->ev_bucket[0], hipEventDisableTiming) != hipSuccess ||
@@ -137,6 +140,8 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
             hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_side_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_ce_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_ce, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return bail(FSMG_ERR_HIP, "event create failed");
     }
     const int64_t sb = state_bytes_for(h->n_flat);
@@ -156,7 +161,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     const size_t tok_words = (size_t)round_up(h->V1, 64);
     const size_t prog_words = (size_t)round_up(h->T + 8, 64);
     const size_t small_bytes = 256 * 4 + sizeof(float) * RING_CAP + sizeof(int) * 8 * fsmg_model::TICKET_LAUNCHES + sizeof(int) * 2 * fsmg_model::XOV_CTL +
-                               sizeof(int) * 2 * tok_words + sizeof(int) * prog_words;
+                               sizeof(int) * 2 * tok_words + sizeof(int) * prog_words + sizeof(int) * fsmg_model::XOV_DONE;
     if (hipMalloc((void**)&small, small_bytes) != hipSuccess) return bail(FSMG_ERR_NOMEM, "hipMalloc(scalars) failed");
     hipMemsetAsync(small, 0, small_bytes, h->stream);
     h->d_step = (long long*)small; h->d_err = (int*)(small + 256); h->d_gnorm = (float*)(small + 512);
@@ -172,6 +177,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
     h->xov_ctl = h->tickets + 8 * fsmg_model::TICKET_LAUNCHES;
     h->tok_first = h->xov_ctl + 2 * fsmg_model::XOV_CTL; h->tok_count = h->tok_first + tok_words;
     h->xov_prog = h->tok_count + tok_words;
+    h->xov_done = h->xov_prog + prog_words;
     if (reset_tok_table(h) != FSMG_OK) return bail(FSMG_ERR_HIP, "fill of the token occurrence table failed");
 
     // decode scratch: per layer h ping/pong + c, plus x and argmax block scratch
@@ -239,9 +245,12 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->ev_upd) hipEventDestroy(h->ev_upd);
     if (h->ev_side_fork) hipEventDestroy(h->ev_side_fork);
     if (h->ev_side) hipEventDestroy(h->ev_side);
+    if (h->ev_ce_fork) hipEventDestroy(h->ev_ce_fork);
+    if (h->ev_ce) hipEventDestroy(h->ev_ce);
     comm_destroy(h);
     if (h->probe) { hipStreamSynchronize(h->probe); hipStreamDestroy(h->probe); }
     if (h->d_probe) hipFree(h->d_probe);
+    if (h->aux2) { hipStreamSynchronize(h->aux2); hipStreamDestroy(h->aux2); }
     if (h->aux) hipStreamDestroy(h->aux);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -332,6 +341,7 @@ int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value) {
     BEGIN_CALL(h);
     HIPCK(h, hipStreamSynchronize(h->stream));
     if (h->aux) HIPCK(h, hipStreamSynchronize(h->aux));
+    if (h->aux2) HIPCK(h, hipStreamSynchronize(h->aux2));
     if (!std::strcmp(what, "chain_spin_limit")) h->chain_spin_limit = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (!std::strcmp(what, "fallback_steps")) h->fallback_steps = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 30));
     else if (!std::strcmp(what, "eager")) h->eager = value != 0;
@@ -339,6 +349,7 @@ int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value) {
     else if (!std::strcmp(what, "inplace_dlogits")) h->inplace_dlogits = value != 0;
     else if (!std::strcmp(what, "upd_split")) h->upd_split = value != 0;
     else if (!std::strcmp(what, "tail_aside")) h->tail_aside = value != 0;
+    else if (!std::strcmp(what, "ce_tail")) h->ce_tail = value != 0;
     else if (!std::strcmp(what, "xov_selfcheck")) h->xov_selfcheck_left = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (!std::strcmp(what, "xov_selfcheck_fault")) h->xov_selfcheck_fault = value != 0;
     else return fail(h, FSMG_ERR_NAME, std::string("unknown knob '") + what + "'");

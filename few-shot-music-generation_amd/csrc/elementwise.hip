@@ -282,12 +282,11 @@ __global__ __launch_bounds__(256) void k_ce_rows(const float* logits, int ld, in
 // exp() is evaluated once per element, and the gradient is written from registers -- the three-pass kernel above
 // re-reads 40 KB rows that have long left the L2 when thousands of rows are in flight (0.141 -> see DESIGN.md).
 // softmax = exp(x - max) / sum instead of exp(x - lse): the same value to ~1 ulp.
+// one row of the register-resident cross entropy, by the 256 threads of a block (sh: 8 floats of LDS; two block barriers inside)
 template <int NV, bool NT>
-__global__ __launch_bounds__(256) void k_ce_rows_reg(const float* logits, int ld, int n_vocab,
-                                                     const int* __restrict__ tgt, float* __restrict__ lse,
-                                                     float* __restrict__ ce, float* dlogits, float inv_n) {     // dlogits may be logits: the whole row is in registers behind the barriers
-    __shared__ float sh[8];
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void ce_row_reg(float* sh, const int r, const float* logits, int ld, int n_vocab, const int* __restrict__ tgt,
+                                           float* __restrict__ lse, float* __restrict__ ce, float* dlogits, float inv_n) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = logits + (long long)r * ld;
     float4 x[NV];
     float m = -INFINITY;
@@ -345,6 +344,55 @@ __global__ __launch_bounds__(256) void k_ce_rows_reg(const float* logits, int ld
                 *reinterpret_cast<float4*>(drow + v) = d;
             }
         }
+    }
+}
+
+template <int NV, bool NT>
+__global__ __launch_bounds__(256) void k_ce_rows_reg(const float* logits, int ld, int n_vocab,
+                                                     const int* __restrict__ tgt, float* __restrict__ lse,
+                                                     float* __restrict__ ce, float* dlogits, float inv_n) {     // dlogits may be logits: the whole row is in registers behind the barriers
+    __shared__ float sh[8];
+    ce_row_reg<NV, NT>(sh, blockIdx.x, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+}
+
+// The same rows by a PERSISTENT grid (every block draws the next row from *next_row, zeroed by the caller: rows are taken in increasing
+// order by whichever blocks have found a CU -- blocks the dispatcher cannot place yet cost nothing) whose rows are still being written
+// by the work-queue projection on other CUs (the XCD-partitioned order: the cross entropy under the forward pair's tail).
+// done[row / tile_rows] reaches done_expect when every column tile of that row tile has been stored AND released at agent scope
+// (k_gemm_bx3h<.., QUEUE>: GemmArgs::done); one thread polls, the block barrier orders the other waves' loads behind it.  A row tile
+// is 256 rows = a multiple of 1 KiB of any leading dimension, so no cache line is shared between a complete tile and one still
+// being written; the lines are read with ordinary loads -- this kernel's launch invalidated the L2s, and a line is touched only
+// behind its tile's counter.  Bounded like every spin of the library: after spin_cap polls (or when somebody else has raised the
+// flag) *err_flag = 2 and the block leaves -- the step is skipped and repeated like any timed-out step.
+template <int NV, bool NT>
+__global__ __launch_bounds__(256) void k_ce_rows_gated(const float* logits, int ld, int rows, int n_vocab, const int* __restrict__ tgt,
+                                                       float* __restrict__ lse, float* __restrict__ ce, float* dlogits, float inv_n,
+                                                       const int* done, int done_expect, int tile_rows, int* err_flag, int spin_cap, int* next_row) {
+    __shared__ float sh[8];
+    __shared__ int s_row;
+    int have = -1;                                       // the row tile this block has already seen complete
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int r = atomicAdd(next_row, 1);
+            if (r < rows && r / tile_rows != have) {
+                for (int spins = 0; __hip_atomic_load(done + r / tile_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < done_expect; ++spins) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (spins >= spin_cap || ((spins & 63) == 63 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) {
+                        __hip_atomic_store(err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        r = rows;                        // give up: the step is skipped
+                        break;
+                    }
+                }
+            }
+            s_row = r;
+        }
+        __syncthreads();
+        const int r = s_row;
+        __syncthreads();
+        if (r >= rows) return;
+        have = r / tile_rows;
+        ce_row_reg<NV, NT>(sh, r, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+        __syncthreads();                                 // sh is reused by the next row
     }
 }
 
@@ -785,6 +833,16 @@ hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, 
         else hipLaunchKernelGGL((k_ce_rows_reg<12, false>), dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
     }
     else hipLaunchKernelGGL(k_ce_rows, dim3(rows), dim3(256), 0, s, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
+    return hipGetLastError();
+}
+
+hipError_t launch_ce_rows_gated(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt, float* lse, float* ce,
+                                float* dlogits, float inv_n, const int* done, int done_expect, int tile_rows, int* err_flag, int spin_cap, int blocks, int* next_row) {
+    if (rows <= 0) return hipSuccess;
+    if (ld > 12 * 1024 || done == nullptr || err_flag == nullptr || next_row == nullptr || blocks <= 0) return hipErrorInvalidValue;
+    blocks = std::min(blocks, rows);
+    if (ld <= 6 * 1024) hipLaunchKernelGGL((k_ce_rows_gated<6, true>), dim3(blocks), dim3(256), 0, s, logits, ld, rows, n_vocab, tgt, lse, ce, dlogits, inv_n, done, done_expect, tile_rows, err_flag, spin_cap, next_row);
+    else hipLaunchKernelGGL((k_ce_rows_gated<12, true>), dim3(blocks), dim3(256), 0, s, logits, ld, rows, n_vocab, tgt, lse, ce, dlogits, inv_n, done, done_expect, tile_rows, err_flag, spin_cap, next_row);
     return hipGetLastError();
 }
 

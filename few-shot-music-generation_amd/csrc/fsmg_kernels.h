@@ -55,6 +55,10 @@ struct GemmArgs {
     // the columns of A -- K rows gathered through `gather` when it is set (the caller guarantees the gathered table < 4 GiB) --,
     // rows [m_split, M) the columns of A2 (never gathered).  m_split is a multiple of 256.
     const float* A2; int lda2; int m_split;
+    // Work-queue launches of the 256 x 256-tile kernel: done != nullptr -> a block that has stored its tile releases it at agent scope and
+    // adds 1 to done[row tile] (zeroed by the caller): what a consumer on other CUs gates the rows of that row tile on
+    // (launch_ce_rows_gated: the cross entropy under the forward pair's tail)
+    int* done;
 };
 // amode/bmode in {OP_KC, OP_XC}. Supported combinations: (KC,XC) (XC,XC) (KC,KC)
 hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, int lds_pad = 0);
@@ -264,6 +268,11 @@ hipError_t launch_token_prep(hipStream_t s, const int* support, int n_support, c
 // (softmax - onehot) * inv_n (pad columns zero) for the backward projection GEMMs
 hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt,
                           float* lse, float* ce, float* dlogits, float inv_n);
+// the same rows (register-resident kernels only: ld <= 12288) by a persistent grid of `blocks` blocks, each row behind the completion
+// counter of its row tile: done[row / tile_rows] >= done_expect (GemmArgs::done of the work-queue projection that is still running)
+hipError_t launch_ce_rows_gated(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt, float* lse, float* ce,
+                                float* dlogits, float inv_n, const int* done, int done_expect, int tile_rows, int* err_flag, int spin_cap, int blocks,
+                                int* next_row /* one int, zero before the launch: the rows are drawn from it */);
 // rows x nparts softmax partials (see GemmArgs::ce_part) -> ce[row] = logsumexp - target logit
 hipError_t launch_ce_combine(hipStream_t s, const float2* part, int nparts, const float* tgt_logit, int rows, float* ce);
 // out[g] = sum over t and b in group g of ce[t*B+b] / (T*rows_per_group + 1e-12); fixed order

@@ -231,6 +231,17 @@ struct fsmg_model {
     // loss, k_embed_grad, the embedding-slice norm -- on the auxiliary stream BESIDE the bottom layer's weight-gradient GEMM, which is
     // issued behind dx instead of in front of it (the two do not depend on each other); the main stream waits for it right behind that
     // GEMM.  Same kernels on the same operands: same bits.  FSMG_TAIL_ASIDE=0 / fsmg_debug_set("tail_aside", 0): everything in line.
+    // XCD-partitioned order: the cross entropy UNDER the forward pair's tail.  Every work-queue tile of the projection releases its
+    // stores and counts itself in xov_done[row tile]; the cross entropy is a persistent grid (one block per CU, rows in increasing
+    // order) on a third stream that starts when the chain is over and takes each row behind its row tile's counter -- instead of
+    // waiting ~100 us for the last tiles with half of the CUs idle and then streaming 460 MB alone.  FSMG_CE_TAIL=0/1,
+    // fsmg_debug_set("ce_tail").  Passes that run the self-check keep the in-line cross entropy (it compares the logits first).
+    bool ce_tail = false;
+    int ce_tail_blocks = 256;           // FSMG_CE_TAIL_BLOCKS
+    hipStream_t aux2 = nullptr;
+    hipEvent_t ev_ce_fork = nullptr, ev_ce = nullptr;
+    int* xov_done = nullptr;            // [XOV_DONE] completion counters of the projection's row tiles (GemmArgs::done)
+    static constexpr int XOV_DONE = 256;
     bool tail_aside = true;
     bool side_pending = false;          // the auxiliary stream may still be reading the main lane's slabs (gemm() waits before it reuses them)
     hipEvent_t ev_side_fork = nullptr, ev_side = nullptr;

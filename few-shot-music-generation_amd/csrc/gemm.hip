@@ -1332,6 +1332,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
         f32x16 (&sub)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * h2][0]);
         store_tile_at(g, sub, ep, z, m0 + wm * 128 + h2 * 64, n0 + wn * 64, (n0 + wn * 64) / 128, (g.N + 127) / 128, wn & 1, lane);
     }
+    if constexpr (QUEUE) {
+        if (g.done != nullptr) {            // the tile is complete: release every wave's stores at agent scope, then count it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            bx_barrier();
+            if (tid == 0) __hip_atomic_fetch_add(g.done + tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (PROF && g.prof != nullptr && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long p_end = __builtin_amdgcn_s_memtime();
