@@ -55,8 +55,8 @@ struct GemmArgs {
     // the columns of A -- K rows gathered through `gather` when it is set (the caller guarantees the gathered table < 4 GiB) --,
     // rows [m_split, M) the columns of A2 (never gathered).  m_split is a multiple of 256.
     const float* A2; int lda2; int m_split;
-    // Work-queue launches of the 256 x 256-tile kernel: done != nullptr -> a block that has stored its tile releases it at agent scope and
-    // adds 1 to done[row tile] (zeroed by the caller): what a consumer on other CUs gates the rows of that row tile on
+    // Work-queue launches of the 256 x 256-tile kernel: done != nullptr -> the tile is stored write-through (sc1), and a block whose stores
+    // have all been acknowledged adds 1 to done[row tile] (zeroed by the caller): what a consumer on other CUs gates the rows of that row tile on
     // (launch_ce_rows_gated: the cross entropy under the forward pair's tail)
     int* done;
 };

@@ -179,6 +179,14 @@ __device__ __forceinline__ void store_tile_at(const GemmArgs& g, f32x16 (&acc)[2
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 }
                 float4* dst = reinterpret_cast<float4*>(C + (long long)row * g.ldc + col);
+                if (g.done != nullptr) {    // a consumer on other CUs reads this tile while the launch is still running (GemmArgs::done): write-through at
+                    // agent scope, so that "the wave's stores have been acknowledged" (s_waitcnt vmcnt(0)) means "visible to every XCD" and the
+                    // tile needs no L2 write-back of its own (an agent-scope release fence per tile flushes the XCD's whole L2 -- beside a
+                    // kernel that streams 460 MB through it: measured, the pair's tail went from 100 to 460 us)
+                    typedef float f4_ __attribute__((ext_vector_type(4)));
+                    const f4_ q = {v.x, v.y, v.z, v.w};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(dst), "v"(q) : "memory");
+                } else
                 if (g.nt_store) {       // write-once streaming output (logits): keep it out of the way of L2-resident data
                     __builtin_nontemporal_store(v.x, &dst->x); __builtin_nontemporal_store(v.y, &dst->y);
                     __builtin_nontemporal_store(v.z, &dst->z); __builtin_nontemporal_store(v.w, &dst->w);
@@ -1333,8 +1341,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
         store_tile_at(g, sub, ep, z, m0 + wm * 128 + h2 * 64, n0 + wn * 64, (n0 + wn * 64) / 128, (g.N + 127) / 128, wn & 1, lane);
     }
     if constexpr (QUEUE) {
-        if (g.done != nullptr) {            // the tile is complete: release every wave's stores at agent scope, then count it
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (g.done != nullptr) {            // the tile is complete: every wave's (write-through) stores acknowledged, then count it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             bx_barrier();
             if (tid == 0) __hip_atomic_fetch_add(g.done + tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
