@@ -144,11 +144,15 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     const int t_cut = (T >= 4 * h->xov_tail && h->xov_tail > 0) ? (T - h->xov_tail) / h->xov_pub * h->xov_pub : T;
     GemmArgs ghead = logits_args(h, B, 0, t_cut);
     const bool xov = h->xov_call && (h->xov_parts & 1) && xcd && want_dlogits && !ov && xov_fits(ghead);
-    // the cross entropy under the pair's tail (fsmg_model::ce_tail): not in a pass that self-checks the logits first, not with a tail split
+#ifdef FSMG_EXPERIMENTS
+    // the cross entropy under the pair's tail (fsmg_model::ce_tail, measured and rejected): not in a pass that self-checks the logits first
     const int tiles_m = (int)((rows + 255) / 256);
     const bool ce_tail = xov && h->ce_tail && h->aux2 != nullptr && h->xov_selfcheck_left <= 0 && t_cut == T && !h->timing &&
                          h->V1p <= 12 * 1024 && tiles_m < fsmg_model::XOV_DONE;      // (the last word of xov_done is the row counter)
     if (ce_tail) ghead.done = h->xov_done;
+#else
+    constexpr bool ce_tail = false;
+#endif
     const int xfree = xov_first_free(B);
     const int rpx = xov ? lstm_xcd16_packed_rows(B) : 0;
     if (xov) xov_gate(h, ghead, B);
@@ -258,11 +262,14 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
                 gt.bx3 = 1; gt.ksplit = 1;
                 HIPCK(h, launch_gemm(s, OP_KC, OP_XC, gt, 0));
             }
+#ifdef FSMG_EXPERIMENTS
             if (ce_tail) {         // the gated cross entropy starts when the chain is over, beside what is left of the queue
                 HIPCK(h, hipEventRecord(h->ev_ce_fork, s));
                 HIPCK(h, hipStreamWaitEvent(h->aux2, h->ev_ce_fork, 0));
             }
+#endif
             GEMMCK(gemm_cleanup(h, s, OP_KC, OP_XC, ghead, h->xov_ctl));
+#ifdef FSMG_EXPERIMENTS
             if (ce_tail) {
                 const int tiles_n = (h->V1p + 255) / 256;
                 HIPCK(h, launch_ce_rows_gated(h->aux2, h->logits, h->V1p, (int)rows, h->V1, h->Y, h->lse, h->ce, dlogits_buf(h),
@@ -271,6 +278,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
                 HIPCK(h, hipEventRecord(h->ev_ce, h->aux2));
                 HIPCK(h, hipStreamWaitEvent(s, h->ev_ce, 0));
             }
+#endif
             HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));    // the restricted launch and its tiles in flight
         }
         if (h->xov_selfcheck_left > 0) GEMMCK(xov_selfcheck(h, B));

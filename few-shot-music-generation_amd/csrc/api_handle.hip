@@ -93,8 +93,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_UPD_SPLIT")) h->upd_split = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_TAIL_ASIDE")) h->tail_aside = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_LAZY_CS")) h->lazy_cs = (e[0] != '0');
-        if (const char* e = std::getenv("FSMG_CE_TAIL")) h->ce_tail = (e[0] != '0');
-        if (const char* e = std::getenv("FSMG_CE_TAIL_BLOCKS")) h->ce_tail_blocks = std::max(1, std::min(4096, std::atoi(e)));
+
         if (const char* e = std::getenv("FSMG_INPLACE_DLOGITS")) h->inplace_dlogits = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XOV_SELFCHECK")) h->xov_selfcheck_left = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
@@ -105,6 +104,8 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_FWD_RT")) h->force_fwd_rt = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_CHAIN_SPIN_LIMIT")) h->chain_spin_limit = std::max(0, std::atoi(e));
 #ifdef FSMG_EXPERIMENTS         // settled A/Bs: tuning values and rejected alternatives, experiment builds only
+        if (const char* e = std::getenv("FSMG_CE_TAIL")) h->ce_tail = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_CE_TAIL_BLOCKS")) h->ce_tail_blocks = std::max(1, std::min(4096, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_XOV_DW_SPLIT")) h->xov_dw_split = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("FSMG_XOV_PUB")) h->xov_pub = std::max(1, std::min(64, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_FILL_EARLY")) h->fill_early = (e[0] != '0');
@@ -130,7 +131,11 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         int least = 0, greatest = 0;
         hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, least) != hipSuccess) return bail(FSMG_ERR_HIP, "aux stream create failed");
-        if (hipStreamCreateWithPriority(&h->aux2, hipStreamNonBlocking, least) != hipSuccess) return bail(FSMG_ERR_HIP, "aux2 stream create failed");
+#ifdef FSMG_EXPERIMENTS
+        if (h->ce_tail && (hipStreamCreateWithPriority(&h->aux2, hipStreamNonBlocking, least) != hipSuccess ||
+                           hipEventCreateWithFlags(&h->ev_ce_fork, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&h->ev_ce, hipEventDisableTiming) != hipSuccess)) return bail(FSMG_ERR_HIP, "aux2 stream create failed");
+#endif
         for (int c = 0; c < fsmg_model::NCHUNK; ++c)
             if (hipEventCreateWithFlags(&h->ev_chunk[c], hipEventDisableTiming) != hipSuccess) return bail(FSMG_ERR_HIP, "event create failed");
         if (hipEventCreateWithFlags(&h->ev_bucket[0], hipEventDisableTiming) != hipSuccess ||
@@ -140,8 +145,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
             hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_side_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_ce_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_ce, hipEventDisableTiming) != hipSuccess ||
+
             hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return bail(FSMG_ERR_HIP, "event create failed");
     }
     const int64_t sb = state_bytes_for(h->n_flat);
@@ -245,12 +249,14 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->ev_upd) hipEventDestroy(h->ev_upd);
     if (h->ev_side_fork) hipEventDestroy(h->ev_side_fork);
     if (h->ev_side) hipEventDestroy(h->ev_side);
+#ifdef FSMG_EXPERIMENTS
     if (h->ev_ce_fork) hipEventDestroy(h->ev_ce_fork);
     if (h->ev_ce) hipEventDestroy(h->ev_ce);
+    if (h->aux2) { hipStreamSynchronize(h->aux2); hipStreamDestroy(h->aux2); }
+#endif
     comm_destroy(h);
     if (h->probe) { hipStreamSynchronize(h->probe); hipStreamDestroy(h->probe); }
     if (h->d_probe) hipFree(h->d_probe);
-    if (h->aux2) { hipStreamSynchronize(h->aux2); hipStreamDestroy(h->aux2); }
     if (h->aux) hipStreamDestroy(h->aux);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -341,7 +347,6 @@ int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value) {
     BEGIN_CALL(h);
     HIPCK(h, hipStreamSynchronize(h->stream));
     if (h->aux) HIPCK(h, hipStreamSynchronize(h->aux));
-    if (h->aux2) HIPCK(h, hipStreamSynchronize(h->aux2));
     if (!std::strcmp(what, "chain_spin_limit")) h->chain_spin_limit = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (!std::strcmp(what, "fallback_steps")) h->fallback_steps = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 30));
     else if (!std::strcmp(what, "eager")) h->eager = value != 0;
@@ -349,7 +354,7 @@ int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value) {
     else if (!std::strcmp(what, "inplace_dlogits")) h->inplace_dlogits = value != 0;
     else if (!std::strcmp(what, "upd_split")) h->upd_split = value != 0;
     else if (!std::strcmp(what, "tail_aside")) h->tail_aside = value != 0;
-    else if (!std::strcmp(what, "ce_tail")) h->ce_tail = value != 0;
+
     else if (!std::strcmp(what, "xov_selfcheck")) h->xov_selfcheck_left = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (!std::strcmp(what, "xov_selfcheck_fault")) h->xov_selfcheck_fault = value != 0;
     else return fail(h, FSMG_ERR_NAME, std::string("unknown knob '") + what + "'");

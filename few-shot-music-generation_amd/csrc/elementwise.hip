@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) void k_ce_rows_reg(const float* logits, int ld
     ce_row_reg<NV, NT>(sh, blockIdx.x, logits, ld, n_vocab, tgt, lse, ce, dlogits, inv_n);
 }
 
+#ifdef FSMG_EXPERIMENTS         // measured and rejected (fsmg_model.h: ce_tail; profiles/r05_ce_under_tail_*): experiment builds only
 // The same rows by a PERSISTENT grid (every block draws the next row from *next_row, zeroed by the caller: rows are taken in increasing
 // order by whichever blocks have found a CU -- blocks the dispatcher cannot place yet cost nothing) whose rows are still being written
 // by the work-queue projection on other CUs (the XCD-partitioned order: the cross entropy under the forward pair's tail).
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(256) void k_ce_rows_gated(const float* logits, int 
         __syncthreads();                                 // sh is reused by the next row
     }
 }
+#endif
 
 // One wave per row: combine the per-slice (max, sum exp) partials written by the projection GEMM's epilogue.
 __global__ __launch_bounds__(256) void k_ce_combine(const float2* __restrict__ part, int nparts,
@@ -836,6 +838,7 @@ hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, 
     return hipGetLastError();
 }
 
+#ifdef FSMG_EXPERIMENTS
 hipError_t launch_ce_rows_gated(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt, float* lse, float* ce,
                                 float* dlogits, float inv_n, const int* done, int done_expect, int tile_rows, int* err_flag, int spin_cap, int blocks, int* next_row) {
     if (rows <= 0) return hipSuccess;
@@ -845,6 +848,7 @@ hipError_t launch_ce_rows_gated(hipStream_t s, const float* logits, int ld, int 
     else hipLaunchKernelGGL((k_ce_rows_gated<12, true>), dim3(blocks), dim3(256), 0, s, logits, ld, rows, n_vocab, tgt, lse, ce, dlogits, inv_n, done, done_expect, tile_rows, err_flag, spin_cap, next_row);
     return hipGetLastError();
 }
+#endif
 
 hipError_t launch_ce_combine(hipStream_t s, const float2* part, int nparts, const float* tgt_logit, int rows, float* ce) {
     if (rows <= 0) return hipSuccess;

@@ -58,7 +58,7 @@ struct GemmArgs {
     // Work-queue launches of the 256 x 256-tile kernel: done != nullptr -> the tile is stored write-through (sc1), and a block whose stores
     // have all been acknowledged adds 1 to done[row tile] (zeroed by the caller): what a consumer on other CUs gates the rows of that row tile on
     // (launch_ce_rows_gated: the cross entropy under the forward pair's tail)
-    int* done;
+    int* done;              // (experiment builds: measured and rejected, profiles/r05_ce_under_tail_*)
 };
 // amode/bmode in {OP_KC, OP_XC}. Supported combinations: (KC,XC) (XC,XC) (KC,KC)
 hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, int lds_pad = 0);

@@ -231,16 +231,19 @@ struct fsmg_model {
     // loss, k_embed_grad, the embedding-slice norm -- on the auxiliary stream BESIDE the bottom layer's weight-gradient GEMM, which is
     // issued behind dx instead of in front of it (the two do not depend on each other); the main stream waits for it right behind that
     // GEMM.  Same kernels on the same operands: same bits.  FSMG_TAIL_ASIDE=0 / fsmg_debug_set("tail_aside", 0): everything in line.
-    // XCD-partitioned order: the cross entropy UNDER the forward pair's tail.  Every work-queue tile of the projection releases its
-    // stores and counts itself in xov_done[row tile]; the cross entropy is a persistent grid (one block per CU, rows in increasing
-    // order) on a third stream that starts when the chain is over and takes each row behind its row tile's counter -- instead of
-    // waiting ~100 us for the last tiles with half of the CUs idle and then streaming 460 MB alone.  FSMG_CE_TAIL=0/1,
-    // fsmg_debug_set("ce_tail").  Passes that run the self-check keep the in-line cross entropy (it compares the logits first).
+#ifdef FSMG_EXPERIMENTS
+    // MEASURED AND REJECTED (round 5, experiment builds only: profiles/r05_ce_under_tail_*): the cross entropy UNDER the forward pair's
+    // tail.  Every work-queue tile of the projection is stored write-through and counts itself in xov_done[row tile]; the cross entropy
+    // is a persistent grid on a third stream that starts when the chain is over and takes each row behind its row tile's counter.
+    // Bit-identical -- and 7-25 % SLOWER: the persistent blocks hold CUs the last tiles need (136 VGPRs: no co-residency with a GEMM
+    // block), the tail grows from 105 to 225 us and the cross entropy itself takes 330 us instead of 92; the idle CU-time of the tail
+    // (~12 k CU-us) is half of what the pass needs in the first place.  FSMG_CE_TAIL=1, FSMG_CE_TAIL_BLOCKS.
     bool ce_tail = false;
-    int ce_tail_blocks = 256;           // FSMG_CE_TAIL_BLOCKS
+    int ce_tail_blocks = 256;
     hipStream_t aux2 = nullptr;
     hipEvent_t ev_ce_fork = nullptr, ev_ce = nullptr;
-    int* xov_done = nullptr;            // [XOV_DONE] completion counters of the projection's row tiles (GemmArgs::done)
+#endif
+    int* xov_done = nullptr;            // [XOV_DONE] completion counters of the projection's row tiles (GemmArgs::done; experiment builds)
     static constexpr int XOV_DONE = 256;
     bool tail_aside = true;
     bool side_pending = false;          // the auxiliary stream may still be reading the main lane's slabs (gemm() waits before it reuses them)

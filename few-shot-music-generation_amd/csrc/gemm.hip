@@ -179,6 +179,7 @@ __device__ __forceinline__ void store_tile_at(const GemmArgs& g, f32x16 (&acc)[2
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 }
                 float4* dst = reinterpret_cast<float4*>(C + (long long)row * g.ldc + col);
+#ifdef FSMG_EXPERIMENTS
                 if (g.done != nullptr) {    // a consumer on other CUs reads this tile while the launch is still running (GemmArgs::done): write-through at
                     // agent scope, so that "the wave's stores have been acknowledged" (s_waitcnt vmcnt(0)) means "visible to every XCD" and the
                     // tile needs no L2 write-back of its own (an agent-scope release fence per tile flushes the XCD's whole L2 -- beside a
@@ -187,6 +188,7 @@ __device__ __forceinline__ void store_tile_at(const GemmArgs& g, f32x16 (&acc)[2
                     const f4_ q = {v.x, v.y, v.z, v.w};
                     asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(dst), "v"(q) : "memory");
                 } else
+#endif
                 if (g.nt_store) {       // write-once streaming output (logits): keep it out of the way of L2-resident data
                     __builtin_nontemporal_store(v.x, &dst->x); __builtin_nontemporal_store(v.y, &dst->y);
                     __builtin_nontemporal_store(v.z, &dst->z); __builtin_nontemporal_store(v.w, &dst->w);
@@ -1340,6 +1342,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
         f32x16 (&sub)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * h2][0]);
         store_tile_at(g, sub, ep, z, m0 + wm * 128 + h2 * 64, n0 + wn * 64, (n0 + wn * 64) / 128, (g.N + 127) / 128, wn & 1, lane);
     }
+#ifdef FSMG_EXPERIMENTS
     if constexpr (QUEUE) {
         if (g.done != nullptr) {            // the tile is complete: every wave's (write-through) stores acknowledged, then count it
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1347,6 +1350,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
             if (tid == 0) __hip_atomic_fetch_add(g.done + tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#endif
     if (PROF && g.prof != nullptr && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long p_end = __builtin_amdgcn_s_memtime();

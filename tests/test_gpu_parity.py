@@ -1215,40 +1215,3 @@ def test_lazy_column_split_copies_are_refreshed_before_anybody_reads_them(hidden
     assert a.train_step(*eps[4]) == b.train_step(*eps[4])
     for k, v in b.get_params().items():
         np.testing.assert_array_equal(a.get_param(k), v)
-
-
-@pytest.mark.parametrize('shape', ['mid', 'cfg-B'])
-def test_cross_entropy_under_the_forward_pairs_tail_gives_the_same_bits(shape, monkeypatch):
-    """Round 5 (fsmg_debug_set("ce_tail", 1)): under the XCD-partitioned order every work-queue tile of the projection releases its
-    stores and counts itself per row tile; the cross entropy runs as a persistent grid on a third stream from the moment the chain is
-    over, each row behind its row tile's counter, instead of after the last tile.  Same row arithmetic: losses, dlogits-derived
-    gradients and parameters are bit-identical to the in-line cross entropy; a forced time-out (the gate never opens) skips the step
-    and recovers like any other."""
-    monkeypatch.setenv('FSMG_XCD_OVERLAP', '1')
-    if shape == 'mid':
-        cfg = small_config(hidden_size=512, embedding_size=32, input_size=3000, max_len=32)
-        N, K, Q = 5, 5, 4
-    else:
-        over, N, K, Q = FULL['cfg-B']
-        cfg = small_config(**over)
-    eps = O.synthetic_episodes(6, N, K, Q, cfg['max_len'], cfg['input_size'], seed=71)
-    a, b = new_model(cfg, max_sequences=N * (K + Q)), new_model(cfg, max_sequences=N * (K + Q))
-    assert a.debug_read('xcd_partitioned', 2)[0] == 1.0
-    a.debug_set('ce_tail', 1); a.debug_set('xov_selfcheck', 0); b.debug_set('xov_selfcheck', 0)
-    for e in eps[:4]:
-        assert a.train_step(*e) == b.train_step(*e)
-    a.forward_backward(*eps[4]); b.forward_backward(*eps[4])
-    for k in a.param_shapes:
-        np.testing.assert_array_equal(a.get_grad(k), b.get_grad(k))
-    assert a.apply_update(1.0) == b.apply_update(1.0)
-    assert a.stats()['timeouts'] == 0 and int(a.debug_read('xcd_partitioned', 3)[2]) == 1
-    if shape == 'mid':
-        a.debug_set('fallback_steps', 2); a.debug_set('chain_spin_limit', 0)
-        la = a.train_step(*eps[5])                          # the chain gives up, the gated tiles and the gated rows leave: skipped, repeated
-        st = a.stats()
-        assert st['timeouts'] == 1 and st['steps_skipped_timeout'] == 1 and a.step == 6
-        a.debug_set('chain_spin_limit', 1 << 18)
-        b.debug_set('persistent', 0); lb = b.train_step(*eps[5]); b.debug_set('persistent', 1)
-        assert la == lb
-    for k, v in b.get_params().items():
-        np.testing.assert_array_equal(a.get_param(k), v)
