@@ -229,7 +229,9 @@ def other_configs(torch, device, log, steps=20, warmup=5):
                                'bf16_split_kernels': bool(eng.debug_read('xcd_bx3', 1)[0]),
                                'us_per_time_step': {c: 1e3 * cell[c][0] / (T * steps) for c in cell},
                                'note': 'fp32 XCD-local kernels (k_lstm_fwd_xcd / k_lstm_bwd_xcd, v_mfma_f32_4x4x1) on the whole chip, serial order: '
-                                       'the north star\'s fused-cell fraction; the headline step runs the bf16-split chains packed on 3 XCDs beside the GEMMs (roofline)'}
+                                       'the north star\'s fused-cell fraction; the headline step runs the bf16-split chains packed on 3 XCDs beside the GEMMs (roofline).  '
+                                       '>= 0.30 at 45 rows is not reachable with a per-step cross-CU hand-off (2.0 us per step needed, 2.2 / 2.35 measured; DESIGN.md 10.6); '
+                                       'it is met from 100 rows on (other_configs.cfg-D: the bf16-split kernels, 0.43) and against the XCDs the cell occupies in the partitioned order'}
         r['leg_s'] = time.perf_counter() - t_leg
         res[name] = r
         log('other_configs: %s %.1f episodes/s (%.3f ms/step, guard %s)' % (name, r['value'], ms, r['guard']['ok']))

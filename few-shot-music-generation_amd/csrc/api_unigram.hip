@@ -120,6 +120,9 @@ int fsmg_unigram_set_counts(fsmg_unigram_handle u, const float* host, int64_t co
     std::vector<unsigned> tmp((size_t)count);
     for (int64_t i = 0; i < count; ++i) {
         if (!(host[i] >= 0.f) || host[i] > 4.0e9f) return ufail(u, FSMG_ERR_INVALID, "counts must be finite and >= 0");
+        // the counts live on the device as unsigned integers: a checkpoint whose counts are not whole numbers is refused, not
+        // rounded behind the caller's back
+        if (host[i] != std::floor(host[i])) return ufail(u, FSMG_ERR_INVALID, "counts must be whole numbers (element " + std::to_string(i) + " is " + std::to_string(host[i]) + ")");
         tmp[(size_t)i] = (unsigned)std::llround((double)host[i]);
     }
     UCK(u, hipStreamSynchronize(u->stream));

@@ -1,4 +1,4 @@
-// Internal launcher interface between the C-ABI orchestration (fsmg_api.hip) and the
+// Internal launcher interface between the C-ABI orchestration (api_*.hip behind fsmg_model.h) and the
 // gfx950 kernels.  Nothing here is exported; include/fsmg.h is the public surface.
 #pragma once
 #include <hip/hip_runtime.h>

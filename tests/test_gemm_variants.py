@@ -1,6 +1,6 @@
 """The bf16-split GEMM has several implementations of the same arithmetic (csrc/gemm.hip): k_gemm_bx3 (128 x 128 tiles), its
 wave-specialised variant k_gemm_bx3w and the 256 x 256-tile k_gemm_bx3h (chosen per shape by use_ws_gemm / use_h_gemm,
-csrc/fsmg_api.hip) and, in all of them, operand loads as buffer loads or through 64-bit lane addresses (k_gemm_bx3h: two
+csrc/api_schedule.hip) and, in all of them, operand loads as buffer loads or through 64-bit lane addresses (k_gemm_bx3h: two
 x-contiguous operands through LDS-DMA as well, FSMG_GEMM_DMA).  DESIGN.md claims they produce THE SAME BITS for the same K split -- same LDS image, k order and term order --
 which is what lets the choice be made per shape by measured speed alone.  ("For the same K split": the variants keep a different
 number of blocks per CU, so the split policy may cut K differently for them and the slabs are then summed in a different

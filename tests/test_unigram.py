@@ -75,4 +75,8 @@ def test_device_histogram_equals_the_host_restatement_on_episode_sized_input():
     with pytest.raises(FsmgError, match='TOKEN_RANGE'):
         u.train(np.array([3, -1], np.int32))
     assert np.array_equal(u.get_counts(), before)       # a rejected batch leaves the counts alone
+    frac = before.copy(); frac[7] += 0.5
+    with pytest.raises(FsmgError, match='whole numbers'):   # the device holds integers: a fractional checkpoint is refused, not rounded
+        u.set_counts(frac)
+    assert np.array_equal(u.get_counts(), before)
     assert abs(u.nll(np.array([3], np.int32)) - host_unigram_nll(counts, np.array([3]))) < 1e-5
