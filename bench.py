@@ -548,6 +548,13 @@ def main():
             keep = os.environ['FSMG_BENCH_SCHEDULES'].split(',')
             plans = [pl for pl in plans if pl[0] in keep] or plans[:1]
     schedules, built, failed_plans = {}, {}, {}
+    keeper = None          # the ONE handle that stays alive: the first plan that ran, replaced by the first whose guard holds (what `used` picks)
+
+    def drop(m_):
+        try:
+            m_.engine.close()
+        except Exception:                      # noqa: BLE001
+            pass
     for name, env_over in plans:
         # a schedule that cannot be built or run on this box must not cost the run its result line: every rank reports whether
         # it got through, and the schedule counts only if all did (the first plan is the one the step has always used)
@@ -583,15 +590,22 @@ def main():
                            'ms_per_step_regions': [1e3 * w / max(args.steps, 1) for w in worst],
                            'per_rank_ms_per_step': [1e3 * sorted(p)[len(p) // 2] / max(args.steps, 1) for p in per],
                            'guard_ok': all(x['ok'] for x in gs), 'guard_per_rank': gs}
-        built[name] = (m_, p_, el)
+        # Only one handle is kept alive between plans: a process's HIP streams share a few hardware queues, and the streams of
+        # several live handles can end up serialising each other (-32 % for one variant with six handles alive)
+        if keeper is None:
+            keeper = name
+            built[name] = (m_, p_, el)
+        elif not schedules[keeper]['guard_ok'] and schedules[name]['guard_ok']:
+            drop(built.pop(keeper)[0])
+            keeper = name
+            built[name] = (m_, p_, el)
+        else:
+            drop(m_)
+            del m_, p_
     # `value` is the schedule a user gets from the default configuration (plans[0]: one episode-parallel pass, buckets released when
     # the backward pass ends) -- the other schedules of an N > 1 run are listed beside it, never picked for the headline
-    ok_names = [n for n in schedules if schedules[n]['guard_ok']] or list(schedules)
-    used = plans[0][0] if plans[0][0] in ok_names else ok_names[0]
+    used = keeper
     model, par, local_elapsed = built[used]
-    for n in list(built):
-        if n != used:
-            del built[n]
     eng = model.engine
     elapsed = schedules[used]['ms_per_step'] * max(args.steps, 1) / 1e3
     per_rank = [t * max(args.steps, 1) / 1e3 for t in schedules[used]['per_rank_ms_per_step']]
