@@ -143,7 +143,6 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     // (t_cut is a multiple of the publishing period: the queue's last row tile then waits for a step that IS published)
     const int t_cut = (T >= 4 * h->xov_tail && h->xov_tail > 0) ? (T - h->xov_tail) / h->xov_pub * h->xov_pub : T;
     GemmArgs ghead = logits_args(h, B, 0, t_cut);
-    if (h->xov_call && t_cut == T) ghead.half_tiles = h->xov_half;
     const bool xov = h->xov_call && (h->xov_parts & 1) && xcd && want_dlogits && !ov && xov_fits(ghead);
 #ifdef FSMG_EXPERIMENTS
     // the cross entropy under the pair's tail (fsmg_model::ce_tail, measured and rejected): not in a pass that self-checks the logits first

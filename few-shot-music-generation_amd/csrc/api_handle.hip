@@ -93,7 +93,6 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_UPD_SPLIT")) h->upd_split = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_TAIL_ASIDE")) h->tail_aside = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_LAZY_CS")) h->lazy_cs = (e[0] != '0');
-        if (const char* e = std::getenv("FSMG_XOV_HALF")) h->xov_half = std::max(0, std::min(64, std::atoi(e)));
 
         if (const char* e = std::getenv("FSMG_INPLACE_DLOGITS")) h->inplace_dlogits = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XOV_SELFCHECK")) h->xov_selfcheck_left = std::max(0, std::atoi(e));
@@ -355,7 +354,6 @@ int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value) {
     else if (!std::strcmp(what, "inplace_dlogits")) h->inplace_dlogits = value != 0;
     else if (!std::strcmp(what, "upd_split")) h->upd_split = value != 0;
     else if (!std::strcmp(what, "tail_aside")) h->tail_aside = value != 0;
-    else if (!std::strcmp(what, "xov_half")) h->xov_half = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
 
     else if (!std::strcmp(what, "xov_selfcheck")) h->xov_selfcheck_left = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (!std::strcmp(what, "xov_selfcheck_fault")) h->xov_selfcheck_fault = value != 0;

@@ -59,20 +59,7 @@ struct GemmArgs {
     // have all been acknowledged adds 1 to done[row tile] (zeroed by the caller): what a consumer on other CUs gates the rows of that row tile on
     // (launch_ce_rows_gated: the cross entropy under the forward pair's tail)
     int* done;              // (experiment builds: measured and rejected, profiles/r05_ce_under_tail_*)
-    // Work-queue launches of the 256 x 256-tile kernel, K not split: the LAST half_tiles row tiles are drawn as items of 128 rows each
-    // (same block, the four waves of the other row half idle their MFMAs: half the matrix-pipe work per item).  The gated projection's
-    // last row tiles can only start when the chain is nearly over; as half items the tail behind the chain is filled in finer grains.
-    // Every output element is computed by the same MFMA sequence either way: same bits.  Item order: whole tiles (row tiles slowest),
-    // then the halves (row halves slowest).
-    int half_tiles;
 };
-// items a work-queue launch of the 256 x 256-tile kernel draws (GemmArgs::half_tiles; K splits multiply whole tiles only)
-__host__ __device__ inline int gemm_queue_items(const GemmArgs& g) {
-    const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256, ks = g.ksplit > 1 ? g.ksplit : 1;
-    if (g.half_tiles <= 0 || ks > 1) return tiles_m * tiles_n * ks;
-    const int full = tiles_m - (g.half_tiles < tiles_m ? g.half_tiles : tiles_m);
-    return full * tiles_n + ((g.M - 256 * full + 127) / 128) * tiles_n;
-}
 // amode/bmode in {OP_KC, OP_XC}. Supported combinations: (KC,XC) (XC,XC) (KC,KC)
 hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, int lds_pad = 0);
 // dynamic-LDS padding that caps a GEMM at `blocks_per_cu` resident blocks per CU

@@ -179,8 +179,6 @@ struct fsmg_model {
     int xov_dw_split = 4;               // K split of dW under this schedule: an item must be short against the chain it runs beside
     int xov_tail = 0;                   // FSMG_XOV_TAIL: time steps whose projection rows are left to a chip-wide launch behind the chain (0: none)
     int xov_pub = 6;                    // FSMG_XOV_PUB: the forward chain publishes every this many steps (a 256-row tile is 5.7 steps of 45 rows)
-    int xov_half = 0;                   // FSMG_XOV_HALF / fsmg_debug_set("xov_half"): the projection's last this many row tiles are queue items of 128 rows
-                                        // (GemmArgs::half_tiles): the tail behind the forward chain in finer grains
     int xov_strikes = 0;                // time-outs of passes in the XCD-partitioned order: the second one parks the schedule for this handle
     bool xov_last = false;              // the pass in flight took the XCD-partitioned order
     int xov_parts = 3;                  // FSMG_XOV_PARTS: 1 = forward pair only, 2 = backward pair only, 3 = both
@@ -513,7 +511,7 @@ inline int xov_debug() { static const int dbg = std::getenv("FSMG_XOV_DEBUG") ? 
 // Work-queue GEMM in two launches of k_gemm_bx3h<..., QUEUE> (GemmArgs::xcd_first): the restricted one lets the XCDs >= first
 // draw items (all of them: the two launches drain one queue); the clean-up one, ordered behind the kernel that owned the other
 // XCDs, lets the whole chip take what is left.  work / claim words are zeroed on the main stream before the fork.
-inline int gemm_items(const GemmArgs& g) { return gemm_queue_items(g); }
+inline int gemm_items(const GemmArgs& g) { return ((g.M + 255) / 256) * ((g.N + 255) / 256) * std::max(1, g.ksplit); }
 inline bool xov_fits(const GemmArgs& g) { return 4 + gemm_items(g) <= fsmg_model::XOV_CTL; }
 void choose_schedule(fsmg_model* h, int B, bool train = false);
 void xov_gate(fsmg_model* h, GemmArgs& g, int B);

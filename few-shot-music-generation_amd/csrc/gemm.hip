@@ -132,8 +132,7 @@ template <int XW> struct Loader<OP_XC, XW> : XcLoader<XW> {
 // the 64 x 64 sub-tile whose first row / column is mrow0 / ncol0, staged through the wave-private slice `ep` (32 x 68 floats);
 // wn = which 64-column half of its 128-column tile tn this is (the forward-only cross entropy's partials are per half)
 __device__ __forceinline__ void store_tile_at(const GemmArgs& g, f32x16 (&acc)[2][2], float* ep, int z, int mrow0, int ncol0,
-                                              int tn, int tilesN, int wn, int lane, int mlim = -1) {
-    const int M_ = mlim >= 0 ? mlim : g.M;               // row bound: the matrix, or the end of a 128-row queue item
+                                              int tn, int tilesN, int wn, int lane) {
     const int l31 = lane & 31, khalf = lane >> 5;
     float* C = g.C + (long long)z * g.c_slab;
     constexpr int EP_LD = 68;                                  // 64 + 4: rows stay 16-byte aligned
@@ -167,14 +166,14 @@ __device__ __forceinline__ void store_tile_at(const GemmArgs& g, f32x16 (&acc)[2
                 if (m > NEG) sm = (expf(x0 - m) + expf(x1 - m)) + (expf(x2 - m) + expf(x3 - m));
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
-                if (row < M_) {
+                if (row < g.M) {
                     const int t = g.ce_tgt[row];
                     if (t >= col && t < col + 4) g.ce_tgt_logit[row] = (t == col) ? v.x : (t == col + 1) ? v.y : (t == col + 2) ? v.z : v.w;
                     if ((lane & 15) == 0) g.ce_part[(long long)row * (2 * tilesN) + 2 * tn + wn] = make_float2(m, sm);
                 }
                 continue;
             }
-            if (row < M_ && col < g.N) {                      // N, ldc are multiples of 4: whole float4 in or out
+            if (row < g.M && col < g.N) {                      // N, ldc are multiples of 4: whole float4 in or out
                 if (g.bias != nullptr && z == 0) {
                     const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
@@ -1148,12 +1147,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     const int l31 = lane & 31, khalf = lane >> 5;
     const int tilesM = (g.M + XT - 1) / XT, tilesN = (g.N + XT - 1) / XT;
     int tm, tn, z;
-    int m0q = -1, m_end = g.M;                           // QUEUE: first row and row bound of the item (a whole tile, or a 128-row half)
     if (QUEUE) {
         __shared__ int s_item;
-        const int total = gemm_queue_items(g);
-        const int halves = (g.half_tiles > 0 && g.ksplit <= 1) ? min(g.half_tiles, tilesM) : 0;
-        const int n_whole = (tilesM - halves) * tilesN;  // items below this index are whole tiles
+        const int total = tilesM * tilesN * (g.ksplit > 1 ? g.ksplit : 1);
         if (g.xcd_first > 0) {
             int xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1183,9 +1179,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
                 if (j < min(g.work_limit, total) && atomicCAS(g.claim + j, 0, 1) == 0) item = j;
             }
             if (item >= 0 && g.gate != nullptr) {          // wait for the last time step the tile's rows belong to
-                const int last_row = (halves > 0 && item >= n_whole) ? min(g.M, (tilesM - halves) * XT + ((item - n_whole) / tilesN + 1) * 128) - 1
-                                                                      : min(g.M, ((item / tilesN) % tilesM + 1) * XT) - 1;
-                int t_need = last_row / g.gate_rows;
+                const int tm_ = (item / tilesN) % tilesM;
+                int t_need = (min(g.M, (tm_ + 1) * XT) - 1) / g.gate_rows;
                 if (g.gate_every > 1) t_need = min(g.gate_last, (t_need / g.gate_every + 1) * g.gate_every - 1);
                 const int spin_cap = g.gate_spin;
                 for (int spins = 0; __hip_atomic_load(g.gate + t_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.gate_expect; ++spins) {
@@ -1210,21 +1205,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
 #ifdef FSMG_EXPERIMENTS
         if (g.gate != nullptr && (g.dbg & 128)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (the measured alternative)
 #endif
-        if (halves > 0 && item >= n_whole) {
-            const int hr = (item - n_whole) / tilesN;
-            tn = (item - n_whole) % tilesN; z = 0;
-            m0q = (tilesM - halves) * XT + hr * 128; m_end = min(g.M, m0q + 128);
-            tm = m0q / XT;
-        } else {
-            tm = (item / tilesN) % tilesM; tn = item % tilesN; z = item / (tilesM * tilesN);
-        }
+        tm = (item / tilesN) % tilesM; tn = item % tilesN; z = item / (tilesM * tilesN);
     } else {
         const int bid = xcd_tile(blockIdx.x, tilesM * tilesN);
         tile_coords(bid, tilesM, tilesN, g.group_m, tm, tn);
         z = blockIdx.y;
     }
-    const int m0 = (QUEUE && m0q >= 0) ? m0q : tm * XT, n0 = tn * XT;
-    const bool mm = !QUEUE || wm * 128 < m_end - m0;     // this wave's 128 rows hold rows of the item (false: the idle half of a 128-row item)
+    const int m0 = tm * XT, n0 = tn * XT;
     unsigned long long pacc[5] = {0, 0, 0, 0, 0}, plast = 0, p_entry = 0, p_loop = 0;
     if (PROF && (g.dbg & 16) && blockIdx.x < 256 && blockIdx.y == 0) {      // experiment: first-round blocks start staggered
         const int n = ((blockIdx.x >> 3) & 7) * (g.dbg >> 8);
@@ -1249,8 +1236,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
         sa.init(first ? g.A : g.A2, first ? g.lda : g.lda2, first ? g.m_split : g.M - g.m_split, first ? m0 : m0 - g.m_split,
                 first ? g.gather : nullptr, kb, tid, g.K, smem + 2 * STAGE + wave * 2048, ke);
     } else
-    if constexpr (DMA && AMODE == OP_XC) sa.init(g.A, g.lda, m_end, m0, nullptr, kb, tid, g.K, smem + 2 * STAGE + wave * 2048);
-    else sa.init(g.A, g.lda, m_end, m0, g.gather, kb, tid, g.K);
+    if constexpr (DMA && AMODE == OP_XC) sa.init(g.A, g.lda, g.M, m0, nullptr, kb, tid, g.K, smem + 2 * STAGE + wave * 2048);
+    else sa.init(g.A, g.lda, g.M, m0, g.gather, kb, tid, g.K);
 #ifdef FSMG_EXPERIMENTS
     if constexpr (QUEUE && AMODE == OP_KC && BUFM >= 2) sa.coherent = g.gate != nullptr && (g.dbg & 32) != 0;     // (the measured alternative: agent-scope loads)
 #endif
@@ -1298,10 +1285,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
         bf16x8_t a[3][4], b[3][2];
 #define BXH_READ_A(pl) _Pragma("unroll") for (int i = 0; i < 4; ++i) a[pl][i] = *reinterpret_cast<const bf16x8_t*>(at + (pl) * PLANE + fa + i * 512);
 #define BXH_READ_B(pl) _Pragma("unroll") for (int j = 0; j < 2; ++j) b[pl][j] = *reinterpret_cast<const bf16x8_t*>(bt + (pl) * PLANE + fb + j * 512);
-        if (mm) {
         BXH_READ_A(2) BXH_READ_B(0)
         if (READS_ALL_FIRST) { BXH_READ_A(0) BXH_READ_B(2) BXH_READ_A(1) BXH_READ_B(1) }
-        }
         __builtin_amdgcn_sched_barrier(0);
         if (late && more) {
             BXH_COMMIT((kt + 1) & 1)
@@ -1309,16 +1294,14 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
         }
         __builtin_amdgcn_sched_barrier(0);
         BX_STAMP(3)
-        if (mm) {
         if (!READS_ALL_FIRST) { BXH_READ_A(0) BXH_READ_B(2) BXH_READ_A(1) BXH_READ_B(1) }
-        }
 #undef BXH_READ_A
 #undef BXH_READ_B
 #define BXH_TERM(PA, PB)                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][i], b[PB][j], acc[i][j], 0, 0, 0);
-        if (mm) { BXH_TERM(2, 0) BXH_TERM(0, 2) BXH_TERM(1, 1) BXH_TERM(1, 0) BXH_TERM(0, 1) BXH_TERM(0, 0) }
+        BXH_TERM(2, 0) BXH_TERM(0, 2) BXH_TERM(1, 1) BXH_TERM(1, 0) BXH_TERM(0, 1) BXH_TERM(0, 0)
 #undef BXH_TERM
         BX_STAMP(2)
         if (!late && more) {
@@ -1350,14 +1333,14 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sink += acc[i][j][r];
         if (sink == 1.2345e-30f) g.C[0] = sink;
-    } else if (mm)
+    } else
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {    // the wave's 128 x 64 tile as two 64 x 64 halves
         // a 256-column tile may reach past the last 128-column tile of N: nothing to store there, and the forward-only cross
         // entropy has no partial slot for it (a write would land in the next row's slots)
         if ((n0 + wn * 64) / 128 >= (g.N + 127) / 128) break;
         f32x16 (&sub)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * h2][0]);
-        store_tile_at(g, sub, ep, z, m0 + wm * 128 + h2 * 64, n0 + wn * 64, (n0 + wn * 64) / 128, (g.N + 127) / 128, wn & 1, lane, m_end);
+        store_tile_at(g, sub, ep, z, m0 + wm * 128 + h2 * 64, n0 + wn * 64, (n0 + wn * 64) / 128, (g.N + 127) / 128, wn & 1, lane);
     }
 #ifdef FSMG_EXPERIMENTS
     if constexpr (QUEUE) {
@@ -1388,7 +1371,7 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
         if (g.work == nullptr || g.claim == nullptr || (g.xcd_first > 0 && g.stop == nullptr) || g.gather != nullptr || g.prof != nullptr) return hipErrorInvalidValue;
         const long long a_b = 4LL * g.lda * (AMODE == OP_KC ? g.M : g.K), b_b = 4LL * g.ldb * (BMODE == OP_KC ? g.N : g.K);
         if (a_b >= 0xfffff000LL || b_b >= 0xfffff000LL) return hipErrorInvalidValue;
-        const int total = gemm_queue_items(g);
+        const int total = ((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.ksplit > 1 ? g.ksplit : 1);
         const int lim = g.work_limit < total ? g.work_limit : total;
         const int blocks = g.xcd_first > 0 ? (int)(((long long)lim * 8 + 7 - g.xcd_first) / (8 - g.xcd_first)) + 64 : total;
         const bool a_dma = AMODE != OP_XC || (g.lda % 4 == 0 && g.M % 4 == 0 && ((uintptr_t)g.A & 15) == 0);

@@ -1215,28 +1215,3 @@ def test_lazy_column_split_copies_are_refreshed_before_anybody_reads_them(hidden
     assert a.train_step(*eps[4]) == b.train_step(*eps[4])
     for k, v in b.get_params().items():
         np.testing.assert_array_equal(a.get_param(k), v)
-
-
-@pytest.mark.parametrize('shape', ['mid', 'cfg-B'])
-def test_half_row_queue_items_give_the_same_bits(shape, monkeypatch):
-    """Round 5 (fsmg_debug_set("xov_half", n)): the last n row tiles of the gated projection are drawn from the work queue as items
-    of 128 rows -- same block, the waves of the other row half idle their MFMAs -- so that the tail behind the forward chain is filled
-    in finer grains.  Every logit is the same MFMA sequence either way: losses, gradients and parameters bit-identical, incl. a row
-    count that ends in a partial half (mid: 1440 rows = 5 tiles + 160 rows; cfg-B: 5760 = 22 tiles + 128)."""
-    monkeypatch.setenv('FSMG_XCD_OVERLAP', '1')
-    if shape == 'mid':
-        cfg = small_config(hidden_size=512, embedding_size=32, input_size=3000, max_len=32)
-        N, K, Q = 5, 5, 4
-    else:
-        over, N, K, Q = FULL['cfg-B']
-        cfg = small_config(**over)
-    eps = O.synthetic_episodes(4, N, K, Q, cfg['max_len'], cfg['input_size'], seed=81)
-    a, b = new_model(cfg, max_sequences=N * (K + Q)), new_model(cfg, max_sequences=N * (K + Q))
-    a.debug_set('xov_half', 3 if shape == 'cfg-B' else 6)           # mid: EVERY row tile as halves
-    for e in eps[:3]:
-        assert a.train_step(*e) == b.train_step(*e)
-    a.forward_backward(*eps[3]); b.forward_backward(*eps[3])
-    for k in a.param_shapes:
-        np.testing.assert_array_equal(a.get_grad(k), b.get_grad(k))
-    st = a.stats()
-    assert st['timeouts'] == 0 and st['xov_selfcheck_mismatches'] == 0 and int(a.debug_read('xcd_partitioned', 3)[2]) == 1
