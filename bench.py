@@ -169,73 +169,46 @@ def step_roofline(cfg, B, gf, ms_per_step):
     return out
 
 
-def other_configs(torch, device, log, steps=20, warmup=5):
+def other_configs(log, steps=20, warmup=5):
     """cfg-C, cfg-D's per-rank workload (20-way 1-shot, 100 rows), cfg-E (MAML-style step) and the reference's default dims for `steps`
-    train steps each, plus cfg-B in the SERIAL order (fsmg_config.schedule = single_stream: the fp32 XCD-local fused cell chip-wide,
-    the number the north star's >= 0.30 is about) with the cell kernels event-timed.  Each leg: value, ms_per_step, guard.ok,
-    roofline_step.frac."""
-    from fsmg.dist import EpisodeParallel
-    from models.lstm_baseline import LSTMBaseline
-    from models.maml_lstm import MAMLLSTM
-    legs = [(n, OTHER[n], {}) for n in ('cfg-C', 'cfg-D', 'cfg-E', 'ref-default')] + [('cfg-B-serial-order', (dict(CFG_B), 5, 5, 4), {'schedule': 'single_stream'})]
+    train steps each, plus cfg-B in the SERIAL order (FSMG_XCD_OVERLAP=0: the fp32 XCD-local fused cell chip-wide, the number the
+    north star's >= 0.30 is about) with the cell kernels event-timed.  Each leg is this script again in a process of its own
+    (`--config X --steps 20 --warmup 5`, one timed region): a handle created late in a process that has allocated and freed a few
+    other handles' gigabytes can run 50 % slower (measured: the MAML-style step 3.7 -> 5.6 ms as the fifth handle of a process,
+    tools/_probe_cfge.py) -- what a user gets is a fresh process.  Per leg: value, ms_per_step, guard.ok, roofline_step.frac."""
+    import subprocess
+    legs = [(n, n, {}) for n in ('cfg-C', 'cfg-D', 'cfg-E', 'ref-default')] + [('cfg-B-serial-order', 'cfg-B', {'FSMG_XCD_OVERLAP': '0'})]
     res = {}
-    for name, (base, N, K, Q), over in legs:
+    for name, config, env_over in legs:
         t_leg = time.perf_counter()
-        cfg = dict(base, device=device)
-        B, T = N * (K + Q), cfg['max_len']
-        maml = (cfg['inner_steps'], cfg['inner_lr']) if name == 'cfg-E' else None
-        pool = synthetic_episodes(32, N, K, Q, T, cfg['input_size'], seed=4321)
-        d_sup = torch.from_numpy(np.stack([s for s, _ in pool])).cuda()
-        d_qry = torch.from_numpy(np.stack([q for _, q in pool])).cuda()
-        ss, qs = d_sup[0].numel() * 4, d_qry[0].numel() * 4
-        m = (MAMLLSTM if maml else LSTMBaseline)(dict(cfg, max_sequences=B, **over))
-        m.recover_or_init('')
-        par, eng = EpisodeParallel(m), m.engine
-        kw = dict(maml=maml) if maml else {}
-
-        def step(i):
-            e = i % len(pool)
-            par.train_step(d_sup.data_ptr() + e * ss, d_qry.data_ptr() + e * qs, want_loss=False, shape=(N, K, Q), **kw)
-        s0 = eng.step
-        for i in range(warmup):
-            step(i)
-        torch.cuda.synchronize()
-        s1 = eng.step
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(warmup + i)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        st = eng.stats()
-        ms = 1e3 * dt / steps
-        r = {'value': steps / dt, 'unit': 'episodes/s', 'ms_per_step': ms, 'steps': steps, 'rows_per_episode': B,
-             'guard': {'ok': bool(eng.step - s1 == steps and s1 - s0 == warmup and st['timeouts'] == 0 and st['steps_skipped_timeout'] == 0
-                                  and st['steps_skipped_token_range'] == 0 and st['xov_selfcheck_mismatches'] == 0),
-                       'advanced_by': eng.step - s1, 'timeouts': st['timeouts'], 'persistent_path': bool(st['persistent_path'])}}
-        gf = algorithmic_gflop(cfg, B)
-        if not maml:
-            r['roofline_step'] = {'frac': step_roofline(cfg, B, gf, ms)['frac']}
-        if name == 'cfg-B-serial-order':          # the fused cell in the serial order: HIP events around its two launches per step
-            cell = {}
-            for cls in CELL_CLASSES:
-                eng.timing_select(cls); eng.timing_enable(True); eng.timing_reset()
-                for i in range(steps):
-                    step(i)
-                cell[cls] = eng.timing_read(cls)
-                eng.timing_enable(False)
-            tot_ms = sum(x for x, _ in cell.values())
-            ach = sum(gf[c] for c in cell) * steps / tot_ms
-            r['fused_cell'] = {'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
-                               'bf16_split_kernels': bool(eng.debug_read('xcd_bx3', 1)[0]),
-                               'us_per_time_step': {c: 1e3 * cell[c][0] / (T * steps) for c in cell},
+        env = dict(os.environ, FSMG_BENCH_REPEATS='1', **env_over)
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', config, '--steps', str(steps), '--warmup', str(warmup),
+               '--no-cpu-baseline', '--no-breakdown', '--no-other-configs', '--no-extras']
+        try:
+            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=180)
+            line = [l for l in proc.stdout.splitlines() if l.startswith('{"metric"')][-1]
+            d = json.loads(line)
+        except Exception as e:                         # noqa: BLE001 -- a leg that fails is reported, the others still run
+            res[name] = {'error': repr(e)[:300]}
+            log('other_configs: %s FAILED (%r)' % (name, e))
+            continue
+        r = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
+             'guard': {'ok': bool(d['guard']['ok']), 'advanced_by': d['guard']['advanced_by'], 'timeouts': d['guard']['timeouts'],
+                       'persistent_path': d['guard']['persistent_path']},
+             'workload': d['config']['workload']}
+        if d.get('roofline_step'):
+            r['roofline_step'] = {'frac': d['roofline_step']['frac']}
+        if name == 'cfg-B-serial-order' and d.get('roofline'):
+            rf = d['roofline']
+            r['fused_cell'] = {'achieved': rf['achieved'], 'peak': rf['peak'], 'unit': rf['unit'], 'frac': rf['frac'], 'kernel_variant': rf.get('kernel_variant'),
+                               'us_per_time_step': {'lstm_fwd': rf['forward']['us_per_time_step'], 'lstm_bwd': rf['backward']['us_per_time_step']},
                                'note': 'fp32 XCD-local kernels (k_lstm_fwd_xcd / k_lstm_bwd_xcd, v_mfma_f32_4x4x1) on the whole chip, serial order: '
                                        'the north star\'s fused-cell fraction; the headline step runs the bf16-split chains packed on 3 XCDs beside the GEMMs (roofline).  '
                                        '>= 0.30 at 45 rows is not reachable with a per-step cross-CU hand-off (2.0 us per step needed, 2.2 / 2.35 measured; DESIGN.md 10.6); '
-                                       'it is met from 100 rows on (other_configs.cfg-D: the bf16-split kernels, 0.43) and against the XCDs the cell occupies in the partitioned order'}
+                                       'it is met from 100 rows on (cfg-D on the bf16-split kernels: 0.43) and against the XCDs the cell occupies in the partitioned order'}
         r['leg_s'] = time.perf_counter() - t_leg
         res[name] = r
-        log('other_configs: %s %.1f episodes/s (%.3f ms/step, guard %s)' % (name, r['value'], ms, r['guard']['ok']))
-        del m, par, eng, d_sup, d_qry
+        log('other_configs: %s %.1f episodes/s (%.3f ms/step, guard %s, %.1f s)' % (name, r['value'], r['ms_per_step'], r['guard']['ok'], r['leg_s']))
     return res
 
 
@@ -426,6 +399,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the clock probe, the validation leg and the host-path legs (the other_configs sub-runs)')
     ap.add_argument('--config', default='cfg-B', choices=['cfg-B', 'cfg-C', 'cfg-D', 'cfg-Bx4', 'cfg-Bx8', 'cfg-E', 'ref-default'])
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
@@ -670,6 +644,8 @@ def main():
     # real-time counter while a few train steps run (the peaks of every `frac` are quoted at the 2.4 GHz spec clock)
     clock_ghz = None
     try:
+        if args.no_extras:
+            raise StopIteration
         n_clk = max(4, min(args.steps, 12))
         eng.synchronize()
         for i in range(2):
@@ -679,6 +655,8 @@ def main():
             step(2 + i)
         clock_ghz = eng.clock_end()
         eng.synchronize()
+    except StopIteration:
+        pass
     except Exception as e:                     # noqa: BLE001
         log('clock probe failed: %r' % (e,))
         extras_failed['clock_probe'] = repr(e)
@@ -813,11 +791,11 @@ def main():
         # the other BASELINE.json configurations and the serial-order fused cell on the driver's record -- 20 steps
         # each on fresh handles inside this run (one timed region between two synchronisations; a diagnostic, never the headline)
         try:
-            out['other_configs'] = other_configs(torch, local, log)
+            out['other_configs'] = other_configs(log)
         except Exception as e:                 # noqa: BLE001
             log('other_configs leg failed: %r' % (e,))
             extras_failed['other_configs'] = repr(e)
-    if rank == 0 and not maml:
+    if rank == 0 and not maml and not args.no_extras:
         try:
             # the other half of BASELINE.json's metric: the validation path (query-only forward, batched 16 episodes
             # per call like train.evaluate does); inputs resident in HBM, NLLs read back per call
@@ -834,7 +812,7 @@ def main():
         except Exception as e:                 # noqa: BLE001 -- an extra leg must not cost the result line
             log('eval leg failed: %r' % (e,))
             extras_failed['eval'] = repr(e)
-    if rank == 0 and world == 1 and not maml:
+    if rank == 0 and world == 1 and not maml and not args.no_extras:
         try:
             # the reference's calling convention: host numpy episodes in, the loss read back every step (one 23 KB H2D
             # token copy + one synchronising 4-byte D2H per step) -- PCIe-inclusive, never the headline value
