@@ -253,8 +253,7 @@ hipError_t launch_gather_rows(hipStream_t s, const int* table, const int* idx, i
 // p[0 .. n_words) = word (p 16-byte aligned); the step uses this instead of hipMemsetAsync so that its hipGraph holds kernel nodes only
 hipError_t launch_fill32(hipStream_t s, void* p, uint32_t word, long long n_words);
 // dst[0 .. n_words) = src[0 .. n_words) (both 16-byte aligned, n_words a multiple of 4): a kernel instead of hipMemcpyAsync D2D, whose
-// engine the runtime picks per call -- a shader blit (31 us for the 78 MB of cfg-E's parameters) in a fresh process, the SDMA engine
-// (~1 ms) once other handles' streams exist in it (measured: cfg-E 3.7 -> 5.7 ms per step inside bench.py's other_configs leg)
+// engine (shader blit or SDMA) the runtime picks per call -- 31 us for the 78 MB of cfg-E's parameters, on the stream, every time
 hipError_t launch_copy_words(hipStream_t s, void* dst, const void* src, long long n_words);
 // the same, skipped on the device when *cond == 0
 hipError_t launch_fill32_if(hipStream_t s, const int* cond, void* p, uint32_t word, long long n_words);
