@@ -9,6 +9,39 @@ namespace fsmg_host {
 
 thread_local std::string g_create_error;
 
+// `aux` must run BESIDE the handle's main stream (fsmg_model::aux_tries).  The probe: a wave on the main stream polls a flag for up to
+// 300 us, a kernel on the candidate stream sets it; if the waiter gives up the two streams share a hardware queue -- keep the
+// candidate allocated (so that the next one the runtime hands out sits on another queue), draw another, at most `max_tries` times.
+static int pick_concurrent_aux(fsmg_model* h, int priority, int max_tries) {
+    int* d = nullptr;
+    if (hipMalloc((void**)&d, 256) != hipSuccess) return fail(h, FSMG_ERR_NOMEM, "hipMalloc(queue probe) failed");
+    std::vector<hipStream_t> rejected;
+    int rc = FSMG_OK, found = 0;
+    for (int t = 1; t <= max_tries && rc == FSMG_OK && !found; ++t) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, priority) != hipSuccess) { rc = fail(h, FSMG_ERR_HIP, "aux stream create failed"); break; }
+        int seen = 0;
+        const int init[2] = {0, -1};
+        if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess ||
+            launch_queue_probe(h->stream, d, d + 1, 0, 30000) != hipSuccess || launch_queue_probe(cand, d, d + 1, 1, 0) != hipSuccess ||
+            hipStreamSynchronize(cand) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
+            hipMemcpy(&seen, d + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+            hipStreamDestroy(cand);
+            rc = fail(h, FSMG_ERR_HIP, "queue probe failed");
+            break;
+        }
+        if (seen == 1) { h->aux = cand; h->aux_tries = t; found = 1; }
+        else rejected.push_back(cand);
+    }
+    if (rc == FSMG_OK && !found) {          // no stream of this process runs beside the main one: keep one for the API's sake, remember it is serial
+        h->aux = rejected.back(); rejected.pop_back();
+        h->aux_tries = -1;
+    }
+    for (hipStream_t s : rejected) hipStreamDestroy(s);
+    hipFree(d);
+    return rc;
+}
+
 // The second launch of the last clip + Adam update (softmax_w, softmax_b and their moments, on the auxiliary stream) may still be in
 // flight: order the main stream behind it.  One event wait, no host synchronisation.
 int settle_pending(fsmg_model* h) {
@@ -130,7 +163,15 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
 #endif
         int least = 0, greatest = 0;
         hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, least) != hipSuccess) return bail(FSMG_ERR_HIP, "aux stream create failed");
+        {
+            static const int tries = std::getenv("FSMG_AUX_TRIES") ? std::max(1, std::min(32, std::atoi(std::getenv("FSMG_AUX_TRIES")))) : 8;
+            if (pick_concurrent_aux(h, least, tries) != FSMG_OK) { std::string e = h->err; return bail(FSMG_ERR_HIP, e); }
+            if (h->aux_tries < 0) {
+                fprintf(stderr, "[fsmg] no second stream of this process runs beside the handle's stream (%d candidates share its hardware queue: "
+                                "GPU_MAX_HW_QUEUES?): serial order, no overlapped tails for this handle\n", tries);
+                h->overlap = false; h->overlap_forced = true; h->tail_aside = false; h->upd_split = false;
+            }
+        }
 #ifdef FSMG_EXPERIMENTS
         if (h->ce_tail && (hipStreamCreateWithPriority(&h->aux2, hipStreamNonBlocking, least) != hipSuccess ||
                            hipEventCreateWithFlags(&h->ev_ce_fork, hipEventDisableTiming) != hipSuccess ||
@@ -207,6 +248,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
                                   4 + items <= fsmg_model::XOV_CTL;
             if (cfg->schedule == FSMG_SCHEDULE_AUTO && std::getenv("FSMG_XCD_OVERLAP") == nullptr && !h->overlap_forced) h->xov = eligible;
         }
+        if (h->aux_tries < 0) h->xov = false;           // its two launches would run one after the other (pick_concurrent_aux)
         // the XCD-partitioned schedule packs the rows on ceil(B / 16) XCDs: only the bf16-split kernels take 16 rows per XCD at one
         // MFMA phase's cost
         if (h->xov && h->bx3 && h->Hp == 512) h->xcd_bx3 = true;

@@ -682,6 +682,20 @@ __global__ __launch_bounds__(256) void k_compare_words(const uint4* __restrict__
     }
 }
 
+// See launch_queue_probe (fsmg_kernels.h): which of two streams' kernels can overlap is decided by the hardware queues the runtime
+// mapped the streams to -- a process has GPU_MAX_HW_QUEUES (4) of them and hands them out round-robin.
+__global__ void k_queue_probe(int* flag, int* out, int role, long long ticks) {
+    if (threadIdx.x != 0) return;
+    if (role == 1) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int seen = 0;
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { seen = 1; break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    out[0] = seen;
+}
+
 // ---------------------------------------------------------------- unigram baseline
 // Reference src/models/unigram_model.py:26-39: word_count (alpha = 1) + scatter_add of ones, prob = gather / reduce_sum,
 // loss = -mean(log prob).  Counts are integers (unsigned atomics: exact and order-independent), handed to the caller as floats.
@@ -945,6 +959,10 @@ hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, flo
     return hipGetLastError();
 }
 
+hipError_t launch_queue_probe(hipStream_t s, int* flag, int* out, int role, long long realtime_ticks) {
+    hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, s, flag, out, role, realtime_ticks);
+    return hipGetLastError();
+}
 hipError_t launch_clock_probe(hipStream_t s, long long realtime_ticks, unsigned long long* out) {
     hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, realtime_ticks, out);
     return hipGetLastError();

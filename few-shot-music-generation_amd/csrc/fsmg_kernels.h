@@ -339,6 +339,10 @@ hipError_t launch_sum_partials(hipStream_t s, const double* partials, int n, flo
 // a[0 .. n_words) against b[0 .. n_words) as 32-bit words (n_words a multiple of 4, both 16-byte aligned): every differing 16-byte
 // word adds 1 to *counter (host-mapped) and sets *err_flag = 2 -- the step is then skipped like a timed-out one
 hipError_t launch_compare_words(hipStream_t s, const void* a, const void* b, long long n_words, int* err_flag, long long* counter);
+// Do two streams run side by side?  role 0 (launched first, on stream A): one wave polls *flag for up to `realtime_ticks` of the 100 MHz
+// counter and writes out[0] = 1 if it saw it set, 0 if it gave up; role 1 (on stream B): sets *flag.  Two streams that share a hardware
+// queue run B behind A, and A gives up.
+hipError_t launch_queue_probe(hipStream_t s, int* flag, int* out, int role, long long realtime_ticks);
 // one wave for `realtime_ticks` of the 100 MHz counter: out[0] = shader-clock ticks elapsed, out[1] = real-time ticks elapsed
 hipError_t launch_clock_probe(hipStream_t s, long long realtime_ticks, unsigned long long* out);
 // unigram baseline (reference src/models/unigram_model.py:26-39): counts[w] += 1 per word; out[0] = -mean(log(count[w] / sum(counts))),

@@ -285,7 +285,8 @@ int fsmg_get_stats(fsmg_handle h, fsmg_stats* out);
  *   gate order, holds dz after a backward), "logits" [T*B,V1p], "lse" [T*B], "ce" [T*B];
  *   rows are TIME-major (row = t*B + b).  count = elements to copy (<= buffer size).
  *   "xcd_bx3" [1]: 1.0 when the handle runs the bf16-split XCD-local recurrent kernels (hidden 512: created for > 64 rows, or for
- *   the XCD-partitioned schedule); "xcd_partitioned" [3]: 1.0 when train passes take the XCD-partitioned order, XCDs the chains occupy, whether the LAST pass took it */
+ *   the XCD-partitioned schedule); "aux_tries" [1]: second streams fsmg_create drew until one ran BESIDE the handle's stream (a process's
+ *   streams share GPU_MAX_HW_QUEUES hardware queues; -1: none did and the handle keeps the serial order); "xcd_partitioned" [3]: 1.0 when train passes take the XCD-partitioned order, XCDs the chains occupy, whether the LAST pass took it */
 int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count);
 /* run-time knobs of a handle that used to be create-time environment variables (tests, diagnostics):
  *   "chain_spin_limit"  polls before a persistent recurrent kernel gives up (0 forces the time-out path)

@@ -1215,3 +1215,32 @@ def test_lazy_column_split_copies_are_refreshed_before_anybody_reads_them(hidden
     assert a.train_step(*eps[4]) == b.train_step(*eps[4])
     for k, v in b.get_params().items():
         np.testing.assert_array_equal(a.get_param(k), v)
+
+
+def test_every_handle_of_a_process_gets_a_second_stream_that_runs_beside_its_own():
+    """Round 5: the runtime maps a process's streams round-robin onto a few hardware queues; a handle whose two streams land on the
+    same queue runs its XCD-partitioned pairs one after the other -- silently, 1.68 -> 2.49 ms per cfg-B step for handles 5, 7 and 9
+    of a process before this (profiles/r05_hw_queue_probe.txt).  fsmg_create now probes the candidate stream (a wave on the main
+    stream polls a flag a kernel on the candidate sets) and draws another until the two overlap.  Ten live handles: each found one,
+    some needed more than one draw, and their step times agree."""
+    import time
+    import torch
+    over, N, K, Q = FULL['cfg-B']
+    cfg = small_config(**dict(over, max_len=32))
+    eps = O.synthetic_episodes(2, N, K, Q, cfg['max_len'], cfg['input_size'], seed=91)
+    models, tries, ms = [], [], []
+    for i in range(10):
+        m = new_model(cfg, max_sequences=N * (K + Q))
+        models.append(m)
+        tries.append(int(m.debug_read('aux_tries', 1)[0]))
+        for _ in range(4):
+            m.train_step(*eps[0])
+        m.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            m.train_step(*eps[1], want_loss=False)
+        m.synchronize()
+        ms.append(1e3 * (time.perf_counter() - t0) / 10)
+    assert all(t >= 1 for t in tries), tries
+    assert max(ms) < 1.25 * min(ms), (ms, tries)            # a serialised pair is +45 % at this shape
+    assert all(m.stats()['timeouts'] == 0 for m in models)
