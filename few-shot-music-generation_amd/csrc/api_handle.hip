@@ -9,6 +9,11 @@ namespace fsmg_host {
 
 thread_local std::string g_create_error;
 
+// The auxiliary stream has the DEFAULT priority.  Rounds 1-4 created it with the lowest one (the chains' kernels were to win the
+// dispatcher); measured in round 5 (profiles/r05_hw_queue_probe.txt): with five or more handles alive in a process, every odd one
+// from the fifth on ran 32-45 % slower -- every kernel of its step 20-50 us longer -- as soon as a step touched its non-default-
+// priority stream (lowest or highest alike; the serial order with only the backward tail on it: 1.83 -> 2.49 ms), and at the default
+// priority nothing is lost anywhere (cfg-B / C / D / ref-default / 360-row batches, train and validation: within +-0.3 %).
 // `aux` must run BESIDE the handle's main stream (fsmg_model::aux_tries).  The probe: a wave on the main stream polls a flag for up to
 // 300 us, a kernel on the candidate stream sets it; if the waiter gives up the two streams share a hardware queue -- keep the
 // candidate allocated (so that the next one the runtime hands out sits on another queue), draw another, at most `max_tries` times.
@@ -161,11 +166,9 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         }
         if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) { h->aux_blocks_per_cu = h->aux_blocks_persist = std::max(1, std::min(4, std::atoi(e))); h->aux_blocks_from_env = true; }
 #endif
-        int least = 0, greatest = 0;
-        hipDeviceGetStreamPriorityRange(&least, &greatest);
         {
             static const int tries = std::getenv("FSMG_AUX_TRIES") ? std::max(1, std::min(32, std::atoi(std::getenv("FSMG_AUX_TRIES")))) : 8;
-            if (pick_concurrent_aux(h, least, tries) != FSMG_OK) { std::string e = h->err; return bail(FSMG_ERR_HIP, e); }
+            if (pick_concurrent_aux(h, 0, tries) != FSMG_OK) { std::string e = h->err; return bail(FSMG_ERR_HIP, e); }
             if (h->aux_tries < 0) {
                 fprintf(stderr, "[fsmg] no second stream of this process runs beside the handle's stream (%d candidates share its hardware queue: "
                                 "GPU_MAX_HW_QUEUES?): serial order, no overlapped tails for this handle\n", tries);
@@ -173,7 +176,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
             }
         }
 #ifdef FSMG_EXPERIMENTS
-        if (h->ce_tail && (hipStreamCreateWithPriority(&h->aux2, hipStreamNonBlocking, least) != hipSuccess ||
+        if (h->ce_tail && (hipStreamCreateWithPriority(&h->aux2, hipStreamNonBlocking, 0) != hipSuccess ||
                            hipEventCreateWithFlags(&h->ev_ce_fork, hipEventDisableTiming) != hipSuccess ||
                            hipEventCreateWithFlags(&h->ev_ce, hipEventDisableTiming) != hipSuccess)) return bail(FSMG_ERR_HIP, "aux2 stream create failed");
 #endif

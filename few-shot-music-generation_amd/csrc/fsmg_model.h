@@ -155,12 +155,11 @@ struct fsmg_model {
     float* colsum_slabs2 = nullptr;
     hipStream_t probe = nullptr;        // fsmg_debug_clock_begin / _end: the shader-clock probe's own stream
     unsigned long long* d_probe = nullptr;
-    hipStream_t aux = nullptr;          // low-priority stream for the projection GEMMs that overlap the recurrence
-    // whether `aux` really runs beside `stream`: the runtime maps a process's streams round-robin onto GPU_MAX_HW_QUEUES (4) hardware
-    // queues, and two streams of one handle that land on the same queue run one after the other -- the XCD-partitioned pairs then
-    // serialise silently (measured: handles 5, 7 and 9 of a process 1.68 -> 2.49 ms per cfg-B step, profiles/r05_hw_queue_probe.txt).
-    // fsmg_create probes it (launch_queue_probe) and draws another stream until the two overlap; -1: never found one (the orders
-    // that need two streams side by side are switched off for the handle), else the streams it took
+    hipStream_t aux = nullptr;          // second stream (DEFAULT priority since round 5: api_handle.hip pick_concurrent_aux) for what runs beside the main one
+    // whether `aux` really runs beside `stream`: the runtime maps a process's streams onto GPU_MAX_HW_QUEUES (4) hardware queues per
+    // priority, and two streams of one handle on the same queue run one after the other.  fsmg_create probes it (launch_queue_probe)
+    // and draws another stream until the two overlap; -1: never found one (the orders that need two streams side by side are
+    // switched off for the handle), else the number of streams it drew
     int aux_tries = 0;
     static constexpr int NCHUNK = 16;   // max time chunks of the overlap schedule
     std::vector<int> chunk_edges;       // explicit chunk boundaries (FSMG_CHUNK_STEPS), empty = uniform

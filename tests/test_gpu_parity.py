@@ -1218,11 +1218,11 @@ def test_lazy_column_split_copies_are_refreshed_before_anybody_reads_them(hidden
 
 
 def test_every_handle_of_a_process_gets_a_second_stream_that_runs_beside_its_own():
-    """Round 5: the runtime maps a process's streams round-robin onto a few hardware queues; a handle whose two streams land on the
-    same queue runs its XCD-partitioned pairs one after the other -- silently, 1.68 -> 2.49 ms per cfg-B step for handles 5, 7 and 9
-    of a process before this (profiles/r05_hw_queue_probe.txt).  fsmg_create now probes the candidate stream (a wave on the main
-    stream polls a flag a kernel on the candidate sets) and draws another until the two overlap.  Ten live handles: each found one,
-    some needed more than one draw, and their step times agree."""
+    """Round 5: with five or more handles alive in a process, handles 5, 7 and 9 ran 1.68 -> 2.49 ms per cfg-B step -- silently,
+    every kernel 15-60 us longer -- as soon as a step touched their lowest-priority auxiliary stream (profiles/r05_hw_queue_probe.txt).
+    The auxiliary stream has the default priority now (nothing lost: same file), and since both streams of a handle then share one
+    pool of hardware queues fsmg_create probes that the pair really overlaps (a wave on the main stream polls a flag a kernel on the
+    candidate sets) and draws another stream otherwise.  Ten live handles: each has its second stream, their step times agree."""
     import time
     import torch
     over, N, K, Q = FULL['cfg-B']
