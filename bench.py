@@ -175,7 +175,7 @@ def other_configs(log, steps=20, warmup=5):
     north star's >= 0.30 is about) with the cell kernels event-timed.  Each leg is this script again in a process of its own
     (`--config X --steps 20 --warmup 5`, one timed region): a handle created late in a process that has allocated and freed a few
     other handles' gigabytes can run 50 % slower (measured: the MAML-style step 3.7 -> 5.6 ms as the fifth handle of a process,
-    tools/_probe_cfge.py) -- what a user gets is a fresh process.  Per leg: value, ms_per_step, guard.ok, roofline_step.frac."""
+    tools/probe_cfge_late_handle.py) -- what a user gets is a fresh process.  Per leg: value, ms_per_step, guard.ok, roofline_step.frac."""
     import subprocess
     legs = [(n, n, {}) for n in ('cfg-C', 'cfg-D', 'cfg-E', 'ref-default')] + [('cfg-B-serial-order', 'cfg-B', {'FSMG_XCD_OVERLAP': '0'})]
     res = {}
