@@ -173,9 +173,9 @@ def other_configs(log, steps=20, warmup=5):
     """cfg-C, cfg-D's per-rank workload (20-way 1-shot, 100 rows), cfg-E (MAML-style step) and the reference's default dims for `steps`
     train steps each, plus cfg-B in the SERIAL order (FSMG_XCD_OVERLAP=0: the fp32 XCD-local fused cell chip-wide, the number the
     north star's >= 0.30 is about) with the cell kernels event-timed.  Each leg is this script again in a process of its own
-    (`--config X --steps 20 --warmup 5`, one timed region): a handle created late in a process that has allocated and freed a few
-    other handles' gigabytes can run 50 % slower (measured: the MAML-style step 3.7 -> 5.6 ms as the fifth handle of a process,
-    tools/probe_cfge_late_handle.py) -- what a user gets is a fresh process.  Per leg: value, ms_per_step, guard.ok, roofline_step.frac."""
+    (`--config X --steps 20 --warmup 5`, one timed region, 1.5 s): what a user gets is a fresh process, and a leg must not depend on
+    what the process did before it (round 5 found handles 5, 7, 9 of a process 32-45 % slower through the priority of a stream:
+    DESIGN.md 10.4 -- fixed, the isolation stays).  Per leg: value, ms_per_step, guard.ok, roofline_step.frac."""
     import subprocess
     legs = [(n, n, {}) for n in ('cfg-C', 'cfg-D', 'cfg-E', 'ref-default')] + [('cfg-B-serial-order', 'cfg-B', {'FSMG_XCD_OVERLAP': '0'})]
     res = {}
@@ -564,8 +564,8 @@ def main():
                            'ms_per_step_regions': [1e3 * w / max(args.steps, 1) for w in worst],
                            'per_rank_ms_per_step': [1e3 * sorted(p)[len(p) // 2] / max(args.steps, 1) for p in per],
                            'guard_ok': all(x['ok'] for x in gs), 'guard_per_rank': gs}
-        # Only one handle is kept alive between plans: a process's HIP streams share a few hardware queues, and the streams of
-        # several live handles can end up serialising each other (-32 % for one variant with six handles alive)
+        # Only one handle is kept alive between plans: nothing a plan measures may depend on the handles of the plans before it
+        # (with five handles alive, every odd one ran 32 % slower until the auxiliary stream lost its priority)
         if keeper is None:
             keeper = name
             built[name] = (m_, p_, el)
