@@ -13,6 +13,7 @@ int dhout_chunk(fsmg_model* h, const Lane& ln, int B, int t0, int t1, OpBatch* d
     GemmArgs g{};
     g.A = dlogits_buf(h) + (size_t)r0 * h->V1p; g.lda = h->V1p; g.B = h->P + h->off_w; g.ldb = h->V1p;
     g.C = h->dH + (size_t)r0 * h->Hp; g.ldc = h->Hp; g.M = (int)m; g.N = h->Hp; g.K = h->V1p; g.ksplit = 1;
+    if (h->fs_call) g.row_scale = h->crow + r0;          // fused softmax: A holds E', row r of the product times c_r is dH
     return gemm(h, ln, OP_KC, OP_KC, g, defer);
 }
 
@@ -21,6 +22,7 @@ GemmArgs dw_args(fsmg_model* h, int B) {      // dW = Hout^T * dlogits, dd = col
     g.A = h->Hs[h->L - 1] + (size_t)B * h->Hp; g.lda = h->Hp; g.B = dlogits_buf(h); g.ldb = h->V1p;
     g.C = h->G + h->off_w; g.ldc = h->V1p; g.M = h->Hp; g.N = h->V1p; g.K = (int)((int64_t)h->T * B);
     g.colsum = h->G + h->off_d; g.ksplit = 1;
+    if (h->fs_call) { g.A = h->Hsc; g.colsum_w = h->crow; }      // fused softmax: (diag(c) Hout)^T E', dd = sum_r c_r E'[r]
     return g;
 }
 int dw_gemm(fsmg_model* h, const Lane& ln, int B, OpBatch* defer = nullptr) {

@@ -48,6 +48,7 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
     };
     int l;
     if (!std::strcmp(what, "aux_tries")) { host[0] = (float)h->aux_tries; return FSMG_OK; }       // streams drawn until one ran beside the handle's (-1: none did)
+    if (!std::strcmp(what, "fused_softmax")) { host[0] = h->fused_softmax ? 1.0f : 0.0f; if (count > 1) host[1] = h->fs_call ? 1.0f : 0.0f; return FSMG_OK; }   // [0] the knob, [1] whether the last train pass took it
     if (!std::strcmp(what, "xcd_bx3")) { host[0] = h->xcd_bx3 ? 1.0f : 0.0f; return FSMG_OK; }      // a host-side fact: which XCD-local kernel family this handle runs
     if (!std::strcmp(what, "xcd_partitioned")) {      // ... and whether its train passes take the XCD-partitioned order: [0] yes / no, [1] XCDs the chains occupy, [2] the last pass
         host[0] = h->xov ? 1.0f : 0.0f;

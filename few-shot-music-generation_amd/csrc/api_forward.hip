@@ -50,6 +50,17 @@ GemmArgs logits_args(fsmg_model* h, int B, int t0, int t1) {
     g.bias = h->P + h->off_d; g.ksplit = 1; g.nt_store = 1;      // streaming stores: read back by the cross entropy much later (A/B: profiles/r03t_ntp_*)
     return g;
 }
+// fused softmax of a train pass (fsmg_model::fused_softmax): the projection's epilogue leaves E = exp(logit) + the per-slice partials ...
+inline void fused_softmax_args(fsmg_model* h, GemmArgs& g) {
+    g.ce_part = h->ce_part; g.ce_tgt = h->Y; g.ce_tgt_logit = h->tgt_logit; g.ce_nvocab = h->V1; g.ce_store = 1;
+}
+// ... and one kernel turns them into lse, ce, the row scales and c_r * h_r, and patches E[r][y_r] (all rows of the pass)
+int ce_finish(fsmg_model* h, hipStream_t s, int B, int64_t rows) {
+    ScopedTimer tm(h, "ce");
+    HIPCK(h, launch_ce_finish(s, h->ce_part, h->ce_nparts, h->tgt_logit, h->Y, (int)rows, (float)(1.0 / ((double)rows + 1e-12)), h->logits, h->V1p,
+                              h->lse, h->ce, h->crow, h->Hs[h->L - 1] + (size_t)B * h->Hp, h->Hsc, h->Hp, h->d_err, h->d_counters + 4));
+    return FSMG_OK;
+}
 int ce_rows(fsmg_model* h, hipStream_t s, int B, int t0, int t1, int64_t rows_total) {
     ScopedTimer tm(h, "ce");
     const int64_t r0 = (int64_t)t0 * B, m = (int64_t)(t1 - t0) * B;
@@ -98,6 +109,7 @@ int xov_selfcheck(fsmg_model* h, int B) {
     const int64_t rows = (int64_t)h->T * B;
     if (!h->xov_selfcheck_fault) {
         GemmArgs g = logits_args(h, B, 0, h->T);
+        if (h->fs_call) fused_softmax_args(h, g);        // (the same epilogue as the queue launch: E values; the partials it rewrites are the same numbers)
         g.C = h->dlogits; g.bx3 = 3; g.ksplit = 1;
         HIPCK(h, launch_gemm(h->stream, OP_KC, OP_XC, g, 0));
     }
@@ -143,11 +155,19 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     // (t_cut is a multiple of the publishing period: the queue's last row tile then waits for a step that IS published)
     const int t_cut = (T >= 4 * h->xov_tail && h->xov_tail > 0) ? (T - h->xov_tail) / h->xov_pub * h->xov_pub : T;
     GemmArgs ghead = logits_args(h, B, 0, t_cut);
+    // Fused softmax: where dlogits would be written in place, nothing overlaps on a second stream chunk by chunk, and the weight
+    // gradient of the projection runs on the 256 x 256-tile kernel (the one with weighted column sums)
+    h->fs_call = false;
+    if (want_dlogits && h->fused_softmax && !ov && h->bx3 && h->inplace_dlogits && h->Hsc != nullptr && t_cut == T) {
+        h->fs_call = true;                   // (dw_args reads it)
+        h->fs_call = use_h_gemm(h, OP_XC, OP_XC, dw_args(h, B), mainl) && use_h_gemm(h, OP_KC, OP_XC, ghead, mainl);
+    }
+    if (h->fs_call) fused_softmax_args(h, ghead);
     const bool xov = h->xov_call && (h->xov_parts & 1) && xcd && want_dlogits && !ov && xov_fits(ghead);
 #ifdef FSMG_EXPERIMENTS
     // the cross entropy under the pair's tail (fsmg_model::ce_tail, measured and rejected): not in a pass that self-checks the logits first
     const int tiles_m = (int)((rows + 255) / 256);
-    const bool ce_tail = xov && h->ce_tail && h->aux2 != nullptr && h->xov_selfcheck_left <= 0 && t_cut == T && !h->timing &&
+    const bool ce_tail = xov && !h->fs_call && h->ce_tail && h->aux2 != nullptr && h->xov_selfcheck_left <= 0 && t_cut == T && !h->timing &&
                          h->V1p <= 12 * 1024 && tiles_m < fsmg_model::XOV_DONE;      // (the last word of xov_done is the row counter)
     if (ce_tail) ghead.done = h->xov_done;
 #else
@@ -282,7 +302,15 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
             HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));    // the restricted launch and its tiles in flight
         }
         if (h->xov_selfcheck_left > 0) GEMMCK(xov_selfcheck(h, B));
-        if (!ce_tail) GEMMCK(ce_rows(h, s, B, 0, T, rows));
+        if (h->fs_call) GEMMCK(ce_finish(h, s, B, rows));
+        else if (!ce_tail) GEMMCK(ce_rows(h, s, B, 0, T, rows));
+    } else if (h->fs_call) {
+        {
+            ScopedTimer tm(h, "gemm_logits");
+            ghead.bx3 = 3;                                                     // (use_h_gemm said so above; K = Hp: never split)
+            HIPCK(h, launch_gemm(s, OP_KC, OP_XC, ghead, 0));
+        }
+        GEMMCK(ce_finish(h, s, B, rows));
     } else {
         GEMMCK(logits_and_ce(h, mainl, B, 0, T, rows, want_dlogits));
     }

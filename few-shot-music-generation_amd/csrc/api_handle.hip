@@ -131,6 +131,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_UPD_SPLIT")) h->upd_split = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_TAIL_ASIDE")) h->tail_aside = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_LAZY_CS")) h->lazy_cs = (e[0] != '0');
+        if (const char* e = std::getenv("FSMG_FUSED_SOFTMAX")) h->fused_softmax = (e[0] != '0');
 
         if (const char* e = std::getenv("FSMG_INPLACE_DLOGITS")) h->inplace_dlogits = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XOV_SELFCHECK")) h->xov_selfcheck_left = std::max(0, std::atoi(e));
@@ -379,6 +380,7 @@ int fsmg_get_stats(fsmg_handle h, fsmg_stats* out) {
     out->steps_skipped_token_range = h->host_counters ? h->host_counters[1] : 0;
     out->steps_skipped_peer_failure = h->host_counters ? h->host_counters[2] : 0;
     out->xov_selfcheck_mismatches = h->host_counters ? h->host_counters[3] : 0;
+    out->softmax_range_rows = h->host_counters ? h->host_counters[4] : 0;
     out->xcd_launches = h->n_xcd_launches;
     out->persistent_launches = h->n_persist_launches;
     out->step_launches = h->n_step_launches;
@@ -399,6 +401,7 @@ int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value) {
     else if (!std::strcmp(what, "inplace_dlogits")) h->inplace_dlogits = value != 0;
     else if (!std::strcmp(what, "upd_split")) h->upd_split = value != 0;
     else if (!std::strcmp(what, "tail_aside")) h->tail_aside = value != 0;
+    else if (!std::strcmp(what, "fused_softmax")) h->fused_softmax = value != 0;
 
     else if (!std::strcmp(what, "xov_selfcheck")) h->xov_selfcheck_left = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (!std::strcmp(what, "xov_selfcheck_fault")) h->xov_selfcheck_fault = value != 0;

@@ -79,6 +79,7 @@ int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g, OpBatc
         }
         g.ksplit = 1;
         HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
+        if (g.row_scale != nullptr) HIPCK(h, launch_scale_rows(s, g.C, g.row_scale, g.M, g.N));
         return FSMG_OK;
     }
     // not deferred: this GEMM writes the lane's own slabs -- if a batch still holds a REDUCE over them (the XCD-partitioned order's
@@ -94,12 +95,14 @@ int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g, OpBatc
     HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
     if (deferred) {
         GEMMCK(defer->room(colsum ? 2 : 1));
-        GEMMCK(defer->reduce(slabs, mn, S, C, mn, sq));
+        GEMMCK(defer->reduce(slabs, mn, S, C, mn, sq, sq == nullptr ? g.row_scale : nullptr, g.N));
+        if (sq != nullptr && g.row_scale != nullptr) return fail(h, FSMG_ERR_STATE, "internal: row-scaled GEMM with squared-norm partials");
         if (colsum) GEMMCK(defer->reduce(cslabs, g.N, S, colsum, g.N));
         if (sq_done) *sq_done = sq != nullptr;
         return FSMG_OK;
     }
     HIPCK(h, launch_reduce_slabs2(s, slabs, mn, S, C, mn, cslabs, g.N, colsum, colsum ? g.N : 0));
+    if (g.row_scale != nullptr) HIPCK(h, launch_scale_rows(s, C, g.row_scale, g.M, g.N));
     return FSMG_OK;
 }
 

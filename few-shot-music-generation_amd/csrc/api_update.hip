@@ -174,6 +174,19 @@ void on_timeout(fsmg_model* h) {
                             "(stale operand rows in an XCD's L2?): the step is repeated, serial order from here on\n", (long long)h->host_counters[3]);
         }
     }
+    // ... or a row's largest logit left the range the shift-free fused softmax is used for (k_ce_finish): the handle takes the
+    // cross-entropy pass with the shifted softmax from here on
+    if (h->host_counters && h->host_counters[4] != h->seen_softmax_range) {
+        h->seen_softmax_range = h->host_counters[4];
+        if (h->fused_softmax) {
+            h->fused_softmax = false;
+            hipStreamSynchronize(h->stream);
+            if (h->aux) hipStreamSynchronize(h->aux);
+            drop_graphs(h);                       // (a captured pass holds the fused path)
+            fprintf(stderr, "[fsmg] fused softmax: a row's largest logit is outside [-60, 60] (%lld rows so far): the step is repeated, "
+                            "cross-entropy pass with the shifted softmax from here on\n", (long long)h->host_counters[4]);
+        }
+    }
     // two launches that must run side by side are one more way to time out (something serialises the dispatches: a counter-collecting
     // profiler, a debugger): a handle that has seen it twice keeps the serial order
     if (h->xov_last && ++h->xov_strikes >= 2 && h->xov) {

@@ -115,6 +115,10 @@ __global__ __launch_bounds__(256) void k_multi_op(const MultiOps r) {
                 const float4 w = *reinterpret_cast<const float4*>(sl + z * o.stride + 4 * i);
                 v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
             }
+            if (o.row_scale != nullptr) {               // (dH of the fused softmax: row r of the sum times c_r)
+                const float c = o.row_scale[(4 * i) / o.row_len];
+                v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+            }
             *reinterpret_cast<float4*>(out + 4 * i) = v;
         }
         return;
@@ -414,6 +418,58 @@ __global__ __launch_bounds__(256) void k_ce_combine(const float2* __restrict__ p
     }
     s = wave_sum(s);
     if (lane == 0) ce[row] = m + logf(s) - tgt_logit[row];
+}
+
+// Second half of the fused softmax of a train pass (launch_ce_finish, fsmg_kernels.h).  One wave per row.
+__global__ __launch_bounds__(256) void k_ce_finish(const float2* __restrict__ part, int nparts, const float* __restrict__ tgt_logit,
+                                                   const int* __restrict__ tgt, int rows, float inv_n, float* E, int ld,
+                                                   float* __restrict__ lse, float* __restrict__ ce, float* __restrict__ crow,
+                                                   const float* __restrict__ hs, float* __restrict__ hs_scaled, int hp,
+                                                   int* err_flag, unsigned long long* range_counter) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float2* p = part + (long long)row * nparts;
+    float m = -INFINITY;
+    for (int i = lane; i < nparts; i += 64) m = fmaxf(m, p[i].x);
+    m = wave_max(m);
+    float s = 0.0f;
+    for (int i = lane; i < nparts; i += 64) {
+        const float2 v = p[i];
+        if (v.x > -INFINITY) s += v.y * expf(v.x - m);
+    }
+    s = wave_sum(s);
+    const float S = s * expf(m);                  // = sum_v exp(x_v): what the stored E values add up to
+    const float c = inv_n / S;
+    if (lane == 0) {
+        const float l = m + logf(s);
+        lse[row] = l;
+        ce[row] = l - tgt_logit[row];
+        crow[row] = c;
+        if (!(m <= CE_RANGE && m >= -CE_RANGE)) {          // E or S left the normal fp32 range (or is NaN): this step takes the shifted softmax
+            *err_flag = 2;
+            atomicAdd_system(range_counter, 1ull);
+            __threadfence_system();
+        } else {
+            float* e = E + (long long)row * ld + tgt[row];
+            *e = *e - S;                              // (softmax - onehot) * inv_n == c * E' now holds for the whole row
+        }
+    }
+    const float* hrow = hs + (long long)row * hp;
+    float* orow = hs_scaled + (long long)row * hp;
+    for (int i = 4 * lane; i < hp; i += 256) {
+        float4 v = *reinterpret_cast<const float4*>(hrow + i);
+        v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+        *reinterpret_cast<float4*>(orow + i) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scale_rows(float* C, const float* __restrict__ row_scale, long long n4, int n_per_row4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float c = row_scale[i / n_per_row4];
+        float4 v = reinterpret_cast<float4*>(C)[i];
+        v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+        reinterpret_cast<float4*>(C)[i] = v;
+    }
 }
 
 // out[g] = sum_{t, b in group g} ce[t*B+b] / (T*rpg + 1e-12), double accumulation, fixed order.
@@ -867,6 +923,24 @@ hipError_t launch_ce_rows_gated(hipStream_t s, const float* logits, int ld, int 
 hipError_t launch_ce_combine(hipStream_t s, const float2* part, int nparts, const float* tgt_logit, int rows, float* ce) {
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_ce_combine, dim3((rows + 3) / 4), dim3(256), 0, s, part, nparts, tgt_logit, rows, ce);
+    return hipGetLastError();
+}
+
+hipError_t launch_ce_finish(hipStream_t s, const float2* part, int nparts, const float* tgt_logit, const int* tgt, int rows, float inv_n,
+                            float* E, int ld, float* lse, float* ce, float* crow, const float* hs, float* hs_scaled, int hp,
+                            int* err_flag, long long* range_counter) {
+    if (rows <= 0) return hipSuccess;
+    if ((hp & 3) != 0 || err_flag == nullptr || range_counter == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ce_finish, dim3((rows + 3) / 4), dim3(256), 0, s, part, nparts, tgt_logit, tgt, rows, inv_n, E, ld, lse, ce, crow,
+                       hs, hs_scaled, hp, err_flag, (unsigned long long*)range_counter);
+    return hipGetLastError();
+}
+
+hipError_t launch_scale_rows(hipStream_t s, float* C, const float* row_scale, int M, int N) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    if ((N & 3) != 0) return hipErrorInvalidValue;
+    const long long n4 = (long long)M * N / 4;
+    hipLaunchKernelGGL(k_scale_rows, dim3((int)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, s, C, row_scale, n4, N / 4);
     return hipGetLastError();
 }
 

@@ -27,6 +27,17 @@ struct GemmArgs {
     // 64-column slice, (max, sum exp(x - max)) over the columns < ce_nvocab into ce_part[row][2*tile_n + half] and
     // the logit of the row's target column into ce_tgt_logit[row]
     float2* ce_part; const int* ce_tgt; float* ce_tgt_logit; int ce_nvocab;
+    // ce_store != 0 (train passes, "fused softmax"): besides the partials the epilogue stores E = exp(x) (x = logit incl. bias; 0 in the
+    // pad columns) into C -- the un-normalised softmax with NO shift, which launch_ce_finish turns into the loss gradient by patching
+    // one element per row and handing a per-row scale to the two GEMMs that consume it.  Valid while every row's largest logit is
+    // within [-CE_RANGE, CE_RANGE] (launch_ce_finish checks, the caller falls back to launch_ce_rows otherwise).
+    int ce_store;
+    // column sums of op(B) weighted per K row (XC B, 256 x 256-tile kernel only): colsum[n] = sum_k colsum_w[k] * B[k][n]
+    // (dd = sum_r c_r E'[r][v] of the fused softmax); colsum_w must be readable up to K rounded up to 16
+    const float* colsum_w;
+    // host-side plumbing (api_schedule.hip gemm()): C[m][:] is multiplied by row_scale[m] once it is complete -- in the deferred
+    // slab sum where there is one, by launch_scale_rows otherwise.  The kernels ignore it.
+    const float* row_scale;
     int nt_store;           // 1: C is written with non-temporal stores (streaming, read back much later)
     // Work-queue launches for the XCD-partitioned schedule (k_gemm_queue; not with `gather` on an XC operand).  Every block
     // draws one (split, row tile, column tile) item, row tiles slowest, in the order blocks start.  work[0] / work[1]: draw
@@ -245,7 +256,8 @@ hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a);
 //                 group (the mean loss of a train pass: rides in a launch that has work for the rest of the chip)
 enum { MULTI_FILL = 0, MULTI_REDUCE = 1, MULTI_MEAN = 2 };
 constexpr int MULTI_MAX_OPS = 16;
-struct MultiOp { int kind; void* dst; const void* src; long long n; long long stride; int nslab; uint32_t word; const int* cond; double* sq; };
+struct MultiOp { int kind; void* dst; const void* src; long long n; long long stride; int nslab; uint32_t word; const int* cond; double* sq;
+                 const float* row_scale; int row_len; /* REDUCE without sq: dst[i] = row_scale[i / row_len] * sum (row_len % 4 == 0) */ };
 struct MultiOps { MultiOp op[MULTI_MAX_OPS]; int count; };
 hipError_t launch_multi_op(hipStream_t s, const MultiOps& r);
 // out[r][0..T) = table[idx[r]][0..T) for r < n_rows (device-resident split table -> the token staging buffer)
@@ -272,6 +284,17 @@ hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, 
 hipError_t launch_ce_rows_gated(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt, float* lse, float* ce,
                                 float* dlogits, float inv_n, const int* done, int done_expect, int tile_rows, int* err_flag, int spin_cap, int blocks,
                                 int* next_row /* one int, zero before the launch: the rows are drawn from it */);
+constexpr float CE_RANGE = 60.0f;       // |largest logit of a row| the shift-free softmax of GemmArgs::ce_store is used for (exp(x) and its row sum stay normal fp32 numbers)
+// Fused softmax of a train pass, second half (first: GemmArgs::ce_store): per row, from the partials -- lse, ce = lse - target logit,
+// S = sum_v exp(x_v), c = inv_n / S -> crow[row]; E[row][tgt] -= S, so that (softmax - onehot) * inv_n == c * E' for the WHOLE row
+// (dlogits is never written: dH = diag(c) (E' W^T), dW = (diag(c) Hout)^T E', dd = sum_r c_r E'[r]); hs_scaled[row][:] = c * hs[row][:].
+// A row whose largest logit is outside [-CE_RANGE, CE_RANGE] raises *err_flag = 2 and counts itself in *range_counter (host-mapped):
+// the step is skipped and repeated on launch_ce_rows.
+hipError_t launch_ce_finish(hipStream_t s, const float2* part, int nparts, const float* tgt_logit, const int* tgt, int rows, float inv_n,
+                            float* E, int ld, float* lse, float* ce, float* crow, const float* hs, float* hs_scaled, int hp,
+                            int* err_flag, long long* range_counter);
+// C[m][0 .. N) *= row_scale[m] (rows of N floats, N % 4 == 0)
+hipError_t launch_scale_rows(hipStream_t s, float* C, const float* row_scale, int M, int N);
 // rows x nparts softmax partials (see GemmArgs::ce_part) -> ce[row] = logsumexp - target logit
 hipError_t launch_ce_combine(hipStream_t s, const float2* part, int nparts, const float* tgt_logit, int rows, float* ce);
 // out[g] = sum over t and b in group g of ce[t*B+b] / (T*rows_per_group + 1e-12); fixed order

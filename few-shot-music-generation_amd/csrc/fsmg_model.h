@@ -232,6 +232,18 @@ struct fsmg_model {
     // exceeds the 256 MB memory-side cache); fsmg_debug_read("logits") of a train pass then returns dlogits -- FSMG_INPLACE_DLOGITS=0
     // or fsmg_debug_set("inplace_dlogits", 0) keeps both
     bool inplace_dlogits = true;
+    // Fused softmax of a train pass (round 5): the projection's epilogue stores E = exp(logit) and per-slice softmax partials, a
+    // per-row kernel (k_ce_finish) derives lse / ce / c_r = 1 / (n S_r), patches E[r][y_r] -= S_r and writes c_r * h_r; then
+    // dH = diag(c) (E' W^T) (the scale rides in dH's slab sum), dW = (diag(c) Hout)^T E', dd = sum_r c_r E'[r] (weighted column sums in
+    // the dW kernel): (softmax - onehot) / n is never materialised and the 460 MB cross-entropy pass is gone.  Taken where the
+    // projection-gradient GEMMs run on the 256 x 256-tile kernel (use_h_gemm) and dlogits are in place; a row whose largest logit
+    // leaves [-60, 60] makes the step fall back to the shifted softmax (launch_ce_rows) for good on this handle.
+    // FSMG_FUSED_SOFTMAX=0 / fsmg_debug_set("fused_softmax", 0): the cross-entropy pass of rounds 1-4.
+    bool fused_softmax = true;
+    bool fs_call = false;               // the pass in flight takes it (forward() decides, backward() follows)
+    float* Hsc = nullptr;               // [T * Bcap][Hp]: c_r * top-layer h_r (dW's A operand)
+    float* crow = nullptr;              // [T * Bcap + 32]: c_r (dH's row scale, dW's column-sum weights)
+    long long seen_softmax_range = 0;
     // the bandwidth-bound tail of a backward pass -- the deferred slab sums (dW / dd, the upper layers' weight gradients, dx), the mean
     // loss, k_embed_grad, the embedding-slice norm -- on the auxiliary stream BESIDE the bottom layer's weight-gradient GEMM, which is
     // issued behind dx instead of in front of it (the two do not depend on each other); the main stream waits for it right behind that
@@ -396,11 +408,13 @@ struct OpBatch {
         return FSMG_OK;
     }
     // out[i] = sum over the nslab slabs (fixed order); sq: squared-norm partials of out as a by-product
-    int reduce(const float* slabs, long long stride, int nslab, float* out, long long n, double* sq = nullptr) {
+    // row_scale (without sq only): out[i] = row_scale[i / row_len] * sum
+    int reduce(const float* slabs, long long stride, int nslab, float* out, long long n, double* sq = nullptr, const float* row_scale = nullptr, int row_len = 0) {
         if (n <= 0) return FSMG_OK;
         const int rc = room(1); if (rc != FSMG_OK) return rc;
         MultiOp& o = r.op[r.count++];
         o = MultiOp{}; o.kind = MULTI_REDUCE; o.dst = out; o.src = slabs; o.stride = stride; o.nslab = nslab; o.n = n; o.sq = sq;
+        o.row_scale = row_scale; o.row_len = row_len;
         return FSMG_OK;
     }
     int mean(const float* x, long long n, float* out) {       // *out = sum(x) / (n + 1e-12): one block of the launch
@@ -529,6 +543,7 @@ int stage_tokens(fsmg_model* h, const int32_t* support, int n_sup, const int32_t
 int reset_tok_table(fsmg_model* h);
 int token_prep(fsmg_model* h, int n_sup, int n_qry, bool train = false);
 int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_out, bool want_dlogits);
+GemmArgs dw_args(fsmg_model* h, int B);        // api_backward.hip: dW = Hout^T dlogits, dd = colsum(dlogits) (forward() asks which kernel it will take)
 // api_backward.hip
 // part 0: the whole pass; part 1: up to and including the projection gradients; part 2: the rest (see backward())
 int backward(fsmg_model* h, int B, int part = 0);

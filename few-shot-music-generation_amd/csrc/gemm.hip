@@ -170,6 +170,13 @@ __device__ __forceinline__ void store_tile_at(const GemmArgs& g, f32x16 (&acc)[2
                     const int t = g.ce_tgt[row];
                     if (t >= col && t < col + 4) g.ce_tgt_logit[row] = (t == col) ? v.x : (t == col + 1) ? v.y : (t == col + 2) ? v.z : v.w;
                     if ((lane & 15) == 0) g.ce_part[(long long)row * (2 * tilesN) + 2 * tn + wn] = make_float2(m, sm);
+                    if (g.ce_store && col < g.N) {     // train pass: E = exp(x), no shift, zero in the pad columns (see GemmArgs::ce_store)
+                        float* dst = C + (long long)row * g.ldc + col;
+                        __builtin_nontemporal_store(col + 0 < g.ce_nvocab ? expf(v.x) : 0.0f, dst);
+                        __builtin_nontemporal_store(col + 1 < g.ce_nvocab ? expf(v.y) : 0.0f, dst + 1);
+                        __builtin_nontemporal_store(col + 2 < g.ce_nvocab ? expf(v.z) : 0.0f, dst + 2);
+                        __builtin_nontemporal_store(col + 3 < g.ce_nvocab ? expf(v.w) : 0.0f, dst + 3);
+                    }
                 }
                 continue;
             }
@@ -1255,12 +1262,19 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     // column sums of op(B): thread = (x = tid % 256, k half = tid / 256) of the XC stager
     const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0;
     float csum = 0.0f;
+    int cs_k = kb + 8 * ((DMA && BMODE == OP_XC) ? (lane >> 5) : (tid >> 8));      // first K row of the eight values this thread sums per k tile
 #define BXH_FETCH(T)                                                                                           \
     if ((T) < nfull) { sa.fetch(); sb.fetch(); }                                                               \
     else { sa.fetch_partial(kb + (T) * 16, ke, tid); sb.fetch_partial(kb + (T) * 16, ke, tid); }
 #define BXH_COMMIT(ST)                                                                                         \
     sa.load(); sb.load();                                                                                      \
-    if (do_colsum) csum += sb.sum8();                                                                          \
+    if (do_colsum) {                                                                                           \
+        if (g.colsum_w != nullptr) {     /* weighted per K row: the thread's eight values are rows cs_k .. cs_k + 7 */ \
+            const float4 w0 = *reinterpret_cast<const float4*>(g.colsum_w + cs_k), w1 = *reinterpret_cast<const float4*>(g.colsum_w + cs_k + 4); \
+            csum += ((sb.v[0] * w0.x + sb.v[1] * w0.y) + (sb.v[2] * w0.z + sb.v[3] * w0.w)) + ((sb.v[4] * w1.x + sb.v[5] * w1.y) + (sb.v[6] * w1.z + sb.v[7] * w1.w)); \
+            cs_k += 16;                                                                                        \
+        } else csum += sb.sum8();                                                                              \
+    }                                                                                                          \
     sa.commit(smem + (ST) * STAGE);                                                                            \
     sb.commit(smem + (ST) * STAGE + OPER);
 

@@ -41,7 +41,7 @@ class FsmgStats(C.Structure):
     _fields_ = [('timeouts', C.c_int64), ('steps_skipped_timeout', C.c_int64), ('steps_skipped_token_range', C.c_int64),
                 ('xcd_launches', C.c_int64), ('persistent_launches', C.c_int64), ('step_launches', C.c_int64),
                 ('persistent_path', C.c_int32), ('fallback_steps_left', C.c_int32), ('steps_skipped_peer_failure', C.c_int64),
-                ('xov_selfcheck_mismatches', C.c_int64)]
+                ('xov_selfcheck_mismatches', C.c_int64), ('softmax_range_rows', C.c_int64)]
 
 
 _P = C.c_void_p

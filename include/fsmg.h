@@ -276,6 +276,8 @@ typedef struct fsmg_stats {
     int64_t xov_selfcheck_mismatches;   /* XCD-partitioned order: 16-byte words of the gated projection's logits that differed from the
                                            same GEMM recomputed on the serial path (the self-check of a handle's first passes);
                                            non-zero = that step was skipped and repeated, the handle keeps the serial order        */
+    int64_t softmax_range_rows;         /* rows whose largest logit was outside the range of the shift-free fused softmax: the step that
+                                           held them was skipped and repeated with the cross-entropy pass, which the handle keeps from then on */
 } fsmg_stats;
 int fsmg_get_stats(fsmg_handle h, fsmg_stats* out);
 
@@ -296,6 +298,10 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
  *                       recurrent kernels are issued eagerly (default)
  *   "inplace_dlogits"   1 (default): a train pass's cross entropy writes dlogits over the logits it has just read ("logits" then
  *                       reads back as dlogits after a train pass), 0: two buffers
+ *   "fused_softmax"     1 (default): train passes whose projection-gradient GEMMs run on the 256 x 256-tile kernel never materialise
+ *                       dlogits: the projection stores exp(logit), one kernel per pass derives lse / loss / row scales, the two GEMMs
+ *                       apply them ("logits" / "dlogits" then read back exp(logit) with the target element reduced by the row sum);
+ *                       0: the cross-entropy pass
  *   "upd_split"         1: clip + Adam of an eager pass as two launches, the softmax half on the auxiliary stream beside the next
  *                       step's input phase (bit-identical; measured slower), 0 (default): one launch
  *   "tail_aside"        1 (default): the bandwidth-bound tail of an eager backward pass (deferred slab sums, embedding gradient) on

@@ -1112,6 +1112,7 @@ def test_inplace_dlogits_gives_the_same_bits(over, N, K, Q):
     sup, qry = _episode(cfg, N, K, Q, seed=11)
     a, b = new_model(cfg), new_model(cfg)
     b.debug_set('inplace_dlogits', 0)
+    a.debug_set('fused_softmax', 0)                 # (these shapes never take it; said so that the test keeps meaning what it says)
     a.forward_backward(sup, qry); b.forward_backward(sup, qry)
     d = a.debug_dims()
     n = N * (K + Q) * d['T'] * d['V1p']
@@ -1244,3 +1245,61 @@ def test_every_handle_of_a_process_gets_a_second_stream_that_runs_beside_its_own
     assert all(t >= 1 for t in tries), tries
     assert max(ms) < 1.25 * min(ms), (ms, tries)            # a serialised pair is +45 % at this shape
     assert all(m.stats()['timeouts'] == 0 for m in models)
+
+
+@pytest.mark.parametrize('order', ['partitioned', 'serial'])
+def test_fused_softmax_matches_the_cross_entropy_pass(order, monkeypatch):
+    """Round 5: where the projection-gradient GEMMs run on the 256 x 256-tile kernel a train pass never materialises
+    (softmax - onehot) / n: the projection's epilogue stores E = exp(logit) and per-slice partials, k_ce_finish derives lse, the loss,
+    c_r = 1 / (n S_r), patches E[r][y_r] -= S_r and writes c_r h_r; dH = diag(c) (E' W^T), dW = (diag(c) Hout)^T E', dd = the c-weighted
+    column sums of E'.  Against the same handle configuration with the cross-entropy pass (fused_softmax = 0), cfg-B full size, in the
+    XCD-partitioned and in the serial order: losses to 2e-6, lse / ce to 1e-6, every gradient to 2e-5 of its largest element, three
+    updates on -- and against the fp64 oracle inside the tolerances of every other full-size test."""
+    monkeypatch.setenv('FSMG_XCD_OVERLAP', '1' if order == 'partitioned' else '0')
+    over, N, K, Q = FULL['cfg-B']
+    cfg = small_config(**over)
+    B, T = N * (K + Q), cfg['max_len']
+    eps = O.synthetic_episodes(4, N, K, Q, T, cfg['input_size'], seed=101)
+    a, b = new_model(cfg, max_sequences=B), new_model(cfg, max_sequences=B)
+    b.debug_set('fused_softmax', 0)
+    a.forward_backward(*eps[0]); b.forward_backward(*eps[0])
+    assert list(a.debug_read('fused_softmax', 2)) == [1.0, 1.0] and list(b.debug_read('fused_softmax', 2)) == [0.0, 0.0]
+    np.testing.assert_allclose(a.debug_read('lse', B * T), b.debug_read('lse', B * T), rtol=1e-6)
+    np.testing.assert_allclose(a.debug_read('ce', B * T), b.debug_read('ce', B * T), rtol=1e-5, atol=1e-6)
+    for k in a.param_shapes:
+        ga, gb = a.get_grad(k), b.get_grad(k)
+        assert np.abs(ga - gb).max() <= 2e-5 * np.abs(gb).max(), k
+    params = f64_params(a)
+    loss, cache, grads, aux = cached_oracle_step(('fused', order), params, eps[0][0], eps[0][1], cfg)
+    for k in grads:
+        assert rel_max(a.get_grad(k), grads[k]) < 2e-4, k
+    la, lb = a.apply_update(1.0), b.apply_update(1.0)
+    assert abs(la - lb) <= 2e-6 * abs(lb) and abs(la - loss) <= NLL_RTOL * abs(loss)
+    for e in eps[1:]:
+        la, lb = a.train_step(*e), b.train_step(*e)
+        assert abs(la - lb) <= 5e-6 * abs(lb)
+    st = a.stats()
+    assert st['timeouts'] == 0 and st['softmax_range_rows'] == 0 and st['xov_selfcheck_mismatches'] == 0
+
+
+def test_fused_softmax_falls_back_when_a_logit_leaves_its_range():
+    """The fused softmax stores exp(logit) without a shift: fine while a row's largest logit stays within [-60, 60], checked per row
+    by k_ce_finish.  A bias of 100 on one word puts every row outside: the step is skipped on the device (no update), repeated with
+    the cross-entropy pass, and the handle keeps that pass from then on -- same losses as a handle that never used the fused form."""
+    over, N, K, Q = FULL['cfg-B']
+    cfg = small_config(**dict(over, max_len=80))                       # 3600 rows: still on the 256 x 256-tile kernels
+    eps = O.synthetic_episodes(3, N, K, Q, cfg['max_len'], cfg['input_size'], seed=102)
+    a, b = new_model(cfg, max_sequences=N * (K + Q)), new_model(cfg, max_sequences=N * (K + Q))
+    b.debug_set('fused_softmax', 0)
+    la0, lb0 = a.train_step(*eps[0]), b.train_step(*eps[0])
+    assert a.debug_read('fused_softmax', 2)[1] == 1.0 and abs(la0 - lb0) <= 5e-6 * abs(lb0)
+    for m in (a, b):
+        d = m.get_param('softmax_b'); d[7] = 100.0; m.set_param('softmax_b', d)
+    a.debug_set('fallback_steps', 1)
+    la, lb = a.train_step(*eps[1]), b.train_step(*eps[1])
+    st = a.stats()
+    assert st['softmax_range_rows'] > 0 and st['steps_skipped_timeout'] == 1 and a.step == b.step == 2
+    assert list(a.debug_read('fused_softmax', 2)) == [0.0, 0.0]
+    assert abs(la - lb) <= 5e-6 * abs(lb)
+    la, lb = a.train_step(*eps[2]), b.train_step(*eps[2])
+    assert abs(la - lb) <= 2e-5 * abs(lb) and a.stats()['steps_skipped_timeout'] == 1
