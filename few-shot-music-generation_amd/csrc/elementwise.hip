@@ -429,29 +429,24 @@ __global__ __launch_bounds__(256) void k_ce_finish(const float2* __restrict__ pa
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float2* p = part + (long long)row * nparts;
-    float m = -INFINITY;
-    for (int i = lane; i < nparts; i += 64) m = fmaxf(m, p[i].x);
-    m = wave_max(m);
-    float s = 0.0f;
-    for (int i = lane; i < nparts; i += 64) {
-        const float2 v = p[i];
-        if (v.x > -INFINITY) s += v.y * expf(v.x - m);
-    }
-    s = wave_sum(s);
-    const float S = s * expf(m);                  // = sum_v exp(x_v): what the stored E values add up to
+    float S = 0.0f;                               // = sum_v exp(x_v): the partials are un-shifted sums of the stored E values
+    for (int i = lane; i < nparts; i += 64) S += p[i].y;
+    S = wave_sum(S);
     const float c = inv_n / S;
     if (lane == 0) {
-        const float l = m + logf(s);
+        float* e = E + (long long)row * ld + tgt[row];
+        const float et = *e;
+        const float l = logf(S);
         lse[row] = l;
-        ce[row] = l - tgt_logit[row];
+        ce[row] = l - logf(et);                   // the target logit back from its E (exp and log agree to ~1 ulp of the logit's scale)
         crow[row] = c;
-        if (!(m <= CE_RANGE && m >= -CE_RANGE)) {          // E or S left the normal fp32 range (or is NaN): this step takes the shifted softmax
+        // e^-CE_RANGE <= largest E of the row <= S <= vocabulary * e^CE_RANGE: outside (or NaN / Inf) E or S left the normal fp32 range
+        if (!(S >= 8.0e-27f && S <= 1.0e30f && et > 0.0f)) {           // this step takes the shifted softmax
             *err_flag = 2;
             atomicAdd_system(range_counter, 1ull);
             __threadfence_system();
         } else {
-            float* e = E + (long long)row * ld + tgt[row];
-            *e = *e - S;                              // (softmax - onehot) * inv_n == c * E' now holds for the whole row
+            *e = et - S;                              // (softmax - onehot) * inv_n == c * E' now holds for the whole row
         }
     }
     const float* hrow = hs + (long long)row * hp;

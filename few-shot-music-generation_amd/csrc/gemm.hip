@@ -131,6 +131,23 @@ template <int XW> struct Loader<OP_XC, XW> : XcLoader<XW> {
 // instead of 64 (the store tail of a short-K GEMM is issue bound).
 // the 64 x 64 sub-tile whose first row / column is mrow0 / ncol0, staged through the wave-private slice `ep` (32 x 68 floats);
 // wn = which 64-column half of its 128-column tile tn this is (the forward-only cross entropy's partials are per half)
+// sum / maximum over the 16 lanes of a DPP row (every lane gets the result): quad xor 1, quad xor 2, row_half_mirror, row_mirror.
+// (__shfl_xor(v, o, 16) is a ds_bpermute -- an LDS-path instruction with its own wait -- per step: four to eight of them in
+// each of a tile's 32 store passes cost the fused-softmax projection 12 % of its tile time.)
+#define FSMG_ROW16(OP)                                                                                          \
+    v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));        \
+    v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));        \
+    v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));       \
+    v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+// lane J of the own DPP row of 16 (row_newbcast:J)
+template <int J> __device__ __forceinline__ float cs_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_add_(float a, float b) { return a + b; }
+__device__ __forceinline__ float row16_sum(float v) { FSMG_ROW16(row16_add_) return v; }
+__device__ __forceinline__ float row16_max(float v) { FSMG_ROW16(fmaxf) return v; }
+#undef FSMG_ROW16
+
 __device__ __forceinline__ void store_tile_at(const GemmArgs& g, f32x16 (&acc)[2][2], float* ep, int z, int mrow0, int ncol0,
                                               int tn, int tilesN, int wn, int lane) {
     const int l31 = lane & 31, khalf = lane >> 5;
@@ -138,6 +155,11 @@ __device__ __forceinline__ void store_tile_at(const GemmArgs& g, f32x16 (&acc)[2
     constexpr int EP_LD = 68;                                  // 64 + 4: rows stay 16-byte aligned
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        int tg[8];                                             // forward-only cross entropy: the targets of this lane's eight rows, loaded
+        if (g.ce_part != nullptr && !g.ce_store) {             // together ahead of the transpose (one load latency, not one per pass)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) { const int row = mrow0 + i * 32 + p * 4 + (lane >> 4); tg[p] = row < g.M ? g.ce_tgt[row] : -1; }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -149,6 +171,29 @@ __device__ __forceinline__ void store_tile_at(const GemmArgs& g, f32x16 (&acc)[2
             const int rl = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
             const int row = mrow0 + i * 32 + rl, col = ncol0 + c4;
             float4 v = *reinterpret_cast<const float4*>(ep + rl * EP_LD + c4);
+            if (g.ce_part != nullptr && g.ce_store) {
+                // train pass, fused softmax (GemmArgs::ce_store): E = exp(x) with NO shift into C (zero in the pad columns) and the sum of
+                // the wave's 64 columns as this row's partial -- no row maximum, no target lookup (a dependent global load per pass cost
+                // 14 % of the tile): k_ce_finish range-checks the row SUM and takes the target logit as log(E[target])
+                if (g.bias != nullptr && col < g.N) {
+                    const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                float4 e;
+                e.x = (col + 0 < g.ce_nvocab) ? __expf(v.x) : 0.0f; e.y = (col + 1 < g.ce_nvocab) ? __expf(v.y) : 0.0f;
+                e.z = (col + 2 < g.ce_nvocab) ? __expf(v.z) : 0.0f; e.w = (col + 3 < g.ce_nvocab) ? __expf(v.w) : 0.0f;
+                float sm = (e.x + e.y) + (e.z + e.w);
+                sm = row16_sum(sm);
+                if (row < g.M) {
+                    if ((lane & 15) == 0) g.ce_part[(long long)row * (2 * tilesN) + 2 * tn + wn] = make_float2(0.0f, sm);
+                    if (col < g.N) {
+                        float* dst = C + (long long)row * g.ldc + col;
+                        __builtin_nontemporal_store(e.x, dst); __builtin_nontemporal_store(e.y, dst + 1);
+                        __builtin_nontemporal_store(e.z, dst + 2); __builtin_nontemporal_store(e.w, dst + 3);
+                    }
+                }
+                continue;
+            }
             if (g.ce_part != nullptr) {
                 // forward-only cross entropy: softmax statistics of this row over the wave's 64 columns; the 16
                 // lanes of a row (lane>>4 picks the row of this pass) reduce with width-16 shuffles
@@ -160,23 +205,14 @@ __device__ __forceinline__ void store_tile_at(const GemmArgs& g, f32x16 (&acc)[2
                 const float x0 = (col + 0 < g.ce_nvocab) ? v.x : NEG, x1 = (col + 1 < g.ce_nvocab) ? v.y : NEG;
                 const float x2 = (col + 2 < g.ce_nvocab) ? v.z : NEG, x3 = (col + 3 < g.ce_nvocab) ? v.w : NEG;
                 float m = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+                m = row16_max(m);
                 float sm = 0.0f;
                 if (m > NEG) sm = (expf(x0 - m) + expf(x1 - m)) + (expf(x2 - m) + expf(x3 - m));
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+                sm = row16_sum(sm);
                 if (row < g.M) {
-                    const int t = g.ce_tgt[row];
+                    const int t = tg[p];
                     if (t >= col && t < col + 4) g.ce_tgt_logit[row] = (t == col) ? v.x : (t == col + 1) ? v.y : (t == col + 2) ? v.z : v.w;
                     if ((lane & 15) == 0) g.ce_part[(long long)row * (2 * tilesN) + 2 * tn + wn] = make_float2(m, sm);
-                    if (g.ce_store && col < g.N) {     // train pass: E = exp(x), no shift, zero in the pad columns (see GemmArgs::ce_store)
-                        float* dst = C + (long long)row * g.ldc + col;
-                        __builtin_nontemporal_store(col + 0 < g.ce_nvocab ? expf(v.x) : 0.0f, dst);
-                        __builtin_nontemporal_store(col + 1 < g.ce_nvocab ? expf(v.y) : 0.0f, dst + 1);
-                        __builtin_nontemporal_store(col + 2 < g.ce_nvocab ? expf(v.z) : 0.0f, dst + 2);
-                        __builtin_nontemporal_store(col + 3 < g.ce_nvocab ? expf(v.w) : 0.0f, dst + 3);
-                    }
                 }
                 continue;
             }
@@ -1262,17 +1298,30 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     // column sums of op(B): thread = (x = tid % 256, k half = tid / 256) of the XC stager
     const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0;
     float csum = 0.0f;
-    int cs_k = kb + 8 * ((DMA && BMODE == OP_XC) ? (lane >> 5) : (tid >> 8));      // first K row of the eight values this thread sums per k tile
+    // weighted column sums (GemmArgs::colsum_w): ONE dword load per wave and k tile -- lane l takes the weight of K row 8 * (its k half)
+    // + l % 8, requested with the tile's loads a k tile ahead -- and the commit's eight FMAs read it through DPP row broadcasts
+    // (row_newbcast:j: lane j of the own row of 16).  What was measured against it on the 400 us dW launch: two float4 loads per lane at
+    // the commit +46 us (latency in the open), the same a k tile ahead +130 us (two more 1 KiB vector loads per wave beside the four of
+    // the LDS-DMA staging; a CU issues one wave-level load per ~20 cycles), s_load_dwordx16 through the scalar cache +46 us (an SMEM
+    // request in flight turns every counted LDS wait of the k loop and its barrier into lgkmcnt(0)).  The request is UNCONDITIONAL in
+    // the kernels that can be asked for weights (both operands x-contiguous: the weight-gradient shapes); a launch without weights reads
+    // floats of B it never uses.
+    constexpr bool WCS = AMODE == OP_XC && BMODE == OP_XC;
+    const bool cs_weighted = WCS && do_colsum && g.colsum_w != nullptr;
+    const float* cs_p = (WCS && g.colsum_w != nullptr ? g.colsum_w : g.B) + kb + 8 * ((DMA && BMODE == OP_XC) ? (lane >> 5) : (tid >> 8)) + (lane & 7);
+    float cs_wv = 0.0f;
 #define BXH_FETCH(T)                                                                                           \
     if ((T) < nfull) { sa.fetch(); sb.fetch(); }                                                               \
-    else { sa.fetch_partial(kb + (T) * 16, ke, tid); sb.fetch_partial(kb + (T) * 16, ke, tid); }
+    else { sa.fetch_partial(kb + (T) * 16, ke, tid); sb.fetch_partial(kb + (T) * 16, ke, tid); }              \
+    if constexpr (WCS) cs_wv = cs_p[(T) * 16];
 #define BXH_COMMIT(ST)                                                                                         \
     sa.load(); sb.load();                                                                                      \
     if (do_colsum) {                                                                                           \
-        if (g.colsum_w != nullptr) {     /* weighted per K row: the thread's eight values are rows cs_k .. cs_k + 7 */ \
-            const float4 w0 = *reinterpret_cast<const float4*>(g.colsum_w + cs_k), w1 = *reinterpret_cast<const float4*>(g.colsum_w + cs_k + 4); \
-            csum += ((sb.v[0] * w0.x + sb.v[1] * w0.y) + (sb.v[2] * w0.z + sb.v[3] * w0.w)) + ((sb.v[4] * w1.x + sb.v[5] * w1.y) + (sb.v[6] * w1.z + sb.v[7] * w1.w)); \
-            cs_k += 16;                                                                                        \
+        if (cs_weighted) {               /* weighted per K row: cs_wv came in with this tile's loads (BXH_FETCH) */ \
+            csum = fmaf(sb.v[0], cs_bcast<0>(cs_wv), csum); csum = fmaf(sb.v[1], cs_bcast<1>(cs_wv), csum);   \
+            csum = fmaf(sb.v[2], cs_bcast<2>(cs_wv), csum); csum = fmaf(sb.v[3], cs_bcast<3>(cs_wv), csum);   \
+            csum = fmaf(sb.v[4], cs_bcast<4>(cs_wv), csum); csum = fmaf(sb.v[5], cs_bcast<5>(cs_wv), csum);   \
+            csum = fmaf(sb.v[6], cs_bcast<6>(cs_wv), csum); csum = fmaf(sb.v[7], cs_bcast<7>(cs_wv), csum);   \
         } else csum += sb.sum8();                                                                              \
     }                                                                                                          \
     sa.commit(smem + (ST) * STAGE);                                                                            \
@@ -1381,6 +1430,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
 template <int AMODE, int BMODE>
 hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    // weighted column sums, exp(logit) stores: the 256 x 256-tile kernels only (the weights: their x-contiguous-operand instantiations)
+    if (g.colsum_w != nullptr && !(g.bx3 == 3 && AMODE == OP_XC && BMODE == OP_XC && g.colsum != nullptr)) return hipErrorInvalidValue;
+    if (g.ce_store && !(g.bx3 == 3 && g.ce_part != nullptr)) return hipErrorInvalidValue;
     if (g.xcd_first != 0 && g.bx3 == 3) {      // work-queue launch of the 256 x 256-tile kernel (one block per CU)
         if (g.work == nullptr || g.claim == nullptr || (g.xcd_first > 0 && g.stop == nullptr) || g.gather != nullptr || g.prof != nullptr) return hipErrorInvalidValue;
         const long long a_b = 4LL * g.lda * (AMODE == OP_KC ? g.M : g.K), b_b = 4LL * g.ldb * (BMODE == OP_KC ? g.N : g.K);
