@@ -95,7 +95,6 @@ int backward(fsmg_model* h, int B, int part) {
     h->last_bwd_xcd = xcd;
     FillBatch fills(h);                     // embedding-gradient zero + the top layer's BPTT buffers: one launch
     OpBatch late(h);
-    OpBatch late2(h);                       // tail_aside: the bottom layer's weight-gradient sums, on the main stream behind the join
     OpBatch* const d_now = defer_ok ? &fills : nullptr;
     OpBatch* const d_late = defer_ok ? &late : nullptr;
     // (eager passes only: a captured pass would have to join the auxiliary stream inside the graph; event timing wants one stream)
@@ -136,14 +135,10 @@ int backward(fsmg_model* h, int B, int part) {
     }
     if (part == 1 && cut && !cut_late) return fills.flush();
     // the bandwidth-bound tail of the pass on stream `ts`: the deferred slab sums + the mean loss (one launch), the embedding gradient,
-    // the embedding-slice norm.  ts == aux: forked behind what has been issued on the main stream so far, joined by ev_side.
-    auto tail_kernels = [&](hipStream_t ts) -> int {
+    // the embedding-slice norm
+    auto tail_kernels = [&]() -> int {
+        hipStream_t ts = s;
         ScopedTimer tm(h, "embed_grad");
-        if (ts != s) {
-            HIPCK(h, hipEventRecord(h->ev_side_fork, s));
-            HIPCK(h, hipStreamWaitEvent(ts, h->ev_side_fork, 0));
-            late.s = ts;
-        }
         // tail[1] = the mean loss of the pass: nobody reads it before the step's last kernels, so it rides with the slab sums (one
         // block of a launch that keeps the rest of the chip busy) instead of costing a launch behind the cross entropy
         const bool loss_in_batch = late.r.count > 0;
@@ -156,10 +151,6 @@ int backward(fsmg_model* h, int B, int part) {
         // tail[0] = squared norm of the embedding-slice gradients, tail[1] = mean loss of the pass, tail[2] / tail[3] = time-out /
         // token-range indicators
         HIPCK(h, launch_sum_partials(ts, h->partials, nb, h->G + h->n_flat + 0, h->d_err, loss_in_batch ? nullptr : h->ce, (int)rows, h->G + h->n_flat + 1));
-        if (ts != s) {
-            HIPCK(h, hipEventRecord(h->ev_side, ts));
-            h->side_pending = true;
-        }
         return FSMG_OK;
     };
     for (int l = h->L - 1; l >= 0; --l) {
@@ -244,7 +235,7 @@ int backward(fsmg_model* h, int B, int part) {
         // dK_l (weight gradient) and dx_l (input gradient) contract the same dZ and do not depend on each other.  Layer 0 with the tail
         // moved aside: dx first, so that its slab sum, the embedding gradient and the other deferred sums run on the auxiliary stream
         // beside the dK GEMM (below); everywhere else dK first (the layer below waits for dx only).
-        OpBatch* const dk_defer = (aside && l == 0) ? &late2 : d_late;
+        OpBatch* const dk_defer = d_late;
         auto dk_gemm = [&]() -> int {
             {
                 ScopedTimer tm(h, "gemm_dk");
@@ -293,18 +284,32 @@ int backward(fsmg_model* h, int B, int part) {
             return FSMG_OK;
         };
         if (aside && l == 0) {
+            // the sums deferred so far (dW's slabs: the bulk of the tail's bytes) go out on the auxiliary stream beside dx -- a 128-tile
+            // GEMM that leaves CUs free.  Nothing is put beside dK: the 256-tile kernel holds every CU's whole register file (two
+            // 256-VGPR waves per SIMD), a kernel of another stream gets no wave in until its blocks retire (measured: dx's 12 MB slab
+            // sum took 110 us beside dK and ended 13 us after it; the embedding gradient behind it, then the join -- DESIGN.md 10.10).
+            if (late.r.count > 0) {
+                HIPCK(h, hipEventRecord(h->ev_side_fork, s));
+                HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_side_fork, 0));
+                late.s = h->aux;
+                GEMMCK(late.flush());
+                HIPCK(h, hipEventRecord(h->ev_side, h->aux));
+                late.s = s;
+                h->side_pending = true;           // (a GEMM that had to fall back to the lane's own slabs waits for this: gemm())
+            }
             GEMMCK(dx_gemm());
-            GEMMCK(tail_kernels(h->aux));
             GEMMCK(dk_gemm());
-            HIPCK(h, hipStreamWaitEvent(s, h->ev_side, 0));
-            h->side_pending = false;
-            GEMMCK(late2.flush());
+            if (h->side_pending) {
+                HIPCK(h, hipStreamWaitEvent(s, h->ev_side, 0));
+                h->side_pending = false;
+            }
+            GEMMCK(tail_kernels());
         } else {
             GEMMCK(dk_gemm());
             GEMMCK(dx_gemm());
         }
     }
-    if (!aside) GEMMCK(tail_kernels(s));
+    if (!aside) GEMMCK(tail_kernels());
     if (ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));     // dW / dd landed
     PHASE(6);
     h->have_grads = true;
