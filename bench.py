@@ -132,7 +132,7 @@ def algorithmic_gflop(cfg, B):
     return {k: v / 1e9 for k, v in g.items()}
 
 
-def step_roofline(cfg, B, gf, ms_per_step):
+def step_roofline(cfg, B, gf, ms_per_step, fused_softmax=False):
     """Blended bound of the whole train step: every dense contraction at its own arithmetic's peak (GEMMs: fp32 products from six
     bf16 MFMAs = dense bf16 peak / 6; fused cell: fp32 MFMA), the HBM-bound passes (cross entropy: logits read + dlogits written;
     clip + Adam: 7 P floats; activations written once and read once) at the achievable HBM rate -- summed as if nothing overlapped.
@@ -147,7 +147,9 @@ def step_roofline(cfg, B, gf, ms_per_step):
     # does materialise them -- written by the projection, read by the cross entropy, dlogits written (in place since round 5) and
     # read by both projection-gradient GEMMs -- which is listed beside it, not priced as necessary
     by_alg = 2 * 4 * P + 7 * 4 * P + 2 * 4 * n + 2 * (6 * L * H + E) * 4 * n
-    by_logits = 5 * 4 * n * V1
+    # classic softmax: logits written + read, dlogits written (in place) + read by dH and dW = 5 passes; fused softmax (round 5, DESIGN.md
+    # 10.10): exp(logit) written by the projection's epilogue, read by dH and dW = 3 passes, plus c_r * h_r written and read once
+    by_logits = (3 * 4 * n * V1 + 2 * 4 * n * H) if fused_softmax else 5 * 4 * n * V1
     t_gemm, t_cell, t_hbm = gemm_gf / PEAK_BX3_TFLOPS, cell_gf / PEAK_F32_MFMA_TFLOPS, by_alg / (HBM_ACHIEVABLE_TBPS * 1e9)
     out = {'bound_ms': t_gemm + t_cell + t_hbm, 'frac': (t_gemm + t_cell + t_hbm) / ms_per_step,
            'gemm_ms_at_bf16_peak_over_6': t_gemm, 'cell_ms_at_fp32_mfma_peak': t_cell, 'hbm_ms_at_%.1f_TBps' % HBM_ACHIEVABLE_TBPS: t_hbm,
@@ -156,7 +158,8 @@ def step_roofline(cfg, B, gf, ms_per_step):
            'hbm_bytes_moved_model': by_alg + by_logits,
            'frac_r04_definition': (t_gemm + t_cell + (2 * 4 * n * V1 + 7 * 4 * P + 2 * (6 * L * H + E) * 4 * n) / (HBM_ACHIEVABLE_TBPS * 1e9)) / ms_per_step,
            'note': 'sum of the three bounds (no overlap assumed) over the measured ms_per_step; hbm_bytes = SURVEY.md 8(d) algorithmic bytes (no logits); '
-                   'hbm_bytes_moved_model adds what the step materialises around the vocabulary projection (logits written + read, dlogits written + read twice; '
+                   'hbm_bytes_moved_model adds what the step materialises around the vocabulary projection (classic: logits written + read, dlogits written + read twice; '
+                   'fused softmax: exp(logit) written once + read twice, c*h written + read; '
                    'split-K slabs not included); frac_r04_definition = the round-4 figure, whose HBM term counted one logits round trip as necessary'}
     try:
         with open(os.path.join(ROOT, 'profiles', 'r05_pmc.json')) as f:
@@ -503,8 +506,11 @@ def main():
              'steps_skipped_timeout': stats['steps_skipped_timeout'], 'steps_skipped_token_range': stats['steps_skipped_token_range'],
              'persistent_path': bool(stats['persistent_path']), 'fallback_steps_left': stats['fallback_steps_left'],
              'xcd_local_kernels': stats['xcd_launches'] > 0,
+             'xov_selfcheck_mismatches': stats.get('xov_selfcheck_mismatches'), 'softmax_range_rows': stats.get('softmax_range_rows'),
+             'fused_softmax_taken': bool(eng_.debug_read('fused_softmax', 2)[1]),
              'ok': (step_after - step_before == args.steps * REPEATS and step_before - step0 == args.warmup and stats['timeouts'] == 0
-                    and stats['steps_skipped_timeout'] == 0 and stats['steps_skipped_token_range'] == 0)}
+                    and stats['steps_skipped_timeout'] == 0 and stats['steps_skipped_token_range'] == 0
+                    and not stats.get('xov_selfcheck_mismatches') and not stats.get('softmax_range_rows'))}
         return els, g
 
     # exchange schedules timed in this run (N > 1); a single GPU has nothing to exchange: one graph per step
@@ -714,7 +720,7 @@ def main():
             # that the GEMMs run on the bf16 pipe) and over the blended bound (GEMM FLOPs at peak/6 of bf16, cell FLOPs at fp32 MFMA)
             'step_mfma_frac': None if maml else (total_gflop / (1e3 * elapsed / max(args.steps, 1))) / PEAK_F32_MFMA_TFLOPS,
             'step_tflops': None if maml else total_gflop / (1e3 * elapsed / max(args.steps, 1)),
-            'roofline_step': None if maml else step_roofline(cfg, B, gf, 1e3 * elapsed / max(args.steps, 1)),
+            'roofline_step': None if maml else step_roofline(cfg, B, gf, 1e3 * elapsed / max(args.steps, 1), bool(guard.get('fused_softmax_taken'))),
             'final_loss': float(losses[-1]), 'first_loss': float(losses[0]),
             'per_rank_ms_per_step': [1e3 * t / max(args.steps, 1) for t in per_rank], 'comm': comm,
             'schedule_used': used,
