@@ -148,7 +148,7 @@ def step_roofline(cfg, B, gf, ms_per_step, fused_softmax=False):
     # read by both projection-gradient GEMMs -- which is listed beside it, not priced as necessary
     by_alg = 2 * 4 * P + 7 * 4 * P + 2 * 4 * n + 2 * (6 * L * H + E) * 4 * n
     # classic softmax: logits written + read, dlogits written (in place) + read by dH and dW = 5 passes; fused softmax (round 5, DESIGN.md
-    # 10.10): exp(logit) written by the projection's epilogue, read by dH and dW = 3 passes, plus c_r * h_r written and read once
+    # 10.8): exp(logit) written by the projection's epilogue, read by dH and dW = 3 passes, plus c_r * h_r written and read once
     by_logits = (3 * 4 * n * V1 + 2 * 4 * n * H) if fused_softmax else 5 * 4 * n * V1
     t_gemm, t_cell, t_hbm = gemm_gf / PEAK_BX3_TFLOPS, cell_gf / PEAK_F32_MFMA_TFLOPS, by_alg / (HBM_ACHIEVABLE_TBPS * 1e9)
     out = {'bound_ms': t_gemm + t_cell + t_hbm, 'frac': (t_gemm + t_cell + t_hbm) / ms_per_step,

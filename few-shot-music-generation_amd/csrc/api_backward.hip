@@ -300,7 +300,7 @@ int backward(fsmg_model* h, int B, int part) {
         // CU's whole register file (two 256-VGPR waves per SIMD): a kernel of another stream gets no wave in until its blocks retire
         // -- measured at cfg-B, dx's 12 MB slab sum took 110 us beside dK and ended 13 us after it, the embedding gradient behind it,
         // then the join; with only dW's slab sums aside (beside the 128-tile dx): cfg-B +0.2 %, cfg-C +0.2 %, cfg-D -0.3 %, cfg-E -0.6 %
-        // = nothing, so those passes keep the tail in line (DESIGN.md 10.11).
+        // = nothing, so those passes keep the tail in line (DESIGN.md 10.9).
         bool dk_h = false;
         if (aside && l == 0) GEMMCK(dk_gemm(&dk_h));
         if (aside && l == 0 && dk_h) {

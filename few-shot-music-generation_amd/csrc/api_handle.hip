@@ -18,6 +18,12 @@ thread_local std::string g_create_error;
 // 300 us, a kernel on the candidate stream sets it; if the waiter gives up the two streams share a hardware queue -- keep the
 // candidate allocated (so that the next one the runtime hands out sits on another queue), draw another, at most `max_tries` times.
 static int pick_concurrent_aux(fsmg_model* h, int priority, int max_tries) {
+    if (max_tries <= 0) {       // FSMG_AUX_TRIES=0: no probe, the first stream is taken as it comes (counter passes: a profiler that serialises
+        // dispatches makes every candidate look like a shared queue; tools/pmc_passes.sh wants the partitioned order's kernels on record)
+        if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, priority) != hipSuccess) return fail(h, FSMG_ERR_HIP, "aux stream create failed");
+        h->aux_tries = 0;
+        return FSMG_OK;
+    }
     int* d = nullptr;
     if (hipMalloc((void**)&d, 256) != hipSuccess) return fail(h, FSMG_ERR_NOMEM, "hipMalloc(queue probe) failed");
     std::vector<hipStream_t> rejected;
@@ -168,7 +174,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) { h->aux_blocks_per_cu = h->aux_blocks_persist = std::max(1, std::min(4, std::atoi(e))); h->aux_blocks_from_env = true; }
 #endif
         {
-            static const int tries = std::getenv("FSMG_AUX_TRIES") ? std::max(1, std::min(32, std::atoi(std::getenv("FSMG_AUX_TRIES")))) : 8;
+            static const int tries = std::getenv("FSMG_AUX_TRIES") ? std::max(0, std::min(32, std::atoi(std::getenv("FSMG_AUX_TRIES")))) : 8;
             if (pick_concurrent_aux(h, 0, tries) != FSMG_OK) { std::string e = h->err; return bail(FSMG_ERR_HIP, e); }
             if (h->aux_tries < 0) {
                 fprintf(stderr, "[fsmg] no second stream of this process runs beside the handle's stream (%d candidates share its hardware queue: "

@@ -440,8 +440,8 @@ __global__ __launch_bounds__(256) void k_ce_finish(const float2* __restrict__ pa
         lse[row] = l;
         ce[row] = l - logf(et);                   // the target logit back from its E (exp and log agree to ~1 ulp of the logit's scale)
         crow[row] = c;
-        // e^-CE_RANGE <= largest E of the row <= S <= vocabulary * e^CE_RANGE: outside (or NaN / Inf) E or S left the normal fp32 range
-        if (!(S >= 8.0e-27f && S <= 1.0e30f && et > 0.0f)) {           // this step takes the shifted softmax
+        // outside (or NaN / Inf): E, S or c left the normal fp32 range, or the target's E is too small to take its log
+        if (!(S >= CE_SUM_MIN && S <= CE_SUM_MAX && et >= CE_TGT_MIN)) {           // this step takes the shifted softmax
             *err_flag = 2;
             atomicAdd_system(range_counter, 1ull);
             __threadfence_system();

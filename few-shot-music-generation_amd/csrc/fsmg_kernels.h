@@ -29,8 +29,10 @@ struct GemmArgs {
     float2* ce_part; const int* ce_tgt; float* ce_tgt_logit; int ce_nvocab;
     // ce_store != 0 (train passes, "fused softmax"): besides the partials the epilogue stores E = exp(x) (x = logit incl. bias; 0 in the
     // pad columns) into C -- the un-normalised softmax with NO shift, which launch_ce_finish turns into the loss gradient by patching
-    // one element per row and handing a per-row scale to the two GEMMs that consume it.  Valid while every row's largest logit is
-    // within [-CE_RANGE, CE_RANGE] (launch_ce_finish checks, the caller falls back to launch_ce_rows otherwise).
+    // one element per row and handing a per-row scale to the two GEMMs that consume it.  The partial of a slice is (0, sum of its E):
+    // no row maximum, no target lookup (launch_ce_finish takes the target logit as log(E[target])).  Valid while every row's sum and
+    // target element stay normal fp32 numbers (CE_SUM_MIN / CE_SUM_MAX / CE_TGT_MIN: launch_ce_finish checks, the caller falls back
+    // to launch_ce_rows otherwise).
     int ce_store;
     // column sums of op(B) weighted per K row (XC B, 256 x 256-tile kernel only): colsum[n] = sum_k colsum_w[k] * B[k][n]
     // (dd = sum_r c_r E'[r][v] of the fused softmax); colsum_w must be readable up to K rounded up to 16
@@ -284,11 +286,13 @@ hipError_t launch_ce_rows(hipStream_t s, const float* logits, int ld, int rows, 
 hipError_t launch_ce_rows_gated(hipStream_t s, const float* logits, int ld, int rows, int n_vocab, const int* tgt, float* lse, float* ce,
                                 float* dlogits, float inv_n, const int* done, int done_expect, int tile_rows, int* err_flag, int spin_cap, int blocks,
                                 int* next_row /* one int, zero before the launch: the rows are drawn from it */);
-constexpr float CE_RANGE = 60.0f;       // |largest logit of a row| the shift-free softmax of GemmArgs::ce_store is used for (exp(x) and its row sum stay normal fp32 numbers)
+// what the shift-free softmax of GemmArgs::ce_store is used for: e^-60 <= S = sum_v exp(x_v) <= 1e30 (the largest logit of a row within
+// about [-60, 69 - log(vocabulary)]) and exp(target logit) >= 1e-30 (its log is taken) -- E, S and c = 1 / (n S) stay normal fp32 numbers
+constexpr float CE_SUM_MIN = 8.0e-27f, CE_SUM_MAX = 1.0e30f, CE_TGT_MIN = 1.0e-30f;
 // Fused softmax of a train pass, second half (first: GemmArgs::ce_store): per row, from the partials -- lse, ce = lse - target logit,
 // S = sum_v exp(x_v), c = inv_n / S -> crow[row]; E[row][tgt] -= S, so that (softmax - onehot) * inv_n == c * E' for the WHOLE row
 // (dlogits is never written: dH = diag(c) (E' W^T), dW = (diag(c) Hout)^T E', dd = sum_r c_r E'[r]); hs_scaled[row][:] = c * hs[row][:].
-// A row whose largest logit is outside [-CE_RANGE, CE_RANGE] raises *err_flag = 2 and counts itself in *range_counter (host-mapped):
+// A row outside CE_SUM_MIN / CE_SUM_MAX / CE_TGT_MIN (or NaN) raises *err_flag = 2 and counts itself in *range_counter (host-mapped):
 // the step is skipped and repeated on launch_ce_rows.
 hipError_t launch_ce_finish(hipStream_t s, const float2* part, int nparts, const float* tgt_logit, const int* tgt, int rows, float inv_n,
                             float* E, int ld, float* lse, float* ce, float* crow, const float* hs, float* hs_scaled, int hp,

@@ -276,8 +276,9 @@ typedef struct fsmg_stats {
     int64_t xov_selfcheck_mismatches;   /* XCD-partitioned order: 16-byte words of the gated projection's logits that differed from the
                                            same GEMM recomputed on the serial path (the self-check of a handle's first passes);
                                            non-zero = that step was skipped and repeated, the handle keeps the serial order        */
-    int64_t softmax_range_rows;         /* rows whose largest logit was outside the range of the shift-free fused softmax: the step that
-                                           held them was skipped and repeated with the cross-entropy pass, which the handle keeps from then on */
+    int64_t softmax_range_rows;         /* rows outside the range of the shift-free fused softmax (sum_v exp(logit) within [e^-60, 1e30],
+                                           exp(target logit) >= 1e-30): the step that held them was skipped and repeated with the
+                                           cross-entropy pass, which the handle keeps from then on */
 } fsmg_stats;
 int fsmg_get_stats(fsmg_handle h, fsmg_stats* out);
 

@@ -47,7 +47,7 @@ def _run(**env_over):
 
 @pytest.mark.gpu
 def test_every_bf16_split_gemm_variant_gives_the_same_bits():
-    # FSMG_FUSED_SOFTMAX=0: the fused softmax of a train pass (DESIGN.md 10.10) exists in the 256 x 256-tile kernel only and is a
+    # FSMG_FUSED_SOFTMAX=0: the fused softmax of a train pass (DESIGN.md 10.8) exists in the 256 x 256-tile kernel only and is a
     # different (tolerance-equal, not bit-equal) arithmetic of the cross entropy -- with it on, WHICH softmax runs would follow the
     # GEMM variant; its own variants are compared below
     classic = dict(FSMG_FUSED_SOFTMAX='0')

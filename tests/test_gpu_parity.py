@@ -1282,10 +1282,12 @@ def test_fused_softmax_matches_the_cross_entropy_pass(order, monkeypatch):
     assert st['timeouts'] == 0 and st['softmax_range_rows'] == 0 and st['xov_selfcheck_mismatches'] == 0
 
 
-def test_fused_softmax_falls_back_when_a_logit_leaves_its_range():
-    """The fused softmax stores exp(logit) without a shift: fine while a row's largest logit stays within [-60, 60], checked per row
-    by k_ce_finish.  A bias of 100 on one word puts every row outside: the step is skipped on the device (no update), repeated with
-    the cross-entropy pass, and the handle keeps that pass from then on -- same losses as a handle that never used the fused form."""
+@pytest.mark.parametrize('case', ['row_sum_overflows', 'target_underflows'])
+def test_fused_softmax_falls_back_when_a_logit_leaves_its_range(case):
+    """The fused softmax stores exp(logit) without a shift: fine while a row's sum of them stays within [e^-60, 1e30] (its largest
+    logit within about [-60, 60]) and exp(target logit) >= 1e-30, checked per row by k_ce_finish.  A bias of 100 on one word puts every row outside: the step is skipped on the device (no update), repeated with
+    the cross-entropy pass, and the handle keeps that pass from then on -- same losses as a handle that never used the fused form.
+    A bias of -80 on half the vocabulary leaves the row sums alone but takes exp(target logit) of about half the rows below 1e-30."""
     over, N, K, Q = FULL['cfg-B']
     cfg = small_config(**dict(over, max_len=80))                       # 3600 rows: still on the 256 x 256-tile kernels
     eps = O.synthetic_episodes(3, N, K, Q, cfg['max_len'], cfg['input_size'], seed=102)
@@ -1294,7 +1296,10 @@ def test_fused_softmax_falls_back_when_a_logit_leaves_its_range():
     la0, lb0 = a.train_step(*eps[0]), b.train_step(*eps[0])
     assert a.debug_read('fused_softmax', 2)[1] == 1.0 and abs(la0 - lb0) <= 5e-6 * abs(lb0)
     for m in (a, b):
-        d = m.get_param('softmax_b'); d[7] = 100.0; m.set_param('softmax_b', d)
+        d = m.get_param('softmax_b')
+        if case == 'row_sum_overflows': d[7] = 100.0
+        else: d[:5000] = -80.0
+        m.set_param('softmax_b', d)
     a.debug_set('fallback_steps', 1)
     la, lb = a.train_step(*eps[1]), b.train_step(*eps[1])
     st = a.stats()

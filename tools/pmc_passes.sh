@@ -13,12 +13,13 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ
     # then k_lstm_*_xcd16<2>); f32cell: FSMG_XCD_OVERLAP=0 = the fp32 fused cell k_lstm_*_xcd<2> of the serial order
     rm -rf /tmp/pmc_${n}_$fam
     if [ $fam = f32cell ]; then export FSMG_XCD_OVERLAP=0; steps=3; else unset FSMG_XCD_OVERLAP; steps=6; fi
+    export FSMG_AUX_TRIES=0      # no concurrency probe: under --pmc dispatches are serialised and every candidate stream would be rejected (-> serial order)
     timeout 240 rocprofv3 --pmc $set --kernel-trace -f csv -d /tmp/pmc_${n}_$fam -o p -- python $R/tools/pmc_workload.py $steps > $O/${TAG}_pmc_${n}_$fam.log 2>&1
     echo "pass $n $fam: exit $?" >> $O/${TAG}_pmc_passes.log
     f=$(find /tmp/pmc_${n}_$fam -name "*counter_collection.csv" | head -1)
     if [ -n "$f" ]; then cp $f $O/${TAG}_pmc_${n}_$fam.csv; ARGS="$ARGS ${n}_$fam=$O/${TAG}_pmc_${n}_$fam.csv"; fi
   done
 done
-unset FSMG_XCD_OVERLAP
+unset FSMG_XCD_OVERLAP FSMG_AUX_TRIES
 python $R/tools/pmc_to_json.py $O/${TAG}_pmc.json $ARGS steps:bx3=6 steps:f32cell=3 > $O/${TAG}_pmc_summary.txt 2>&1
 tail -5 $O/${TAG}_pmc_passes.log
