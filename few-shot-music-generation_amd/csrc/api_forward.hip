@@ -52,12 +52,12 @@ GemmArgs logits_args(fsmg_model* h, int B, int t0, int t1) {
 }
 // fused softmax of a train pass (fsmg_model::fused_softmax): the projection's epilogue leaves E = exp(logit) + the per-slice partials ...
 inline void fused_softmax_args(fsmg_model* h, GemmArgs& g) {
-    g.ce_part = h->ce_part; g.ce_tgt = h->Y; g.ce_tgt_logit = h->tgt_logit; g.ce_nvocab = h->V1; g.ce_store = 1;
+    g.ce_part = h->ce_part; g.ce_nvocab = h->V1; g.ce_store = 1;      // (no target lookup in the epilogue: k_ce_finish reads the target's E)
 }
 // ... and one kernel turns them into lse, ce, the row scales and c_r * h_r, and patches E[r][y_r] (all rows of the pass)
 int ce_finish(fsmg_model* h, hipStream_t s, int B, int64_t rows) {
     ScopedTimer tm(h, "ce");
-    HIPCK(h, launch_ce_finish(s, h->ce_part, h->ce_nparts, h->tgt_logit, h->Y, (int)rows, (float)(1.0 / ((double)rows + 1e-12)), h->logits, h->V1p,
+    HIPCK(h, launch_ce_finish(s, h->ce_part, h->ce_nparts, h->Y, (int)rows, (float)(1.0 / ((double)rows + 1e-12)), h->logits, h->V1p,
                               h->lse, h->ce, h->crow, h->Hs[h->L - 1] + (size_t)B * h->Hp, h->Hsc, h->Hp, h->d_err, h->d_counters + 4));
     return FSMG_OK;
 }

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void k_ce_combine(const float2* __restrict__ p
 }
 
 // Second half of the fused softmax of a train pass (launch_ce_finish, fsmg_kernels.h).  One wave per row.
-__global__ __launch_bounds__(256) void k_ce_finish(const float2* __restrict__ part, int nparts, const float* __restrict__ tgt_logit,
+__global__ __launch_bounds__(256) void k_ce_finish(const float2* __restrict__ part, int nparts,
                                                    const int* __restrict__ tgt, int rows, float inv_n, float* E, int ld,
                                                    float* __restrict__ lse, float* __restrict__ ce, float* __restrict__ crow,
                                                    const float* __restrict__ hs, float* __restrict__ hs_scaled, int hp,
@@ -921,12 +921,12 @@ hipError_t launch_ce_combine(hipStream_t s, const float2* part, int nparts, cons
     return hipGetLastError();
 }
 
-hipError_t launch_ce_finish(hipStream_t s, const float2* part, int nparts, const float* tgt_logit, const int* tgt, int rows, float inv_n,
+hipError_t launch_ce_finish(hipStream_t s, const float2* part, int nparts, const int* tgt, int rows, float inv_n,
                             float* E, int ld, float* lse, float* ce, float* crow, const float* hs, float* hs_scaled, int hp,
                             int* err_flag, long long* range_counter) {
     if (rows <= 0) return hipSuccess;
     if ((hp & 3) != 0 || err_flag == nullptr || range_counter == nullptr) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_ce_finish, dim3((rows + 3) / 4), dim3(256), 0, s, part, nparts, tgt_logit, tgt, rows, inv_n, E, ld, lse, ce, crow,
+    hipLaunchKernelGGL(k_ce_finish, dim3((rows + 3) / 4), dim3(256), 0, s, part, nparts, tgt, rows, inv_n, E, ld, lse, ce, crow,
                        hs, hs_scaled, hp, err_flag, (unsigned long long*)range_counter);
     return hipGetLastError();
 }

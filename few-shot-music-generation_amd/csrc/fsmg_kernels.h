@@ -294,7 +294,7 @@ constexpr float CE_SUM_MIN = 8.0e-27f, CE_SUM_MAX = 1.0e30f, CE_TGT_MIN = 1.0e-3
 // (dlogits is never written: dH = diag(c) (E' W^T), dW = (diag(c) Hout)^T E', dd = sum_r c_r E'[r]); hs_scaled[row][:] = c * hs[row][:].
 // A row outside CE_SUM_MIN / CE_SUM_MAX / CE_TGT_MIN (or NaN) raises *err_flag = 2 and counts itself in *range_counter (host-mapped):
 // the step is skipped and repeated on launch_ce_rows.
-hipError_t launch_ce_finish(hipStream_t s, const float2* part, int nparts, const float* tgt_logit, const int* tgt, int rows, float inv_n,
+hipError_t launch_ce_finish(hipStream_t s, const float2* part, int nparts, const int* tgt, int rows, float inv_n,
                             float* E, int ld, float* lse, float* ce, float* crow, const float* hs, float* hs_scaled, int hp,
                             int* err_flag, long long* range_counter);
 // C[m][0 .. N) *= row_scale[m] (rows of N floats, N % 4 == 0)
