@@ -1,5 +1,5 @@
 // Drives the C-ABI from plain C++ (no Python, no torch) so that the host shim can run under AddressSanitizer:
-//   hipcc -fsanitize=address -shared-libsan -g -Iinclude tools/abi_asan_smoke.cpp few-shot-music-generation_amd/lib/libfsmg_asan.so -o tools/abi_asan_smoke.bin
+//   hipcc -fsanitize=address -shared-libsan -g -Iinclude tools/abi_asan_smoke.cpp -Lfew-shot-music-generation_amd/lib -lfsmg_asan -o tools/abi_asan_smoke.bin
 //   ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 LD_LIBRARY_PATH=few-shot-music-generation_amd/lib ./tools/abi_asan_smoke.bin
 // (PyTorch-ROCm exits silently at import under the ASan runtime, so the pytest suite runs under UBSan only.)
 #include <cstdio>
