@@ -156,11 +156,12 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
     const int t_cut = (T >= 4 * h->xov_tail && h->xov_tail > 0) ? (T - h->xov_tail) / h->xov_pub * h->xov_pub : T;
     GemmArgs ghead = logits_args(h, B, 0, t_cut);
     // Fused softmax: where dlogits would be written in place, nothing overlaps on a second stream chunk by chunk, and the weight
-    // gradient of the projection runs on the 256 x 256-tile kernel (the one with weighted column sums)
+    // gradient of the projection runs on the 256 x 256-tile kernel (the one with weighted column sums).  The projection itself may be
+    // any of the bf16-split kernels: they share the epilogue (store_tile_at) and the layout of the partials.
     h->fs_call = false;
-    if (want_dlogits && h->fused_softmax && !ov && h->bx3 && h->inplace_dlogits && h->Hsc != nullptr && t_cut == T) {
+    if (want_dlogits && h->fused_softmax && !ov && h->bx3 && h->inplace_dlogits && h->Hsc != nullptr && t_cut == T && mainl.lds_pad == 0) {
         h->fs_call = true;                   // (dw_args reads it)
-        h->fs_call = use_h_gemm(h, OP_XC, OP_XC, dw_args(h, B), mainl) && use_h_gemm(h, OP_KC, OP_XC, ghead, mainl);
+        h->fs_call = use_h_gemm(h, OP_XC, OP_XC, dw_args(h, B), mainl);
     }
     if (h->fs_call) fused_softmax_args(h, ghead);
     const bool xov = h->xov_call && (h->xov_parts & 1) && xcd && want_dlogits && !ov && xov_fits(ghead);
@@ -306,8 +307,10 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
         else if (!ce_tail) GEMMCK(ce_rows(h, s, B, 0, T, rows));
     } else if (h->fs_call) {
         {
-            ScopedTimer tm(h, "gemm_logits");
-            ghead.bx3 = 3;                                                     // (use_h_gemm said so above; K = Hp: never split)
+            ScopedTimer tm(h, "gemm_logits");                                  // the kernel the shape would get anyway (K = Hp: never split)
+            ghead.bx3 = h->bx3;
+            if (use_h_gemm(h, OP_KC, OP_XC, ghead, mainl)) ghead.bx3 = 3;
+            else if (use_ws_gemm(h, OP_KC, OP_XC, ghead, mainl)) { ghead.bx3 = 2; ghead.group_m = 4; }
             HIPCK(h, launch_gemm(s, OP_KC, OP_XC, ghead, 0));
         }
         GEMMCK(ce_finish(h, s, B, rows));

@@ -1430,9 +1430,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
 template <int AMODE, int BMODE>
 hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
-    // weighted column sums, exp(logit) stores: the 256 x 256-tile kernels only (the weights: their x-contiguous-operand instantiations)
+    // weighted column sums: the 256 x 256-tile kernels' x-contiguous-operand instantiations only; exp(logit) stores: the bf16-split kernels
     if (g.colsum_w != nullptr && !(g.bx3 == 3 && AMODE == OP_XC && BMODE == OP_XC && g.colsum != nullptr)) return hipErrorInvalidValue;
-    if (g.ce_store && !(g.bx3 == 3 && g.ce_part != nullptr)) return hipErrorInvalidValue;
+    if (g.ce_store && !(g.bx3 != 0 && g.ce_part != nullptr && g.ksplit <= 1)) return hipErrorInvalidValue;      // (every bf16-split kernel: one epilogue)
     if (g.xcd_first != 0 && g.bx3 == 3) {      // work-queue launch of the 256 x 256-tile kernel (one block per CU)
         if (g.work == nullptr || g.claim == nullptr || (g.xcd_first > 0 && g.stop == nullptr) || g.gather != nullptr || g.prof != nullptr) return hipErrorInvalidValue;
         const long long a_b = 4LL * g.lda * (AMODE == OP_KC ? g.M : g.K), b_b = 4LL * g.ldb * (BMODE == OP_KC ? g.N : g.K);

@@ -1247,16 +1247,20 @@ def test_every_handle_of_a_process_gets_a_second_stream_that_runs_beside_its_own
     assert all(m.stats()['timeouts'] == 0 for m in models)
 
 
-@pytest.mark.parametrize('order', ['partitioned', 'serial'])
-def test_fused_softmax_matches_the_cross_entropy_pass(order, monkeypatch):
-    """Round 5: where the projection-gradient GEMMs run on the 256 x 256-tile kernel a train pass never materialises
+REF_DEFAULT = (dict(input_size=10000, max_len=50, embedding_size=250, hidden_size=200, n_layers=1), 5, 5, 4)       # the reference's shipped dims
+
+
+@pytest.mark.parametrize('name,order', [('cfg-B', 'partitioned'), ('cfg-B', 'serial'), ('ref-default', 'serial'), ('cfg-C', 'serial')])
+def test_fused_softmax_matches_the_cross_entropy_pass(name, order, monkeypatch):
+    """Round 5: where the projection's weight gradient runs on the 256 x 256-tile kernel a train pass never materialises
     (softmax - onehot) / n: the projection's epilogue stores E = exp(logit) and per-slice partials, k_ce_finish derives lse, the loss,
     c_r = 1 / (n S_r), patches E[r][y_r] -= S_r and writes c_r h_r; dH = diag(c) (E' W^T), dW = (diag(c) Hout)^T E', dd = the c-weighted
     column sums of E'.  Against the same handle configuration with the cross-entropy pass (fused_softmax = 0), cfg-B full size, in the
     XCD-partitioned and in the serial order: losses to 2e-6, lse / ce to 1e-6, every gradient to 2e-5 of its largest element, three
-    updates on -- and against the fp64 oracle inside the tolerances of every other full-size test."""
+    updates on -- and against the fp64 oracle inside the tolerances of every other full-size test.  The projection itself may be any of
+    the bf16-split kernels (one epilogue): the 128-tile ones at the reference's shipped dims and at cfg-C (two layers of 1024)."""
     monkeypatch.setenv('FSMG_XCD_OVERLAP', '1' if order == 'partitioned' else '0')
-    over, N, K, Q = FULL['cfg-B']
+    over, N, K, Q = REF_DEFAULT if name == 'ref-default' else FULL[name]
     cfg = small_config(**over)
     B, T = N * (K + Q), cfg['max_len']
     eps = O.synthetic_episodes(4, N, K, Q, T, cfg['input_size'], seed=101)
@@ -1270,7 +1274,7 @@ def test_fused_softmax_matches_the_cross_entropy_pass(order, monkeypatch):
         ga, gb = a.get_grad(k), b.get_grad(k)
         assert np.abs(ga - gb).max() <= 2e-5 * np.abs(gb).max(), k
     params = f64_params(a)
-    loss, cache, grads, aux = cached_oracle_step(('fused', order), params, eps[0][0], eps[0][1], cfg)
+    loss, cache, grads, aux = cached_oracle_step(('fused', name, order), params, eps[0][0], eps[0][1], cfg)
     for k in grads:
         assert rel_max(a.get_grad(k), grads[k]) < 2e-4, k
     la, lb = a.apply_update(1.0), b.apply_update(1.0)
