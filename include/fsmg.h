@@ -299,7 +299,7 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
  *                       recurrent kernels are issued eagerly (default)
  *   "inplace_dlogits"   1 (default): a train pass's cross entropy writes dlogits over the logits it has just read ("logits" then
  *                       reads back as dlogits after a train pass), 0: two buffers
- *   "fused_softmax"     1 (default): train passes whose projection-gradient GEMMs run on the 256 x 256-tile kernel never materialise
+ *   "fused_softmax"     1 (default): train passes whose projection weight gradient runs on the 256 x 256-tile kernel never materialise
  *                       dlogits: the projection stores exp(logit), one kernel per pass derives lse / loss / row scales, the two GEMMs
  *                       apply them ("logits" / "dlogits" then read back exp(logit) with the target element reduced by the row sum);
  *                       0: the cross-entropy pass
