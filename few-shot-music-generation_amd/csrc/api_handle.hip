@@ -1,5 +1,6 @@
 // Handle life cycle (fsmg_create / fsmg_destroy), knobs, statistics, greedy decode.
 // Host-side C++ only (part of the C-ABI of libfsmg, include/fsmg.h); every kernel lives in gemm.hip / lstm_*.hip / elementwise.hip.
+#include <mutex>
 #include "fsmg_model.h"
 
 using namespace fsmg;
@@ -62,8 +63,38 @@ int settle_pending(fsmg_model* h) {
     return FSMG_OK;
 }
 
+namespace {
+std::mutex g_turn_mu;
+fsmg_model* g_turn_last[16] = {};         // per device: the handle whose call returned last
+bool turnstile_on() { static const bool on = !(std::getenv("FSMG_TURNSTILE") && std::atoi(std::getenv("FSMG_TURNSTILE")) == 0); return on; }
+}
+// (begin_call) behind what the handle that had the device before this one has issued so far
+static int take_turn(fsmg_model* h) {
+    if (!turnstile_on() || h->ev_turn == nullptr) return FSMG_OK;
+    std::lock_guard<std::mutex> lk(g_turn_mu);
+    fsmg_model*& last = g_turn_last[h->device & 15];
+    if (last != nullptr && last != h && last->stream != nullptr && !last->capturing.load()) {
+        HIPCK(h, hipEventRecord(last->ev_turn, last->stream));
+        HIPCK(h, hipEventRecord(last->ev_turn_aux, last->aux != nullptr ? last->aux : last->stream));
+        HIPCK(h, hipStreamWaitEvent(h->stream, last->ev_turn, 0));
+        HIPCK(h, hipStreamWaitEvent(h->stream, last->ev_turn_aux, 0));
+        if (h->aux != nullptr) {             // (this handle's second stream forks behind its first inside a call; what an earlier call left on it does not)
+            HIPCK(h, hipStreamWaitEvent(h->aux, last->ev_turn, 0));
+            HIPCK(h, hipStreamWaitEvent(h->aux, last->ev_turn_aux, 0));
+        }
+    }
+    last = h;
+    return FSMG_OK;
+}
+static void forget_turn(fsmg_model* h) {          // fsmg_destroy: nobody may wait on this handle's events any more
+    std::lock_guard<std::mutex> lk(g_turn_mu);
+    if (g_turn_last[h->device & 15] == h) g_turn_last[h->device & 15] = nullptr;
+}
+
 int begin_call(fsmg_model* h, bool keep_pending) {
     HIPCK(h, hipSetDevice(h->device));
+    const int rc = take_turn(h);
+    if (rc != FSMG_OK) return rc;
     return keep_pending ? FSMG_OK : settle_pending(h);
 }
 
@@ -173,6 +204,13 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         }
         if (const char* e = std::getenv("FSMG_AUX_BLOCKS")) { h->aux_blocks_per_cu = h->aux_blocks_persist = std::max(1, std::min(4, std::atoi(e))); h->aux_blocks_from_env = true; }
 #endif
+        if (hipEventCreateWithFlags(&h->ev_turn, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_turn_aux, hipEventDisableTiming) != hipSuccess) return bail(FSMG_ERR_HIP, "event create failed");
+        if (turnstile_on()) {      // the probe below asks whether two streams of this handle run side by side: not while another handle's pass has the chip
+            std::lock_guard<std::mutex> lk(g_turn_mu);
+            fsmg_model* last = g_turn_last[h->device & 15];
+            if (last != nullptr && last->stream != nullptr && !last->capturing.load()) { (void)hipStreamSynchronize(last->stream); if (last->aux) (void)hipStreamSynchronize(last->aux); }
+        }
         {
             static const int tries = std::getenv("FSMG_AUX_TRIES") ? std::max(0, std::min(32, std::atoi(std::getenv("FSMG_AUX_TRIES")))) : 8;
             if (pick_concurrent_aux(h, 0, tries) != FSMG_OK) { std::string e = h->err; return bail(FSMG_ERR_HIP, e); }
@@ -278,6 +316,7 @@ int fsmg_destroy(fsmg_handle h) {
     (void)begin_call(h);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->aux) hipStreamSynchronize(h->aux);
+    forget_turn(h);
     drain_timers(h);
     drop_graphs(h);
     if (h->scratch) hipFree(h->scratch);
@@ -301,6 +340,8 @@ int fsmg_destroy(fsmg_handle h) {
     if (h->ev_upd) hipEventDestroy(h->ev_upd);
     if (h->ev_side_fork) hipEventDestroy(h->ev_side_fork);
     if (h->ev_side) hipEventDestroy(h->ev_side);
+    if (h->ev_turn) hipEventDestroy(h->ev_turn);
+    if (h->ev_turn_aux) hipEventDestroy(h->ev_turn_aux);
 #ifdef FSMG_EXPERIMENTS
     if (h->ev_ce_fork) hipEventDestroy(h->ev_ce_fork);
     if (h->ev_ce) hipEventDestroy(h->ev_ce);

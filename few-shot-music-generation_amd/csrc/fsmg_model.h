@@ -9,6 +9,7 @@
 //   api_step.hip      train / eval / MAML-style entry points          api_comm.hip  RCCL glue (fsmg_comm_*)
 //   api_unigram.hip   unigram baseline                                 api_debug.hip debug reads, timers, clock probe
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
@@ -265,6 +266,10 @@ struct fsmg_model {
     bool tail_aside = true;
     bool side_pending = false;          // the auxiliary stream may still be reading the main lane's slabs (gemm() waits before it reuses them)
     hipEvent_t ev_side_fork = nullptr, ev_side = nullptr;
+    // take_turn (api_handle.hip): recorded on this handle's stream / auxiliary stream by the NEXT handle that takes the device, which then
+    // waits for them
+    hipEvent_t ev_turn = nullptr, ev_turn_aux = nullptr;
+    std::atomic<bool> capturing{false};      // run_graphed is between BeginCapture and EndCapture on `stream`: nobody else records on it
     std::string err;
     bool timing = false;
     std::string timing_only;
@@ -348,6 +353,13 @@ inline void drain_timers(fsmg_model* h) {
 // points pass keep_pending: their forward pass orders itself behind the update where it first reads the softmax parameters.
 int begin_call(fsmg_model* h, bool keep_pending = false);
 int settle_pending(fsmg_model* h);
+// One handle's passes at a time per device (begin_call -> take_turn, api_handle.hip).  The persistent kernels -- recurrence chains with
+// cross-CU hand-offs, gated work-queue GEMMs -- spin on CUs they hold and assume that their peers are resident; two handles of a process
+// whose calls overlap on the GPU (calls return before the work is done) time-share those CUs at best and run into the hand-off time-out
+// at worst (a skipped and repeated step: correct, slow).  So the first call of handle B after a call of handle A on the same device
+// records what A has issued so far (both of A's streams) and makes B's streams wait for it.  A process with one handle pays a mutex
+// and a pointer compare per call.  Calls on different handles from different threads AT THE SAME TIME are ordered behind the part of
+// the other call that had been issued, no more.  FSMG_TURNSTILE=0: off.
 #define BEGIN_CALL(h, ...)                                                           \
     do {                                                                             \
         const int rc_begin_ = fsmg_host::begin_call(h, ##__VA_ARGS__);               \
@@ -454,10 +466,12 @@ int run_graphed(fsmg_model* h, const std::string& key, F&& body) {
     if (it == h->graphs.end()) {
         hipGraph_t graph = nullptr;
         const int64_t x0 = h->n_xcd_launches, p0 = h->n_persist_launches, s0 = h->n_step_launches;
-        HIPCK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        h->capturing.store(true);
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { h->capturing.store(false); return fail(h, FSMG_ERR_HIP, "hipStreamBeginCapture failed"); }
         const int rc = body();
         { auto& c = h->graph_counts[key]; c.xcd = h->n_xcd_launches - x0; c.persist = h->n_persist_launches - p0; c.step = h->n_step_launches - s0; c.bwd_xcd = h->last_bwd_xcd; }
         const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        h->capturing.store(false);
         if (rc != FSMG_OK) { if (graph) hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess || graph == nullptr)
             return fail(h, FSMG_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));

@@ -1247,6 +1247,39 @@ def test_every_handle_of_a_process_gets_a_second_stream_that_runs_beside_its_own
     assert all(m.stats()['timeouts'] == 0 for m in models)
 
 
+def test_handles_of_one_process_take_turns_on_the_device():
+    """Calls return before their work is done, and the persistent kernels of a pass -- recurrence chains, gated work-queue GEMMs -- spin
+    on CUs they hold: two handles whose passes overlapped on the GPU would time-share those CUs at best and trip the hand-off time-out at
+    worst.  A call of one handle that follows a call of another on the same device therefore orders itself behind what that one had
+    issued (take_turn, csrc/api_handle.hip).  Three cfg-B handles stepped
+    round-robin WITHOUT a synchronize in between: no time-out, and every handle's losses and parameters are bit for bit those of the
+    same handle stepped alone."""
+    over, N, K, Q = FULL['cfg-B']
+    cfg = small_config(**dict(over, max_len=64))
+    eps = O.synthetic_episodes(4, N, K, Q, cfg['max_len'], cfg['input_size'], seed=93)
+
+    def make(i):
+        return new_model(dict(cfg, seed=3 + i), max_sequences=N * (K + Q))
+    alone = []
+    for i in range(3):
+        m = make(i)
+        for s_ in range(6):
+            m.train_step(*eps[(i + s_) % 4], want_loss=False)
+        alone.append({k: m.get_param(k).copy() for k in m.param_shapes})
+        m.close()
+    models = [make(i) for i in range(3)]
+    for s_ in range(6):
+        for i, m in enumerate(models):
+            m.train_step(*eps[(i + s_) % 4], want_loss=False)        # nothing waits for the GPU here
+            if i == 1:
+                m.debug_set('fallback_steps', 200)                   # (a cheap entry point between two passes takes its turn too)
+    for i, m in enumerate(models):
+        st = m.stats()
+        assert st['timeouts'] == 0 and st['steps_skipped_timeout'] == 0 and m.step == 6, (i, st)
+        for k, v in alone[i].items():
+            np.testing.assert_array_equal(m.get_param(k), v)
+
+
 REF_DEFAULT = (dict(input_size=10000, max_len=50, embedding_size=250, hidden_size=200, n_layers=1), 5, 5, 4)       # the reference's shipped dims
 
 
