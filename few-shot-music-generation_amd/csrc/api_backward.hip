@@ -149,13 +149,15 @@ int backward(fsmg_model* h, int B, int part) {
         const bool loss_in_batch = late.r.count > 0;
         if (loss_in_batch) GEMMCK(late.mean(h->ce, rows, h->G + h->n_flat + 1));
         GEMMCK(late.flush());
-        HIPCK(h, launch_embed_grad(ts, h->X, (int)rows, h->dXemb, h->Ep, h->G + h->off_emb, h->tok_first, h->tok_count));
-        h->tok_table_open = false;
-        const int nb = sqnorm_blocks(rows * h->Ep);
-        if (!dx_sq_done) HIPCK(h, launch_sqnorm_partials(ts, h->dXemb, rows * h->Ep, h->partials));
         // tail[0] = squared norm of the embedding-slice gradients, tail[1] = mean loss of the pass, tail[2] / tail[3] = time-out /
-        // token-range indicators
-        HIPCK(h, launch_sum_partials(ts, h->partials, nb, h->G + h->n_flat + 0, h->d_err, loss_in_batch ? nullptr : h->ce, (int)rows, h->G + h->n_flat + 1));
+        // token-range indicators: one block's work, which rides in the embedding gradient's first launch where the partials are there already
+        const int nb = sqnorm_blocks(rows * h->Ep);
+        const SumPartialsArgs sp{h->partials, nb, h->G + h->n_flat + 0, h->d_err, loss_in_batch ? nullptr : h->ce, (int)rows, h->G + h->n_flat + 1};
+        const bool sum_rides = dx_sq_done && h->dXpart != nullptr && h->tok_first != nullptr;
+        HIPCK(h, launch_embed_grad(ts, h->X, (int)rows, h->dXemb, h->Ep, h->G + h->off_emb, h->tok_first, h->tok_count, h->dXpart, sum_rides ? &sp : nullptr));
+        h->tok_table_open = false;
+        if (!dx_sq_done) HIPCK(h, launch_sqnorm_partials(ts, h->dXemb, rows * h->Ep, h->partials));
+        if (!sum_rides) HIPCK(h, launch_sum_partials(ts, sp.partials, sp.n, sp.dst, sp.flag_src, sp.ce, sp.ce_n, sp.loss_out));
         if (ts != s) {
             HIPCK(h, hipEventRecord(h->ev_side, ts));
             late.s = s;

@@ -72,6 +72,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);
     const int64_t o_lg = place(4 * rows * h->V1p), o_dlg = place(4 * rows * h->V1p), o_lse = place(4 * rows), o_ce = place(4 * rows);
     const int64_t o_dx = place(4 * rows * h->Ep);
+    const int64_t o_dxp = place(4 * rows * h->Ep);      // per-chunk partial rows of the heavy tokens' embedding gradient (launch_embed_grad)
     const int64_t o_hsc = place(4 * rows * Hp), o_crow = place(4 * (rows + 32));       // fused softmax: c_r * h_r, c_r
     const int nparts = 2 * ((h->V1p + 127) / 128);
     const int64_t o_cep = place(8 * rows * nparts), o_tl = place(4 * rows);
@@ -148,7 +149,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     HIPCK(h, hipMemsetAsync(s + o_hf[0], 0, (size_t)(o_dc - o_hf[0]), h->stream));
     h->dC = (float*)(s + o_dc); h->dH = (float*)(s + o_dh); h->logits = (float*)(s + o_lg);
     h->dlogits = (float*)(s + o_dlg);
-    h->lse = (float*)(s + o_lse); h->ce = (float*)(s + o_ce); h->dXemb = (float*)(s + o_dx);
+    h->lse = (float*)(s + o_lse); h->ce = (float*)(s + o_ce); h->dXemb = (float*)(s + o_dx); h->dXpart = (float*)(s + o_dxp);
     h->Hsc = (float*)(s + o_hsc); h->crow = (float*)(s + o_crow);
     HIPCK(h, hipMemsetAsync(h->crow, 0, 4 * (size_t)(rows + 32), h->stream));          // (the weights past the last row are read by a partial k tile, times zero)
     h->partials = (double*)(s + o_part);

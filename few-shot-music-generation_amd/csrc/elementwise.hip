@@ -191,23 +191,47 @@ __global__ void k_token_prep(const int* __restrict__ support, int n_support, con
                              int* __restrict__ Y, int* __restrict__ err_flag, int* __restrict__ tok_first, int* __restrict__ tok_count) {
     const int B = n_support + n_query;
     const long long total = (long long)B * T;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(i / T), t = (int)(i % T);
-        const int* row = (b < n_support) ? support + (long long)b * T : query + (long long)(b - n_support) * T;
-        int tok = row[t];
-        if (tok < 0 || tok >= vocab) {
-            atomicOr(err_flag, 1);
-            tok = min(max(tok, 0), vocab - 1);
+    // (block-uniform trip count: the occurrence-table code below talks to the other lanes of the wave)
+    for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < total; i0 += (long long)gridDim.x * blockDim.x) {
+        const long long i = i0 + threadIdx.x;
+        const bool valid = i < total;
+        const int b = valid ? (int)(i / T) : 0, t = valid ? (int)(i % T) : 0;
+        int tok = 0;
+        if (valid) {
+            const int* row = (b < n_support) ? support + (long long)b * T : query + (long long)(b - n_support) * T;
+            tok = row[t];
+            if (tok < 0 || tok >= vocab) {
+                atomicOr(err_flag, 1);
+                tok = min(max(tok, 0), vocab - 1);
+            }
+            Y[(long long)t * B + b] = tok;
+            if (t + 1 < T) X[(long long)(t + 1) * B + b] = tok;
+            if (t == 0) X[b] = start_word;
         }
-        Y[(long long)t * B + b] = tok;
-        if (t + 1 < T) X[(long long)(t + 1) * B + b] = tok;
-        if (t == 0) X[b] = start_word;
         // occurrence table of the input ids (train passes): first position and count per token -- integer atomics, the result
         // does not depend on their order.  k_embed_grad's owner blocks read it and put it back to (INT_MAX, 0).
         if (tok_first != nullptr) {
-            if (t + 1 < T) { atomicMin(tok_first + tok, (int)((long long)(t + 1) * B + b)); atomicAdd(tok_count + tok, 1); }
-            if (t == 0) { atomicMin(tok_first + start_word, b); atomicAdd(tok_count + start_word, 1); }
+            // Real data repeats: a wave of 64 consecutive steps of one song inside its zero padding holds ONE token, and 2 000 atomics on
+            // one word cost 27 us (measured on padded Zipf episodes).  Two rounds of "the lanes that hold the first pending lane's token
+            // send one atomic": min of their positions, sum of their counts -- integer atomics, the result does not depend on the grouping.
+            bool pending = valid && t + 1 < T;
+            const int pos = (int)((long long)(t + 1) * B + b);
+#pragma unroll 1
+            for (int round = 0; round < 2; ++round) {
+                const unsigned long long act = __ballot(pending);
+                if (act == 0) break;
+                const int lead = __ffsll((long long)act) - 1;
+                const int ltok = __shfl(tok, lead);
+                const bool mine = pending && tok == ltok;
+                const unsigned long long grp = __ballot(mine);
+                int mpos = mine ? pos : 0x7FFFFFFF;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mpos = min(mpos, __shfl_xor(mpos, o));
+                if (mine && (int)(threadIdx.x & 63) == __ffsll((long long)grp) - 1) { atomicMin(tok_first + ltok, mpos); atomicAdd(tok_count + ltok, __popcll(grp)); }
+                if (mine) pending = false;
+            }
+            if (pending) { atomicMin(tok_first + tok, pos); atomicAdd(tok_count + tok, 1); }
+            if (valid && t == 0) { atomicMin(tok_first + start_word, b); atomicAdd(tok_count + start_word, 1); }
         }
     }
 }
@@ -491,8 +515,103 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ c
 // once it has seen tok_count[X[r]] occurrences -- at cfg-B three positions in four hold a token that occurs once, whose
 // block copies one row; without the table every block scanned all earlier positions for a duplicate and all later ones
 // for more occurrences (25 us for 5.9 MB).  The owner resets its table entry, so a completed pass leaves the table clean.
+// (k_sum_partials below; also the last block of k_embed_grad_chunks, which would otherwise be a launch with nothing to do on uniform data)
+__device__ __forceinline__ void sum_partials_body(const double* __restrict__ partials, int n, float* dst,
+                                                  const int* flag_src, const float* __restrict__ ce, int ce_n, float* loss_out) {
+    __shared__ double sh[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += partials[i];
+    s = wave_sum_d(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        dst[0] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+        if (flag_src != nullptr) { dst[2] = (*flag_src == 2) ? 1.0f : 0.0f; dst[3] = (*flag_src == 1) ? 1.0f : 0.0f; dst[4] = 0.0f; }
+    }
+    if (ce == nullptr) return;
+    // the mean loss of a train pass (k_loss_reduce with one group: same order, same bits) -- nobody reads it before the
+    // step's last kernels, so it rides here instead of costing a launch behind the cross entropy
+    __syncthreads();
+    double l = 0.0;
+    for (int i0 = tid; i0 < ce_n; i0 += 256 * 16) {        // sixteen loads in flight, added in index order (the order of k_loss_reduce)
+        float b[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) b[k] = (i0 + 256 * k < ce_n) ? ce[i0 + 256 * k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (i0 + 256 * k < ce_n) l += (double)b[k];
+    }
+    l = wave_sum_d(l);
+    if (lane == 0) sh[wave] = l;
+    __syncthreads();
+    if (tid == 0) *loss_out = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / ((double)ce_n + 1e-12));
+}
+
+
+// Heavy tokens.  Real data is not uniform: the zero padding behind a song's end and the most frequent words occur thousands of times
+// per pass (padded Zipf episodes at cfg-B: 2 000+ of 5 760 positions hold token 0), and an owner block that adds 2 000 rows one
+// after the other took 736 us of a 1.6 ms step.  A token with more than EMBED_HEAVY occurrences is therefore summed in two levels:
+// k_embed_grad_chunks -- the block of the token's first occurrence INSIDE each 256-position chunk adds the chunk's occurrences in
+// position order into part[that position] -- and the owner in k_embed_grad adds those partial rows in chunk order.  Fixed order
+// either way; which path a token takes depends on its count only.
+constexpr int EMBED_HEAVY = 48;
+__global__ __launch_bounds__(256) void k_embed_grad_chunks(const int* __restrict__ X, int n, const float* __restrict__ dX, int Ep,
+                                                           float* __restrict__ part, const int* __restrict__ tok_count, const SumPartialsArgs sp) {
+    // one block per 256-position chunk (uniform data: 23 blocks that find nothing to do); the heavy tokens of the chunk one after the other.
+    // One more block does what k_sum_partials would do in a launch of its own right behind (sp.dst != nullptr): it depends on nothing here.
+    if (blockIdx.x == (unsigned)((n + 255) / 256)) { sum_partials_body(sp.partials, sp.n, sp.dst, sp.flag_src, sp.ce, sp.ce_n, sp.loss_out); return; }
+    __shared__ unsigned long long mask[4];
+    const int base = blockIdx.x * 256, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = base + tid;
+    const int tok = (i < n) ? X[i] : -1;
+    bool pending = (i < n) && tok_count[tok] > EMBED_HEAVY;
+    for (;;) {
+        const unsigned long long pb = __ballot(pending);
+        if (lane == 0) mask[wave] = pb;
+        __syncthreads();
+        int first = -1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) if (first < 0 && mask[w]) first = 64 * w + __ffsll((long long)mask[w]) - 1;
+        __syncthreads();
+        if (first < 0) break;                                   // (block-uniform: every thread read the same four words)
+        const int tk = X[base + first];
+        const bool hit = pending && tok == tk;                   // every occurrence of tk in the chunk (all of them are still pending)
+        const unsigned long long hb = __ballot(hit);
+        if (lane == 0) mask[wave] = hb;
+        __syncthreads();
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned long long mk = mask[w];
+            while (mk) {                    // four rows' loads in flight, added in position order (a row at a time waited ~0.7 us each)
+                int bits[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { bits[k] = mk ? __ffsll((long long)mk) - 1 : -1; mk &= mk - 1; }
+                float v[4][4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float* src = dX + (long long)(base + 64 * w + max(bits[k], 0)) * Ep;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[k][c] = (bits[k] >= 0 && tid + 256 * c < Ep) ? src[tid + 256 * c] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (bits[k] >= 0) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c] += v[k][c];
+                    }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (tid + 256 * c < Ep) part[(long long)(base + first) * Ep + tid + 256 * c] = acc[c];
+        if (hit) pending = false;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_embed_grad(const int* __restrict__ X, int n, const float* __restrict__ dX,
-                                                    int Ep, float* __restrict__ dEmb, int* __restrict__ tok_first, int* __restrict__ tok_count) {
+                                                    int Ep, float* __restrict__ dEmb, int* __restrict__ tok_first, int* __restrict__ tok_count,
+                                                    const float* __restrict__ part) {
     __shared__ unsigned long long mask[4];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tok = X[r];
@@ -500,6 +619,35 @@ __global__ __launch_bounds__(256) void k_embed_grad(const int* __restrict__ X, i
     if (tok_first != nullptr) {
         if (tok_first[tok] != r) return;        // (uniform: every thread reads the same word)
         want = tok_count[tok];
+        if (part != nullptr && want > EMBED_HEAVY) {        // heavy token: the chunks' partial rows (k_embed_grad_chunks), chunk by chunk
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            int found = 0;
+            for (int base = r & ~255; base < n && found < want; base += 256) {
+                const int i = base + tid;
+                const bool hit = (i < n) && (X[i] == tok);
+                const unsigned long long bal = __ballot(hit);
+                if (lane == 0) mask[wave] = bal;
+                __syncthreads();
+                int first = -1;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    found += __popcll(mask[w]);
+                    if (first < 0 && mask[w]) first = 64 * w + __ffsll((long long)mask[w]) - 1;
+                }
+                if (first >= 0) {
+                    const float* src = part + (long long)(base + first) * Ep;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (tid + 256 * c < Ep) acc[c] += src[tid + 256 * c];
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (tid + 256 * c < Ep) dEmb[(long long)tok * Ep + tid + 256 * c] = acc[c];
+            if (tid == 0) { tok_first[tok] = 0x7FFFFFFF; tok_count[tok] = 0; }
+            return;
+        }
     } else {
         // earlier duplicate? then another block owns this token
         int dup = 0;
@@ -667,33 +815,7 @@ __global__ void k_step_increment(const StepIncArgs a) {
 // are garbage
 __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partials, int n, float* dst,
                                                       const int* flag_src, const float* __restrict__ ce, int ce_n, float* loss_out) {
-    __shared__ double sh[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double s = 0.0;
-    for (int i = tid; i < n; i += 256) s += partials[i];
-    s = wave_sum_d(s);
-    if (lane == 0) sh[wave] = s;
-    __syncthreads();
-    if (tid == 0) {
-        dst[0] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
-        if (flag_src != nullptr) { dst[2] = (*flag_src == 2) ? 1.0f : 0.0f; dst[3] = (*flag_src == 1) ? 1.0f : 0.0f; dst[4] = 0.0f; }
-    }
-    if (ce == nullptr) return;
-    // the mean loss of a train pass (k_loss_reduce with one group: same order, same bits) -- nobody reads it before the
-    // step's last kernels, so it rides here instead of costing a launch behind the cross entropy
-    __syncthreads();
-    double l = 0.0;
-    for (int i0 = tid; i0 < ce_n; i0 += 256 * 16) {        // sixteen loads in flight, added in index order (the order of k_loss_reduce)
-        float b[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) b[k] = (i0 + 256 * k < ce_n) ? ce[i0 + 256 * k] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) if (i0 + 256 * k < ce_n) l += (double)b[k];
-    }
-    l = wave_sum_d(l);
-    if (lane == 0) sh[wave] = l;
-    __syncthreads();
-    if (tid == 0) *loss_out = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / ((double)ce_n + 1e-12));
+    sum_partials_body(partials, n, dst, flag_src, ce, ce_n, loss_out);
 }
 
 // ---------------------------------------------------------------- shader-clock probe
@@ -945,10 +1067,18 @@ hipError_t launch_loss_reduce(hipStream_t s, const float* ce, int T, int B, int 
     return hipGetLastError();
 }
 
-hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX, int Ep, float* dEmb, int* tok_first, int* tok_count) {
-    if (n <= 0) return hipSuccess;
+hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX, int Ep, float* dEmb, int* tok_first, int* tok_count, float* part,
+                             const SumPartialsArgs* sum) {
+    if (n <= 0) return sum != nullptr ? hipErrorInvalidValue : hipSuccess;
     if (Ep > 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_embed_grad, dim3(n), dim3(256), 0, s, X, n, dX, Ep, dEmb, tok_first, tok_count);
+    if (tok_first == nullptr || tok_count == nullptr) part = nullptr;       // (the two-level sum of heavy tokens goes by the occurrence table)
+    if (part == nullptr && sum != nullptr) return hipErrorInvalidValue;
+    if (part != nullptr) {
+        SumPartialsArgs sp{};
+        if (sum != nullptr) sp = *sum;
+        hipLaunchKernelGGL(k_embed_grad_chunks, dim3((n + 255) / 256 + (sum != nullptr ? 1 : 0)), dim3(256), 0, s, X, n, dX, Ep, part, tok_count, sp);
+    }
+    hipLaunchKernelGGL(k_embed_grad, dim3(n), dim3(256), 0, s, X, n, dX, Ep, dEmb, tok_first, tok_count, part);
     return hipGetLastError();
 }
 

@@ -307,7 +307,12 @@ hipError_t launch_loss_reduce(hipStream_t s, const float* ce, int T, int B, int 
 // dEmb[tok] = sum over occurrences r (increasing r) of dX[r]; dEmb must be zero-filled before
 // tok_first / tok_count: the occurrence table launch_token_prep filled for this X (nullptr: every block scans for duplicates);
 // the owners put their entries back to (INT_MAX, 0)
-hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX, int Ep, float* dEmb, int* tok_first = nullptr, int* tok_count = nullptr);
+// part (with the table only): [n][Ep] scratch -- a token with more than 48 occurrences (padding, the most frequent words of real data)
+// is summed in two levels, per 256-position chunk into part[first position of the chunk] and then chunk by chunk (k_embed_grad_chunks)
+// sum (with part only): launch_sum_partials' work as one more block of the first launch instead of a launch of its own behind the second
+struct SumPartialsArgs { const double* partials; int n; float* dst; const int* flag_src; const float* ce; int ce_n; float* loss_out; };
+hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX, int Ep, float* dEmb, int* tok_first = nullptr, int* tok_count = nullptr,
+                             float* part = nullptr, const SumPartialsArgs* sum = nullptr);
 // partial sums of squares (double) of x[0..n) into partials[pofs .. pofs+nblocks); returns nblocks via out param
 int sqnorm_blocks(long long n);
 hipError_t launch_sqnorm_partials(hipStream_t s, const float* x, long long n, double* partials);

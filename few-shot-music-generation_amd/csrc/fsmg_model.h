@@ -83,7 +83,7 @@ struct fsmg_model {
     int* d_tok = nullptr; int *X = nullptr, *Y = nullptr;
     std::vector<float*> Z, Hs, Cs;
     float2* ce_part = nullptr; float* tgt_logit = nullptr; int ce_nparts = 0;
-    float *dC = nullptr, *dH = nullptr, *logits = nullptr, *dlogits = nullptr, *lse = nullptr, *ce = nullptr, *dXemb = nullptr;
+    float *dC = nullptr, *dH = nullptr, *logits = nullptr, *dlogits = nullptr, *lse = nullptr, *ce = nullptr, *dXemb = nullptr, *dXpart = nullptr;
     double* partials = nullptr;
     int partials_cap = 0;
     std::vector<float*> HF;             // fragment-ordered h per layer: [T+1][ceil(B/16)*16][Hp]
