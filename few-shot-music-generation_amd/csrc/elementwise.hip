@@ -561,6 +561,7 @@ __global__ __launch_bounds__(256) void k_embed_grad_chunks(const int* __restrict
     // One more block does what k_sum_partials would do in a launch of its own right behind (sp.dst != nullptr): it depends on nothing here.
     if (blockIdx.x == (unsigned)((n + 255) / 256)) { sum_partials_body(sp.partials, sp.n, sp.dst, sp.flag_src, sp.ce, sp.ce_n, sp.loss_out); return; }
     __shared__ unsigned long long mask[4];
+    __shared__ __attribute__((aligned(16))) float wsum[4][1024];
     const int base = blockIdx.x * 256, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = base + tid;
     const int tok = (i < n) ? X[i] : -1;
     bool pending = (i < n) && tok_count[tok] > EMBED_HEAVY;
@@ -578,32 +579,43 @@ __global__ __launch_bounds__(256) void k_embed_grad_chunks(const int* __restrict
         const unsigned long long hb = __ballot(hit);
         if (lane == 0) mask[wave] = hb;
         __syncthreads();
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // every wave adds the rows of ITS 64 positions (lane = a float4 of the row; four rows' loads in flight), the four wave sums are added
+        // in wave order: a fixed order again, and the padding's ~100 rows of a chunk cost 25 dependent adds instead of 100
+        {
+            float4 a4[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            unsigned long long mk = mask[w];
-            while (mk) {                    // four rows' loads in flight, added in position order (a row at a time waited ~0.7 us each)
+            for (int c = 0; c < 4; ++c) a4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned long long mk = mask[wave];
+            const int nf4 = Ep >> 2;                       // float4 per row (Ep % 4 == 0, <= 1024)
+            while (mk) {
                 int bits[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { bits[k] = mk ? __ffsll((long long)mk) - 1 : -1; mk &= mk - 1; }
-                float v[4][4];
+                float4 v[4][4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float* src = dX + (long long)(base + 64 * w + max(bits[k], 0)) * Ep;
+                    const float4* src = reinterpret_cast<const float4*>(dX + (long long)(base + 64 * wave + max(bits[k], 0)) * Ep);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[k][c] = (bits[k] >= 0 && tid + 256 * c < Ep) ? src[tid + 256 * c] : 0.0f;
+                    for (int c = 0; c < 4; ++c) v[k][c] = (bits[k] >= 0 && lane + 64 * c < nf4) ? src[lane + 64 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (bits[k] >= 0) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[c] += v[k][c];
+                        for (int c = 0; c < 4; ++c) { a4[c].x += v[k][c].x; a4[c].y += v[k][c].y; a4[c].z += v[k][c].z; a4[c].w += v[k][c].w; }
                     }
             }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (lane + 64 * c < nf4) reinterpret_cast<float4*>(&wsum[wave][0])[lane + 64 * c] = a4[c];
         }
+        __syncthreads();
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (tid + 256 * c < Ep) part[(long long)(base + first) * Ep + tid + 256 * c] = acc[c];
+            if (tid + 256 * c < Ep) {
+                const int col = tid + 256 * c;
+                part[(long long)(base + first) * Ep + col] = ((wsum[0][col] + wsum[1][col]) + wsum[2][col]) + wsum[3][col];
+            }
         if (hit) pending = false;
         __syncthreads();
     }
@@ -1071,7 +1083,7 @@ hipError_t launch_embed_grad(hipStream_t s, const int* X, int n, const float* dX
                              const SumPartialsArgs* sum) {
     if (n <= 0) return sum != nullptr ? hipErrorInvalidValue : hipSuccess;
     if (Ep > 1024) return hipErrorInvalidValue;
-    if (tok_first == nullptr || tok_count == nullptr) part = nullptr;       // (the two-level sum of heavy tokens goes by the occurrence table)
+    if (tok_first == nullptr || tok_count == nullptr || (Ep & 3) != 0 || ((uintptr_t)dX & 15) != 0) part = nullptr;       // (the two-level sum of heavy tokens goes by the occurrence table; rows as float4)
     if (part == nullptr && sum != nullptr) return hipErrorInvalidValue;
     if (part != nullptr) {
         SumPartialsArgs sp{};

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A long cfg-B training run on the default path (XCD-partitioned order, fused softmax): the loss of a small pool of structured
+"""A long training run (cfg-B dims; LONG_RUN_CONFIG=cfg-C | ref-default for the others) on the default path (XCD-partitioned order, fused softmax): the loss of a small pool of structured
 synthetic episodes must go down, nothing may be skipped, and the tallies that would say a silent fall-back happened must stay zero.
    python tools/long_run.py [steps]      -> loss every 250 steps, fsmg_stats at the end, episodes/s of the whole run"""
 import os, sys, time
@@ -10,7 +10,8 @@ import bench
 from fsmg.binding import FsmgModel
 from oracle import lstm_oracle as O
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-cfg = dict(bench.CFG_B, lr=1e-3)
+which = os.environ.get('LONG_RUN_CONFIG', 'cfg-B')        # cfg-B | cfg-C | ref-default
+cfg = dict(bench.CFG_B if which == 'cfg-B' else bench.OTHER[which][0], lr=1e-3)
 eps = O.synthetic_episodes(32, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=11, realistic=True)
 m = FsmgModel(cfg); m.init_params(3)
 first = float(np.mean([m.eval_step(q) for _, q in eps[:8]]))
