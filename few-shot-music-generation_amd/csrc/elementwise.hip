@@ -189,9 +189,10 @@ __global__ __launch_bounds__(256) void k_multi_op(const MultiOps r) {
 __global__ void k_token_prep(const int* __restrict__ support, int n_support, const int* __restrict__ query,
                              int n_query, int T, int vocab, int start_word, int* __restrict__ X,
                              int* __restrict__ Y, int* __restrict__ err_flag, int* __restrict__ tok_first, int* __restrict__ tok_count) {
+    __shared__ int s_key[512], s_cnt[512], s_min[512];
     const int B = n_support + n_query;
     const long long total = (long long)B * T;
-    // (block-uniform trip count: the occurrence-table code below talks to the other lanes of the wave)
+    // (block-uniform trip count: the occurrence-table code below synchronises the block)
     for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < total; i0 += (long long)gridDim.x * blockDim.x) {
         const long long i = i0 + threadIdx.x;
         const bool valid = i < total;
@@ -211,26 +212,28 @@ __global__ void k_token_prep(const int* __restrict__ support, int n_support, con
         // occurrence table of the input ids (train passes): first position and count per token -- integer atomics, the result
         // does not depend on their order.  k_embed_grad's owner blocks read it and put it back to (INT_MAX, 0).
         if (tok_first != nullptr) {
-            // Real data repeats: a wave of 64 consecutive steps of one song inside its zero padding holds ONE token, and 2 000 atomics on
-            // one word cost 27 us (measured on padded Zipf episodes).  Two rounds of "the lanes that hold the first pending lane's token
-            // send one atomic": min of their positions, sum of their counts -- integer atomics, the result does not depend on the grouping.
-            bool pending = valid && t + 1 < T;
-            const int pos = (int)((long long)(t + 1) * B + b);
+            // Real data repeats: the zero padding behind a song's end and the frequent words -- 2 000 atomics on ONE word of the table cost
+            // 27 us per pass on padded Zipf episodes.  The block's 256 positions meet in an LDS hash table first (512 slots, linear probing,
+            // LDS atomics), and every occupied slot sends one pair of global atomics: integer min / add, the table does not depend on the
+            // grouping.  (A position that finds no slot in eight probes goes to the global table itself.)
+            for (int j = threadIdx.x; j < 512; j += blockDim.x) { s_key[j] = -1; s_cnt[j] = 0; s_min[j] = 0x7FFFFFFF; }
+            __syncthreads();
+            if (valid && t + 1 < T) {
+                const int pos = (int)((long long)(t + 1) * B + b);
+                unsigned slot = ((unsigned)tok * 2654435761u) >> 23;
+                bool placed = false;
 #pragma unroll 1
-            for (int round = 0; round < 2; ++round) {
-                const unsigned long long act = __ballot(pending);
-                if (act == 0) break;
-                const int lead = __ffsll((long long)act) - 1;
-                const int ltok = __shfl(tok, lead);
-                const bool mine = pending && tok == ltok;
-                const unsigned long long grp = __ballot(mine);
-                int mpos = mine ? pos : 0x7FFFFFFF;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mpos = min(mpos, __shfl_xor(mpos, o));
-                if (mine && (int)(threadIdx.x & 63) == __ffsll((long long)grp) - 1) { atomicMin(tok_first + ltok, mpos); atomicAdd(tok_count + ltok, __popcll(grp)); }
-                if (mine) pending = false;
+                for (int probe = 0; probe < 8 && !placed; ++probe) {
+                    const int prev = atomicCAS(&s_key[slot], -1, tok);
+                    if (prev == -1 || prev == tok) { atomicAdd(&s_cnt[slot], 1); atomicMin(&s_min[slot], pos); placed = true; }
+                    else slot = (slot + 1) & 511u;
+                }
+                if (!placed) { atomicMin(tok_first + tok, pos); atomicAdd(tok_count + tok, 1); }
             }
-            if (pending) { atomicMin(tok_first + tok, pos); atomicAdd(tok_count + tok, 1); }
+            __syncthreads();
+            for (int j = threadIdx.x; j < 512; j += blockDim.x)
+                if (s_key[j] >= 0) { atomicMin(tok_first + s_key[j], s_min[j]); atomicAdd(tok_count + s_key[j], s_cnt[j]); }
+            __syncthreads();
             if (valid && t == 0) { atomicMin(tok_first + start_word, b); atomicAdd(tok_count + start_word, 1); }
         }
     }
