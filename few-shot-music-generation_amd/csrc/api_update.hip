@@ -183,7 +183,7 @@ void on_timeout(fsmg_model* h) {
             hipStreamSynchronize(h->stream);
             if (h->aux) hipStreamSynchronize(h->aux);
             drop_graphs(h);                       // (a captured pass holds the fused path)
-            fprintf(stderr, "[fsmg] fused softmax: a row's largest logit is outside [-60, 60] (%lld rows so far): the step is repeated, "
+            fprintf(stderr, "[fsmg] fused softmax: a row's sum of exp(logit) or its target's exp(logit) left the fp32 range of the shift-free form (%lld rows so far): the step is repeated, "
                             "cross-entropy pass with the shifted softmax from here on\n", (long long)h->host_counters[4]);
         }
     }

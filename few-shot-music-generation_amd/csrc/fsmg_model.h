@@ -237,8 +237,9 @@ struct fsmg_model {
     // per-row kernel (k_ce_finish) derives lse / ce / c_r = 1 / (n S_r), patches E[r][y_r] -= S_r and writes c_r * h_r; then
     // dH = diag(c) (E' W^T) (the scale rides in dH's slab sum), dW = (diag(c) Hout)^T E', dd = sum_r c_r E'[r] (weighted column sums in
     // the dW kernel): (softmax - onehot) / n is never materialised and the 460 MB cross-entropy pass is gone.  Taken where the
-    // projection-gradient GEMMs run on the 256 x 256-tile kernel (use_h_gemm) and dlogits are in place; a row whose largest logit
-    // leaves [-60, 60] makes the step fall back to the shifted softmax (launch_ce_rows) for good on this handle.
+    // projection's weight gradient runs on the 256 x 256-tile kernel (use_h_gemm; the projection itself: any bf16-split kernel) and
+    // dlogits are in place; a row whose sum of exp(logit) leaves [e^-60, 1e30] or whose exp(target logit) is below 1e-30 (CE_SUM_MIN /
+    // CE_SUM_MAX / CE_TGT_MIN) makes the step fall back to the shifted softmax (launch_ce_rows) for good on this handle.
     // FSMG_FUSED_SOFTMAX=0 / fsmg_debug_set("fused_softmax", 0): the cross-entropy pass of rounds 1-4.
     bool fused_softmax = true;
     bool fs_call = false;               // the pass in flight takes it (forward() decides, backward() follows)
