@@ -91,6 +91,20 @@ def synthetic_episodes(n_episodes, N, K, Q, T, vocab, seed):
             for _ in range(n_episodes)]
 
 
+def padded_zipf_episodes(n_episodes, N, K, Q, T, vocab, seed):
+    """What real lyrics / MIDI episodes look like instead of SURVEY 8(d)'s uniform pool: word ids Zipf(1.1), song length U[T/4, T], zero
+    padded to T -- a third of a pass's positions hold token 0, the next twenty words 50-400 each (the embedding
+    gradient and the occurrence table are the kernels that care)."""
+    rng = np.random.RandomState(seed)
+
+    def songs(n):
+        a = np.minimum(rng.zipf(1.1, size=(N, n, T)) - 1, vocab - 1).astype(np.int32)
+        lens = rng.randint(max(1, T // 4), T + 1, size=(N, n))
+        a[np.arange(T)[None, None, :] >= lens[:, :, None]] = 0
+        return a
+    return [(songs(K), songs(Q)) for _ in range(n_episodes)]
+
+
 def hbm_traffic(variant=None):
     """(bytes, source): HBM bytes per launch of the fused-cell kernels as RECORDED by the committed rocprofv3 PMC passes
     (tools/pmc_passes.sh -> profiles/r05_pmc.json: raw FETCH_SIZE + WRITE_SIZE per kernel INSTANTIATION, separate passes) -- counters
@@ -173,19 +187,24 @@ def step_roofline(cfg, B, gf, ms_per_step, fused_softmax=False):
 
 
 def other_configs(log, steps=20, warmup=5):
-    """cfg-C, cfg-D's per-rank workload (20-way 1-shot, 100 rows), cfg-E (MAML-style step) and the reference's default dims for `steps`
+    """(+ cfg-B and the reference's default dims on a pool of zero-padded Zipf songs: `--pool padded-zipf`)
+    cfg-C, cfg-D's per-rank workload (20-way 1-shot, 100 rows), cfg-E (MAML-style step) and the reference's default dims for `steps`
     train steps each, plus cfg-B in the SERIAL order (FSMG_XCD_OVERLAP=0: the fp32 XCD-local fused cell chip-wide, the number the
     north star's >= 0.30 is about) with the cell kernels event-timed.  Each leg is this script again in a process of its own
     (`--config X --steps 20 --warmup 5`, one timed region, 1.5 s): what a user gets is a fresh process, and a leg must not depend on
     what the process did before it (round 5 found handles 5, 7, 9 of a process 32-45 % slower through the priority of a stream:
     DESIGN.md 10.4 -- fixed, the isolation stays).  Per leg: value, ms_per_step, guard.ok, roofline_step.frac."""
     import subprocess
-    legs = [(n, n, {}) for n in ('cfg-C', 'cfg-D', 'cfg-E', 'ref-default')] + [('cfg-B-serial-order', 'cfg-B', {'FSMG_XCD_OVERLAP': '0'})]
+    legs = [(n, n, {}) for n in ('cfg-C', 'cfg-D', 'cfg-E', 'ref-default')] + [('cfg-B-serial-order', 'cfg-B', {'FSMG_XCD_OVERLAP': '0'}),
+                                                                                  ('cfg-B-padded-zipf-pool', 'cfg-B', {'_pool': 'padded-zipf'}),
+                                                                                  ('ref-default-padded-zipf-pool', 'ref-default', {'_pool': 'padded-zipf'})]
     res = {}
     for name, config, env_over in legs:
         t_leg = time.perf_counter()
+        env_over = dict(env_over)
+        pool = env_over.pop('_pool', 'uniform')
         env = dict(os.environ, FSMG_BENCH_REPEATS='1', **env_over)
-        cmd = [sys.executable, os.path.abspath(__file__), '--config', config, '--steps', str(steps), '--warmup', str(warmup),
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', config, '--steps', str(steps), '--warmup', str(warmup), '--pool', pool,
                '--no-cpu-baseline', '--no-breakdown', '--no-other-configs', '--no-extras']
         try:
             proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=180)
@@ -403,6 +422,8 @@ def main():
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the clock probe, the validation leg and the host-path legs (the other_configs sub-runs)')
+    ap.add_argument('--pool', default='uniform', choices=['uniform', 'padded-zipf'],
+                    help='token pool: SURVEY 8(d)\'s i.i.d. uniform ids (the headline), or zero-padded Zipf songs (what real data looks like; a diagnostic leg)')
     ap.add_argument('--config', default='cfg-B', choices=['cfg-B', 'cfg-C', 'cfg-D', 'cfg-Bx4', 'cfg-Bx8', 'cfg-E', 'ref-default'])
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
@@ -437,7 +458,7 @@ def main():
     B = N_WAY * (K_SHOT + Q_QUERY)
     maml = (cfg['inner_steps'], cfg['inner_lr']) if args.config == 'cfg-E' else None
 
-    pool_host = synthetic_episodes(POOL, N_WAY, K_SHOT, Q_QUERY, cfg['max_len'], cfg['input_size'], seed=1234 + rank)
+    pool_host = (padded_zipf_episodes if args.pool == 'padded-zipf' else synthetic_episodes)(POOL, N_WAY, K_SHOT, Q_QUERY, cfg['max_len'], cfg['input_size'], seed=1234 + rank)
     d_sup = torch.from_numpy(np.stack([s for s, _ in pool_host])).cuda()
     d_qry = torch.from_numpy(np.stack([q for _, q in pool_host])).cuda()
     sup_stride, qry_stride = d_sup[0].numel() * 4, d_qry[0].numel() * 4
@@ -708,7 +729,7 @@ def main():
             'metric': 'episodes/s (LSTM-baseline train step, synthetic vocab=10k seq_len=128 5-way/5-shot h=512)',
             'value': value, 'unit': 'episodes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'arithmetic': ARITHMETIC, 'gemm_kind': os.environ.get('FSMG_GEMM', 'bx3'), 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32', 'arithmetic': ARITHMETIC, 'gemm_kind': os.environ.get('FSMG_GEMM', 'bx3'), 'data': 'synthetic' if args.pool == 'uniform' else 'synthetic (zero-padded Zipf songs: a diagnostic pool, not SURVEY 8(d)\'s)',
             'config': {'workload': wl + (', MAML-style step (1 inner clipped-SGD step on the support rows + outer clip+Adam on the query gradient)'
                                          if maml else ', full train step (fwd+BPTT+clip+Adam)') + ', one episode per GPU per step',
                        'episodes_per_step': world, 'parallelism': 'episode-parallel x%d, 1 RCCL all-reduce/step' % world},
