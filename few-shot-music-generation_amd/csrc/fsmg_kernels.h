@@ -72,7 +72,17 @@ struct GemmArgs {
     // have all been acknowledged adds 1 to done[row tile] (zeroed by the caller): what a consumer on other CUs gates the rows of that row tile on
     // (launch_ce_rows_gated: the cross entropy under the forward pair's tail)
     int* done;              // (experiment builds: measured and rejected, profiles/r05_ce_under_tail_*)
+    // Operands that arrive PRE-SPLIT (256 x 256-tile kernel only; round 6): the "plane image" launch_split_planes writes -- the three
+    // bf16 planes of op(A) / op(B) as [plane][k / 8][x][8 bf16], k padded with zeros to a multiple of 16, x = the M (N) index -- i.e.
+    // the kernel's LDS image per k group, so a tile is 24 LDS-DMA instructions of 1 KiB and no split work in the k loop.  Same six
+    // products in the same order as the in-loop split: the same bits.  A / B (fp32) are then not read (B's column sums: not with Bpl).
+    const void* Apl; const void* Bpl;
 };
+// Plane images (GemmArgs::Apl / Bpl).  src is op(X) stored k-contiguous (mode OP_KC: src[x][k], ld >= K) or x-contiguous (OP_XC:
+// src[k][x], ld >= X); planes holds plane_image_bytes(K, X) bytes.  Exact: piece1 + piece2 + piece3 == value for every finite fp32.
+inline long long plane_image_k8(int K) { return 2LL * ((K + 15) / 16); }
+inline long long plane_image_bytes(int K, int X) { return 3LL * plane_image_k8(K) * X * 16; }
+hipError_t launch_split_planes(hipStream_t s, int mode, const float* src, int ld, int K, int X, void* planes);
 // amode/bmode in {OP_KC, OP_XC}. Supported combinations: (KC,XC) (XC,XC) (KC,KC)
 hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, int lds_pad = 0);
 // dynamic-LDS padding that caps a GEMM at `blocks_per_cu` resident blocks per CU

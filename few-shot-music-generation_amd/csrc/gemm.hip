@@ -23,6 +23,7 @@
 #include "fsmg_kernels.h"
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 
 namespace fsmg {
 
@@ -879,6 +880,39 @@ struct BxDmaXC {
             *reinterpret_cast<uint4*>(tile + pl * PLANE + lds_ofs) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
     }
 };
+// An operand that arrives PRE-SPLIT (GemmArgs::Apl / Bpl, k_gemm_bx3h): the plane image [plane][k / 8][x][8 bf16] holds, per plane and
+// k group, the 16-byte words of consecutive x one after the other -- which is the LDS image of a tile -- so a [256 x][16 k] tile is
+// six runs of 4 KiB: 24 LDS-DMA instructions of 1 KiB, three per wave, straight into the stage buffer every wave reads its fragments
+// from.  No registers, no VALU, no LDS instruction; what is left of the operand in the k loop is three vector-memory issues per wave.
+// The stage buffer is SHARED (the raw regions of BxDmaXC are wave-private): a DMA may only be issued once every wave is past the
+// barrier behind the stage's last reads, and must have landed (counted vmcnt) before the barrier that publishes the stage -- hence
+// three stages for such an operand: tile kt + 2 is requested while tile kt is being multiplied.
+template <int XT>
+struct BxPlanes {
+    static constexpr int KH = XT * 16, PLANE = 2 * KH;
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned vo[3], so, sstep;
+    int lofs[3];            // wave-uniform byte offsets of the wave's three 1 KiB runs inside an operand tile
+    __device__ __forceinline__ void init(const void* planes, int K, int X, int x0, int kb, int tid) {
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned k8 = 2u * (unsigned)((K + 15) / 16);
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(planes), 0, (int)0xfffffffcu, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = wave * 3 + j, pl = idx >> 3, kh = (idx >> 2) & 1, q = idx & 3;
+            const unsigned x = (unsigned)min(x0 + q * 64 + lane, X - 1);       // past X: the last column again (lands in columns that are never stored)
+            vo[j] = ((pl * k8 + (unsigned)(kb >> 3) + kh) * (unsigned)X + x) * 16u;
+            lofs[j] = pl * PLANE + kh * KH + q * 1024;
+        }
+        so = 0; sstep = 2u * (unsigned)X * 16u;
+    }
+    __device__ __forceinline__ void fetch(unsigned char* stage) {
+        const unsigned s0 = __builtin_amdgcn_readfirstlane(so);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (bx_lds_ptr_t)(stage + lofs[j]), 16, vo[j], s0, 0, 0);
+        so += sstep;
+    }
+};
 template <bool DMA, int MODE, int XT, int NT, bool BUF, bool GATHER = false> struct BxStagerSel { typedef BxStager<MODE, XT, NT, BUF> type; };
 template <int XT, int NT, bool BUF, bool GATHER> struct BxStagerSel<true, OP_XC, XT, NT, BUF, GATHER> { typedef BxDmaXC<XT, GATHER> type; };
 
@@ -1174,14 +1208,19 @@ __global__ __launch_bounds__(256 * (MT + 1), MT == 1 ? 2 : 1) void k_gemm_bx3w(c
 // (xcd_first > 0) lets only blocks on XCDs >= xcd_first draw, only items below work_limit and only while *stop == 0; the clean-up
 // launch (xcd_first < 0) takes what nobody claimed.  Which block computes an item never changes the item.
 // AG: two-part op(A) (GemmArgs::m_split; x-contiguous operands through LDS-DMA only)
-template <int AMODE, int BMODE, bool PROF = false, int BUFM = 0, bool QUEUE = false, bool AG = false>
+// PLM: which operands arrive pre-split as plane images (GemmArgs::Apl / Bpl; bit 0: A, bit 1: B) -- BxPlanes, three LDS stages each
+template <int AMODE, int BMODE, bool PROF = false, int BUFM = 0, bool QUEUE = false, bool AG = false, int PLM = 0>
 __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     constexpr int XT = 256;
-    constexpr int PLANE = 2 * XT * 16, OPER = 3 * PLANE, STAGE = 2 * OPER;            // 8 KiB, 24 KiB, 48 KiB
+    constexpr int PLANE = 2 * XT * 16, OPER = 3 * PLANE;                              // 8 KiB, 24 KiB
     constexpr int EPI = 8 * 32 * 68 * 4;
     constexpr bool DMA = BUFM >= 3;                       // x-contiguous operands through LDS-DMA (BxDmaXC)
-    constexpr int RAW = DMA ? ((AMODE == OP_XC) + (BMODE == OP_XC)) * 8 * 2048 : 0;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[((2 * STAGE > EPI) ? 2 * STAGE : EPI) + RAW];
+    constexpr bool APL = (PLM & 1) != 0, BPL = (PLM & 2) != 0;
+    constexpr int NSA = APL ? 3 : 2, NSB = BPL ? 3 : 2;   // LDS stages per operand
+    constexpr int A_BYTES = NSA * OPER, PIPE = (NSA + NSB) * OPER;                    // 96 / 120 / 144 KiB
+    static_assert(PIPE >= EPI, "the epilogue's transpose slices live in the pipeline's LDS");
+    constexpr int RAW = DMA ? ((AMODE == OP_XC && !APL) + (BMODE == OP_XC && !BPL)) * 8 * 2048 : 0;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[PIPE + RAW];
     __shared__ float s_cs[256];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1271,20 +1310,23 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     const int nk = (ke > kb) ? (ke - kb + 15) / 16 : 0;
     const int nfull = (ke > kb) ? (ke - kb) / 16 : 0;
 
-    typename BxStagerSel<DMA, AMODE, XT, 512, (BUFM >= 2), AG>::type sa;      // 512 threads cover 256 rows / columns, 8 values each
-    typename BxStagerSel<DMA, BMODE, XT, 512, (BUFM >= 1)>::type sb;
-    if constexpr (AG) {                                   // which part of op(A) this row tile belongs to
+    typename std::conditional<APL, BxPlanes<XT>, typename BxStagerSel<DMA, AMODE, XT, 512, (BUFM >= 2), AG>::type>::type sa;      // 512 threads cover 256 rows / columns, 8 values each
+    typename std::conditional<BPL, BxPlanes<XT>, typename BxStagerSel<DMA, BMODE, XT, 512, (BUFM >= 1)>::type>::type sb;
+    static_assert(!(AG && PLM != 0), "two-part A: not with plane images");
+    if constexpr (APL) sa.init(g.Apl, g.K, g.M, m0, kb, tid);
+    else if constexpr (AG) {                              // which part of op(A) this row tile belongs to
         static_assert(!AG || (DMA && AMODE == OP_XC), "two-part A: LDS-DMA staged x-contiguous operand");
         const bool first = m0 < g.m_split;
         sa.init(first ? g.A : g.A2, first ? g.lda : g.lda2, first ? g.m_split : g.M - g.m_split, first ? m0 : m0 - g.m_split,
-                first ? g.gather : nullptr, kb, tid, g.K, smem + 2 * STAGE + wave * 2048, ke);
+                first ? g.gather : nullptr, kb, tid, g.K, smem + PIPE + wave * 2048, ke);
     } else
-    if constexpr (DMA && AMODE == OP_XC) sa.init(g.A, g.lda, g.M, m0, nullptr, kb, tid, g.K, smem + 2 * STAGE + wave * 2048);
+    if constexpr (DMA && AMODE == OP_XC) sa.init(g.A, g.lda, g.M, m0, nullptr, kb, tid, g.K, smem + PIPE + wave * 2048);
     else sa.init(g.A, g.lda, g.M, m0, g.gather, kb, tid, g.K);
 #ifdef FSMG_EXPERIMENTS
-    if constexpr (QUEUE && AMODE == OP_KC && BUFM >= 2) sa.coherent = g.gate != nullptr && (g.dbg & 32) != 0;     // (the measured alternative: agent-scope loads)
+    if constexpr (!APL && QUEUE && AMODE == OP_KC && BUFM >= 2) sa.coherent = g.gate != nullptr && (g.dbg & 32) != 0;     // (the measured alternative: agent-scope loads)
 #endif
-    if constexpr (DMA && BMODE == OP_XC) sb.init(g.B, g.ldb, g.N, n0, nullptr, kb, tid, g.K, smem + 2 * STAGE + ((AMODE == OP_XC) ? 8 * 2048 : 0) + wave * 2048);
+    if constexpr (BPL) sb.init(g.Bpl, g.K, g.N, n0, kb, tid);
+    else if constexpr (DMA && BMODE == OP_XC) sb.init(g.B, g.ldb, g.N, n0, nullptr, kb, tid, g.K, smem + PIPE + ((AMODE == OP_XC && !APL) ? 8 * 2048 : 0) + wave * 2048);
     else sb.init(g.B, g.ldb, g.N, n0, nullptr, kb, tid, g.K);
 
     f32x16 acc[4][2];
@@ -1296,7 +1338,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // column sums of op(B): thread = (x = tid % 256, k half = tid / 256) of the XC stager
-    const bool do_colsum = (BMODE == OP_XC) && g.colsum != nullptr && tm == 0;
+    const bool do_colsum = !BPL && (BMODE == OP_XC) && g.colsum != nullptr && tm == 0;
     float csum = 0.0f;
     // weighted column sums (GemmArgs::colsum_w): ONE dword load per wave and k tile -- lane l takes the weight of K row 8 * (its k half)
     // + l % 8, requested with the tile's loads a k tile ahead -- and the commit's eight FMAs read it through DPP row broadcasts
@@ -1306,16 +1348,27 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
     // request in flight turns every counted LDS wait of the k loop and its barrier into lgkmcnt(0)).  The request is UNCONDITIONAL in
     // the kernels that can be asked for weights (both operands x-contiguous: the weight-gradient shapes); a launch without weights reads
     // floats of B it never uses.
-    constexpr bool WCS = AMODE == OP_XC && BMODE == OP_XC;
+    constexpr bool WCS = AMODE == OP_XC && BMODE == OP_XC && !BPL;
     const bool cs_weighted = WCS && do_colsum && g.colsum_w != nullptr;
     const float* cs_p = (WCS && g.colsum_w != nullptr ? g.colsum_w : g.B) + kb + 8 * ((DMA && BMODE == OP_XC) ? (lane >> 5) : (tid >> 8)) + (lane & 7);
     float cs_wv = 0.0f;
-#define BXH_FETCH(T)                                                                                           \
-    if ((T) < nfull) { sa.fetch(); sb.fetch(); }                                                               \
-    else { sa.fetch_partial(kb + (T) * 16, ke, tid); sb.fetch_partial(kb + (T) * 16, ke, tid); }              \
+    unsigned char* const smemB = smem + A_BYTES;
+    // vector-memory instructions a full tile's requests issue per wave (plane images first, then the operand that is split in the loop):
+    // what may still be in flight -- tile kt + 2 -- when tile kt + 1's LDS-DMA must have landed (the counted wait in front of the barrier)
+    constexpr int NLD_A = APL ? 3 : (AMODE == OP_KC ? 2 : (DMA ? 2 : 8)), NLD_B = BPL ? 3 : (BMODE == OP_KC ? 2 : (DMA ? 2 : 8));
+    constexpr int NLD = NLD_A + NLD_B + (WCS ? 1 : 0);
+    // T: tile index, S3: its stage among three (plane images only).  The DMAs of the plane images go out FIRST: whatever waits for the
+    // loads of the other operand (its commit) has then waited for them too (loads return in order).
+#define BXH_FETCH(T, S3)                                                                                       \
+    if constexpr (APL) sa.fetch(smem + (S3) * OPER);                                                           \
+    if constexpr (BPL) sb.fetch(smemB + (S3) * OPER);                                                          \
+    if ((T) < nfull) { if constexpr (!APL) sa.fetch(); if constexpr (!BPL) sb.fetch(); }                       \
+    else { if constexpr (!APL) sa.fetch_partial(kb + (T) * 16, ke, tid); if constexpr (!BPL) sb.fetch_partial(kb + (T) * 16, ke, tid); } \
     if constexpr (WCS) cs_wv = cs_p[(T) * 16];
 #define BXH_COMMIT(ST)                                                                                         \
-    sa.load(); sb.load();                                                                                      \
+    if constexpr (!APL) sa.load();                                                                             \
+    if constexpr (!BPL) {                                                                                      \
+    sb.load();                                                                                                 \
     if (do_colsum) {                                                                                           \
         if (cs_weighted) {               /* weighted per K row: cs_wv came in with this tile's loads (BXH_FETCH) */ \
             csum = fmaf(sb.v[0], cs_bcast<0>(cs_wv), csum); csum = fmaf(sb.v[1], cs_bcast<1>(cs_wv), csum);   \
@@ -1324,36 +1377,49 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
             csum = fmaf(sb.v[6], cs_bcast<6>(cs_wv), csum); csum = fmaf(sb.v[7], cs_bcast<7>(cs_wv), csum);   \
         } else csum += sb.sum8();                                                                              \
     }                                                                                                          \
-    sa.commit(smem + (ST) * STAGE);                                                                            \
-    sb.commit(smem + (ST) * STAGE + OPER);
+    }                                                                                                          \
+    if constexpr (!APL) sa.commit(smem + (ST) * OPER);                                                         \
+    if constexpr (!BPL) sb.commit(smemB + (ST) * OPER);
+    // the wait for tile T1's plane-image DMAs in front of the barrier that publishes it: tile T1 + 1's requests (NLD of them, when it
+    // is a full tile: a K tail's loads are predicated and not counted on) may stay in flight
+#define BXH_WAIT_PLANES(T1)                                                                                    \
+    if constexpr (PLM != 0) {                                                                                  \
+        if ((T1) + 1 < nfull) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");                      \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+    }
 
     if (nk > 0) {
-        BXH_FETCH(0)
+        BXH_FETCH(0, 0)
         BXH_COMMIT(0)
-        if (nk > 1) { BXH_FETCH(1) }                      // every fetch sits right behind a commit (the VALU half of an iteration)
+        if (nk > 1) { BXH_FETCH(1, 1) }                   // every fetch sits right behind a commit (the VALU half of an iteration)
+        BXH_WAIT_PLANES(0)
     }
     bx_barrier();
     const int fa = khalf * (XT * 16) + (wm * 128 + l31) * 16, fb = khalf * (XT * 16) + (wn * 64 + l31) * 16;
     if (PROF) { p_loop = plast = __builtin_amdgcn_s_memtime(); }
+    int s3 = 0;                                           // kt % 3
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
+        const int s3n = s3 == 0 ? 2 : s3 - 1;             // (kt + 2) % 3: the stage tile kt - 1 was read from
         // every wave starts with the fragments of the FIRST term (a[2], b[0]: 6 of the 18 reads), so that the late waves'
         // first MFMAs do not wait for LDS behind their commit; the other twelve follow the commit and land behind those
         // MFMAs.  (All 18 up front cost 72 live registers during the split: 10 spilled with two x-contiguous operands, and
         // the stagers' load offsets spilled -- reloaded from scratch in front of every load -- with LDS-DMA.)  Two
         // k-contiguous operands have the registers for all 18 and are faster that way (3670 against 3970 cycles per k tile).
-        constexpr bool READS_ALL_FIRST = (AMODE == OP_KC && BMODE == OP_KC);
-        const unsigned char* at = smem + (kt & 1) * STAGE;
-        const unsigned char* bt = at + OPER;
+        constexpr bool READS_ALL_FIRST = (AMODE == OP_KC && BMODE == OP_KC) || PLM != 0;
+        const unsigned char* at = smem + (APL ? s3 : (kt & 1)) * OPER;
+        const unsigned char* bt = smemB + (BPL ? s3 : (kt & 1)) * OPER;
         bf16x8_t a[3][4], b[3][2];
+        // both operands as plane images: nothing to split, the requests of tile kt + 2 go out at the top of the iteration
+        if constexpr (PLM == 3) { if (kt + 2 < nk) { BXH_FETCH(kt + 2, s3n) } }
 #define BXH_READ_A(pl) _Pragma("unroll") for (int i = 0; i < 4; ++i) a[pl][i] = *reinterpret_cast<const bf16x8_t*>(at + (pl) * PLANE + fa + i * 512);
 #define BXH_READ_B(pl) _Pragma("unroll") for (int j = 0; j < 2; ++j) b[pl][j] = *reinterpret_cast<const bf16x8_t*>(bt + (pl) * PLANE + fb + j * 512);
         BXH_READ_A(2) BXH_READ_B(0)
         if (READS_ALL_FIRST) { BXH_READ_A(0) BXH_READ_B(2) BXH_READ_A(1) BXH_READ_B(1) }
         __builtin_amdgcn_sched_barrier(0);
-        if (late && more) {
+        if constexpr (PLM != 3) if (late && more) {
             BXH_COMMIT((kt + 1) & 1)
-            if (kt + 2 < nk) { BXH_FETCH(kt + 2) }
+            if (kt + 2 < nk) { BXH_FETCH(kt + 2, s3n) }
         }
         __builtin_amdgcn_sched_barrier(0);
         BX_STAMP(3)
@@ -1367,16 +1433,19 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bx3h(const GemmArgs g) {
         BXH_TERM(2, 0) BXH_TERM(0, 2) BXH_TERM(1, 1) BXH_TERM(1, 0) BXH_TERM(0, 1) BXH_TERM(0, 0)
 #undef BXH_TERM
         BX_STAMP(2)
-        if (!late && more) {
+        if constexpr (PLM != 3) if (!late && more) {
             BXH_COMMIT((kt + 1) & 1)
-            if (kt + 2 < nk) { BXH_FETCH(kt + 2) }
+            if (kt + 2 < nk) { BXH_FETCH(kt + 2, s3n) }
         }
         BX_STAMP(3)
+        if (more) { BXH_WAIT_PLANES(kt + 1) }
         bx_barrier();
         BX_STAMP(4)
+        s3 = s3 == 2 ? 0 : s3 + 1;
     }
 #undef BXH_FETCH
 #undef BXH_COMMIT
+#undef BXH_WAIT_PLANES
     const unsigned long long p_exit_loop = PROF ? __builtin_amdgcn_s_memtime() : 0;
 
     if (do_colsum) {                    // the two k halves of a column live in threads tid and tid + 256 (LDS-DMA: lanes l, l + 32)
@@ -1433,6 +1502,39 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     // weighted column sums: the 256 x 256-tile kernels' x-contiguous-operand instantiations only; exp(logit) stores: the bf16-split kernels
     if (g.colsum_w != nullptr && !(g.bx3 == 3 && AMODE == OP_XC && BMODE == OP_XC && g.colsum != nullptr)) return hipErrorInvalidValue;
     if (g.ce_store && !(g.bx3 != 0 && g.ce_part != nullptr && g.ksplit <= 1)) return hipErrorInvalidValue;      // (every bf16-split kernel: one epilogue)
+    // Pre-split operands (plane images).  MEASURED AND REJECTED as a product path (round 6, profiles/r06_gemm_planes_rejected.txt): the same
+    // bits, and no faster -- the k loop is bound by the matrix pipe its two waves per SIMD share plus the barrier / first-fragment latency of
+    // every k tile, not by the split (dH 265 -> 272 us with the weights' image, 274 with both images, 285 with the 1.5 x larger image of
+    // E' alone; the projection 353 -> 351 / 343).  The instantiations live in the experiment build (make experiments, tools/gemm_bench PL=).
+    if (g.Apl != nullptr || g.Bpl != nullptr) {
+#ifndef FSMG_EXPERIMENTS
+        return hipErrorInvalidValue;
+#else
+        const long long a_b = 4LL * g.lda * (AMODE == OP_KC ? g.M : g.K), b_b = 4LL * g.ldb * (BMODE == OP_KC ? g.N : g.K);
+        const bool a_ok = g.Apl != nullptr ? plane_image_bytes(g.K, g.M) < 0xfffff000LL : (g.gather == nullptr && a_b < 0xfffff000LL && AMODE == OP_KC);
+        const bool b_ok = g.Bpl != nullptr ? plane_image_bytes(g.K, g.N) < 0xfffff000LL : (b_b < 0xfffff000LL && BMODE == OP_KC);
+        if (g.bx3 != 3 || !a_ok || !b_ok || g.prof != nullptr || g.m_split > 0 || (g.Bpl != nullptr && g.colsum != nullptr) ||
+            (((uintptr_t)g.Apl | (uintptr_t)g.Bpl) & 15) != 0) return hipErrorInvalidValue;
+        const int plm = (g.Apl != nullptr ? 1 : 0) | (g.Bpl != nullptr ? 2 : 0);
+        const int total = ((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.ksplit > 1 ? g.ksplit : 1);
+        if (g.xcd_first != 0) {                      // work-queue launch (the gated projection: A split in the loop, B = the weights' image)
+            if (g.work == nullptr || g.claim == nullptr || (g.xcd_first > 0 && g.stop == nullptr) || plm != 2) return hipErrorInvalidValue;
+            const int lim = g.work_limit < total ? g.work_limit : total;
+            const int blocks = g.xcd_first > 0 ? (int)(((long long)lim * 8 + 7 - g.xcd_first) / (8 - g.xcd_first)) + 64 : total;
+            if constexpr (AMODE == OP_KC) { hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 2, true, false, 2>), dim3(blocks), dim3(512), 0, s, g); return hipGetLastError(); }
+            return hipErrorInvalidValue;
+        }
+        dim3 grid3(((g.M + 255) / 256) * ((g.N + 255) / 256), g.ksplit > 1 ? g.ksplit : 1);
+        if (plm == 3) { hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 2, false, false, 3>), grid3, dim3(512), lds_pad, s, g); return hipGetLastError(); }
+        if constexpr (AMODE == OP_KC) {
+            if (plm == 2) { hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 2, false, false, 2>), grid3, dim3(512), lds_pad, s, g); return hipGetLastError(); }
+        }
+        if constexpr (BMODE == OP_KC) {
+            if (plm == 1) { hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 2, false, false, 1>), grid3, dim3(512), lds_pad, s, g); return hipGetLastError(); }
+        }
+        return hipErrorInvalidValue;
+#endif
+    }
     if (g.xcd_first != 0 && g.bx3 == 3) {      // work-queue launch of the 256 x 256-tile kernel (one block per CU)
         if (g.work == nullptr || g.claim == nullptr || (g.xcd_first > 0 && g.stop == nullptr) || g.gather != nullptr || g.prof != nullptr) return hipErrorInvalidValue;
         const long long a_b = 4LL * g.lda * (AMODE == OP_KC ? g.M : g.K), b_b = 4LL * g.ldb * (BMODE == OP_KC ? g.N : g.K);
@@ -1529,6 +1631,40 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
     return hipGetLastError();
 }
 
+// fp32 operand -> its plane image (GemmArgs::Apl / Bpl): planes[pl][kg][x][8 bf16], kg < k8 = 2 * ceil(K / 16), zeros for k >= K.
+// The same split8 the k loops run, so the pieces -- hence every product -- are the ones the in-loop split makes.
+//   XC source (src[k][x]): thread = (x, kg), eight loads down k (a wave: 256 contiguous bytes each), one 16-byte store per plane
+//       (a wave: 1 KiB contiguous);
+//   KC source (src[x][k]): thread = (x = t / 8, kg = t % 8): 32 contiguous bytes per thread, eight threads a 256-byte run of a row; the
+//       stores of a wave are eight runs of 128 bytes per plane.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ src, int ld, int K, int X, uint4* __restrict__ planes) {
+    const int k8 = 2 * ((K + 15) / 16);
+    int x, kg;
+    if (MODE == OP_XC) { x = blockIdx.x * 256 + threadIdx.x; kg = blockIdx.y; }
+    else { x = blockIdx.x * 32 + (threadIdx.x >> 3); kg = blockIdx.y * 8 + (threadIdx.x & 7); }
+    if (x >= X || kg >= k8) return;
+    float v[8];
+    const int k0 = kg * 8;
+    if (MODE == OP_XC) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (k0 + i < K) ? src[(long long)(k0 + i) * ld + x] : 0.0f;
+    } else {
+        const float* r = src + (long long)x * ld + k0;
+        if (k0 + 8 <= K && ((ld | k0) & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+            const float4 q0 = *reinterpret_cast<const float4*>(r), q1 = *reinterpret_cast<const float4*>(r + 4);
+            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (k0 + i < K) ? r[i] : 0.0f;
+        }
+    }
+    unsigned w[3][4];
+    split8(v, w);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) planes[((long long)pl * k8 + kg) * X + x] = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+}
+
 __global__ void k_reduce_slabs(const float* __restrict__ slabs, long long stride, int nslab,
                                float* __restrict__ out, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1582,6 +1718,15 @@ hipError_t launch_gemm(hipStream_t s, int amode, int bmode, const GemmArgs& g, i
     if (amode == OP_XC && bmode == OP_XC) return launch_t<OP_XC, OP_XC>(s, g, lds_pad);
     if (amode == OP_KC && bmode == OP_KC) return launch_t<OP_KC, OP_KC>(s, g, lds_pad);
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_split_planes(hipStream_t s, int mode, const float* src, int ld, int K, int X, void* planes) {
+    if (K <= 0 || X <= 0) return hipSuccess;
+    if (((uintptr_t)planes & 15) != 0 || (mode != OP_KC && mode != OP_XC)) return hipErrorInvalidValue;
+    const int k8 = (int)plane_image_k8(K);
+    if (mode == OP_XC) hipLaunchKernelGGL((k_split_planes<OP_XC>), dim3((X + 255) / 256, k8), dim3(256), 0, s, src, ld, K, X, (uint4*)planes);
+    else hipLaunchKernelGGL((k_split_planes<OP_KC>), dim3((X + 31) / 32, (k8 + 7) / 8), dim3(256), 0, s, src, ld, K, X, (uint4*)planes);
+    return hipGetLastError();
 }
 
 hipError_t launch_reduce_slabs2(hipStream_t s, const float* slabs, long long slab_stride, int nslab, float* out, long long n,

@@ -162,12 +162,35 @@ int main(int argc, char** argv) {
     const int bx3 = getenv("BX3") ? atoi(getenv("BX3")) : 0;      // BX3=1: the bf16-split kernel (k_gemm_bx3)
     int* ctl; CK(hipMalloc(&ctl, 4 * 65536));
     const char* only = getenv("ONLY");                         // ONLY=substring of the shape name
+    // PL=1 / 2 / 3 (with BX3=3): A / B / both operands as plane images (GemmArgs::Apl / Bpl, launch_split_planes): prints the split
+    // kernels' time, the GEMM's time, and whether its result has the SAME BITS as the launch that splits in the k loop
+    const int pl = getenv("PL") ? atoi(getenv("PL")) : 0;
     for (const Shape& sh : shapes) {
         if (only && !strstr(sh.name, only)) continue;
         const size_t an = (size_t)sh.M * sh.K, bn = (size_t)sh.K * sh.N, cn = (size_t)sh.M * sh.N;
         float* A = dev_random(an, 1); float* B = dev_random(bn, 2);
         float* C; CK(hipMalloc(&C, cn * 4)); float* cs; CK(hipMalloc(&cs, sh.N * 4));
         float* Cref = nullptr; float* csref = nullptr;
+        void* Apl = nullptr; void* Bpl = nullptr; float* Cpl = nullptr;
+        const bool colsum_ok = !(sh.colsum && (pl & 2));
+        if (pl && bx3 == 3) {
+            CK(hipMalloc(&Cpl, cn * 4));
+            float ms;
+            if (pl & 1) {
+                CK(hipMalloc(&Apl, plane_image_bytes(sh.K, sh.M)));
+                CK(launch_split_planes(s, sh.amode, A, (sh.amode == OP_KC) ? sh.K : sh.M, sh.K, sh.M, Apl));
+                CK(hipEventRecord(e0, s)); for (int i = 0; i < 5; ++i) CK(launch_split_planes(s, sh.amode, A, (sh.amode == OP_KC) ? sh.K : sh.M, sh.K, sh.M, Apl));
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("  split A (%s source, %d x %d): %.1f us, %.0f MB image\n", sh.amode == OP_KC ? "KC" : "XC", sh.M, sh.K, ms * 200, plane_image_bytes(sh.K, sh.M) / 1e6);
+            }
+            if (pl & 2) {
+                CK(hipMalloc(&Bpl, plane_image_bytes(sh.K, sh.N)));
+                CK(launch_split_planes(s, sh.bmode, B, (sh.bmode == OP_KC) ? sh.K : sh.N, sh.K, sh.N, Bpl));
+                CK(hipEventRecord(e0, s)); for (int i = 0; i < 5; ++i) CK(launch_split_planes(s, sh.bmode, B, (sh.bmode == OP_KC) ? sh.K : sh.N, sh.K, sh.N, Bpl));
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("  split B (%s source, %d x %d): %.1f us, %.0f MB image\n", sh.bmode == OP_KC ? "KC" : "XC", sh.N, sh.K, ms * 200, plane_image_bytes(sh.K, sh.N) / 1e6);
+            }
+        }
         if (verify) {
             CK(hipMalloc(&Cref, cn * 4)); CK(hipMalloc(&csref, sh.N * 4));
             hipLaunchKernelGGL(k_ref, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, s, A, (sh.amode == OP_KC) ? sh.K : sh.M, sh.amode,
@@ -183,7 +206,14 @@ int main(int argc, char** argv) {
             g.C = (S > 1) ? slabs : C; g.ldc = sh.N; g.M = sh.M; g.N = sh.N; g.K = sh.K;
             g.ksplit = S; g.c_slab = (long long)cn; g.bx3 = bx3;
             g.group_m = getenv("GROUP_M") ? atoi(getenv("GROUP_M")) : 0;
-            if (sh.colsum) { g.colsum = (S > 1) ? csl : cs; g.colsum_slab = sh.N; }
+            if (sh.colsum && colsum_ok) { g.colsum = (S > 1) ? csl : cs; g.colsum_slab = sh.N; }
+            if (Cpl) {                  // the in-loop split's result first: what the plane-image launch must reproduce bit for bit
+                CK(launch_gemm(s, sh.amode, sh.bmode, g, pad));
+                if (S > 1) CK(launch_reduce_slabs(s, slabs, (long long)cn, S, C, (long long)cn));
+                CK(hipMemcpyAsync(Cpl, C, cn * 4, hipMemcpyDeviceToDevice, s));
+                CK(hipMemsetAsync(C, 0xff, cn * 4, s));
+                g.Apl = Apl; g.Bpl = Bpl;
+            }
             float ms_k = 0, ms_t = 0;
             for (int r = -2; r < reps; ++r) {
                 if (xcd_first != 0) CK(hipMemsetAsync(ctl, 0, 4 * 65536, s));
@@ -199,7 +229,7 @@ int main(int argc, char** argv) {
                 CK(hipEventRecord(e1, s));
                 if (S > 1) {
                     CK(launch_reduce_slabs(s, slabs, (long long)cn, S, C, (long long)cn));
-                    if (sh.colsum) CK(launch_reduce_slabs(s, csl, sh.N, S, cs, sh.N));
+                    if (sh.colsum && colsum_ok) CK(launch_reduce_slabs(s, csl, sh.N, S, cs, sh.N));
                 }
                 CK(hipEventRecord(e2, s));
                 CK(hipEventSynchronize(e2));
@@ -207,10 +237,17 @@ int main(int argc, char** argv) {
                 if (r >= 0) { ms_k += a; ms_t += b; }
             }
             ms_k /= reps; ms_t /= reps;
+            if (Cpl) {
+                CK(hipStreamSynchronize(s));
+                std::vector<unsigned> x(cn), y(cn);
+                CK(hipMemcpy(x.data(), C, cn * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(y.data(), Cpl, cn * 4, hipMemcpyDeviceToHost));
+                size_t diff = 0; for (size_t i = 0; i < cn; ++i) diff += x[i] != y[i];
+                printf("  plane images (PL=%d) vs in-loop split, S %d: %zu of %zu words differ  %s\n", pl, S, diff, cn, diff ? "MISMATCH" : "same bits");
+            }
             const int tiles = bx3 == 3 ? ((sh.M + 255) / 256) * ((sh.N + 255) / 256) : ((sh.M + gemm_tile_m() - 1) / gemm_tile_m()) * ((sh.N + 127) / 128);
             if (verify) {
                 CK(hipStreamSynchronize(s));
-                const double e = max_rel(C, Cref, cn), ec = sh.colsum ? max_rel(cs, csref, sh.N) : 0.0;
+                const double e = max_rel(C, Cref, cn), ec = (sh.colsum && colsum_ok) ? max_rel(cs, csref, sh.N) : 0.0;
                 printf("  verify S %d: C max err / max|C| %.2e  rms err / rms %.2e  colsum err %.2e  %s\n", S, e, rms_rel(C, Cref, cn), ec, (e < 2e-5 && ec < 2e-4) ? "ok" : "MISMATCH");
                 CK(hipMemset(C, 0xff, cn * 4));
             }
@@ -219,6 +256,7 @@ int main(int argc, char** argv) {
             if (getenv("PROF") && atoi(getenv("PROF")) && bx3 && xcd_first == 0) profile_launch(s, sh.amode, sh.bmode, g, pad, tiles * S, ms_k);
         }
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(cs));
+        if (Apl) CK(hipFree(Apl)); if (Bpl) CK(hipFree(Bpl)); if (Cpl) CK(hipFree(Cpl));
         if (Cref) { CK(hipFree(Cref)); CK(hipFree(csref)); }
     }
     return 0;
