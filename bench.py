@@ -53,6 +53,9 @@ N_WAY, K_SHOT, Q_QUERY = 5, 5, 4
 OTHER = {
     'cfg-C': (dict(name='lstm_baseline', seed=1234, input_size=4708, max_len=50, embedding_size=250, hidden_size=1024,
                    n_layers=2, lr=5e-3, max_grad_norm=5, n_decay=10000), 5, 5, 4),
+    # "cfg-C: ... T = 50 (YAML) and 128" -- the same two layers of 1024 at the headline's sequence length (637 GFLOP per episode)
+    'cfg-C-T128': (dict(name='lstm_baseline', seed=1234, input_size=4708, max_len=128, embedding_size=250, hidden_size=1024,
+                        n_layers=2, lr=5e-3, max_grad_norm=5, n_decay=10000), 5, 5, 4),
     'cfg-D': (dict(CFG_B), 20, 1, 4),
     # the reference's OWN shipped defaults (src/config/lstm_baseline.yaml: E=250, H=200, L=1; lyrics.yaml: max_len 50; 5shot.yaml),
     # vocabulary sized like the headline workload -- what a user gets who drops the plugin in with the reference's YAMLs
@@ -74,11 +77,18 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_BX3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 HBM_ACHIEVABLE_TBPS = 6.3          # ~6.3 of the 8.0 TB/s spec is achievable
 REPEATS = max(1, int(os.environ.get('FSMG_BENCH_REPEATS', 5)))       # timed regions of K steps each; value = their median
-ARITHMETIC = ('fp32 storage, fp32 accumulation everywhere.  GEMMs (default, FSMG_GEMM=bx3): every operand value is split EXACTLY into three '
-              'bf16 numbers and the six partial products >= 2^-23 of the fp32 product are summed in fp32 by v_mfma_f32_32x32x16_bf16 -- '
-              'error against fp64 below the fp32-MFMA kernel\'s on every shape of the step (tools/gemm_bench.cpp, BX3=0/1 with verify; '
-              'tests/test_gpu_parity.py::test_bf16_split_gemm_is_no_less_accurate_than_the_fp32_mfma_gemm); FSMG_GEMM=f32 selects '
-              'v_mfma_f32_32x32x2_f32 (timed in the same run as alt_gemm_f32_mfma).  Fused LSTM cell: v_mfma_f32_4x4x1_16B_f32 (fp32 MFMA).')
+ARITHMETIC_GEMM = ('fp32 storage, fp32 accumulation everywhere.  GEMMs (default, FSMG_GEMM=bx3): every operand value is split EXACTLY into three '
+                   'bf16 numbers and the six partial products >= 2^-23 of the fp32 product are summed in fp32 by v_mfma_f32_32x32x16_bf16 -- '
+                   'error against fp64 below the fp32-MFMA kernel\'s on every shape of the step (tools/gemm_bench.cpp, BX3=0/1 with verify; '
+                   'tests/test_gpu_parity.py::test_bf16_split_gemm_is_no_less_accurate_than_the_fp32_mfma_gemm); FSMG_GEMM=f32 selects '
+                   'v_mfma_f32_32x32x2_f32 (timed in the same run: roofline.alt_gemm_f32_mfma_value).  ')
+# the fused cell's arithmetic depends on the kernel family the timed schedule ran (the line said 4x4x1 for every schedule)
+ARITHMETIC_CELL = {
+    'bf16x3': 'Fused LSTM cell (this schedule: k_lstm_*_xcd16): the recurrent contraction as the same exact three-way bf16 split, six products per '
+              'fp32 product on v_mfma_f32_16x16x32_bf16, fp32 accumulation; gates, state update and gate gradients in fp32.',
+    'f32': 'Fused LSTM cell (this schedule): v_mfma_f32_4x4x1_16B_f32 (fp32 MFMA); gates, state update and gate gradients in fp32.',
+    'f32_16x16x4': 'Fused LSTM cell (this schedule: column-split persistent kernels): v_mfma_f32_16x16x4_f32 (fp32 MFMA).',
+}
 CELL_CLASSES = ('lstm_fwd', 'lstm_bwd')      # the fused LSTM cell: the north star's target kernel
 CLASSES = ['gemm_zx', 'lstm_fwd', 'gemm_logits', 'ce', 'gemm_dhout', 'gemm_dw', 'lstm_bwd', 'gemm_dk',
            'gemm_dx', 'embed_grad', 'update']
@@ -195,17 +205,18 @@ def other_configs(log, steps=20, warmup=5):
     what the process did before it (round 5 found handles 5, 7, 9 of a process 32-45 % slower through the priority of a stream:
     DESIGN.md 10.4 -- fixed, the isolation stays).  Per leg: value, ms_per_step, guard.ok, roofline_step.frac."""
     import subprocess
-    legs = [(n, n, {}) for n in ('cfg-C', 'cfg-D', 'cfg-E', 'ref-default')] + [('cfg-B-serial-order', 'cfg-B', {'FSMG_XCD_OVERLAP': '0'}),
-                                                                                  ('cfg-B-padded-zipf-pool', 'cfg-B', {'_pool': 'padded-zipf'}),
+    legs = [(n, n, {}) for n in ('cfg-C', 'cfg-C-T128', 'cfg-D', 'cfg-E', 'ref-default')] + [('cfg-B-serial-order', 'cfg-B', {'FSMG_XCD_OVERLAP': '0'}),
+                                                                                  ('cfg-B-padded-zipf-pool', 'cfg-B', {'_pool': 'padded-zipf', '_val': '400'}),
                                                                                   ('ref-default-padded-zipf-pool', 'ref-default', {'_pool': 'padded-zipf'})]
     res = {}
     for name, config, env_over in legs:
         t_leg = time.perf_counter()
         env_over = dict(env_over)
         pool = env_over.pop('_pool', 'uniform')
+        val_steps = env_over.pop('_val', None)
         env = dict(os.environ, FSMG_BENCH_REPEATS='1', **env_over)
         cmd = [sys.executable, os.path.abspath(__file__), '--config', config, '--steps', str(steps), '--warmup', str(warmup), '--pool', pool,
-               '--no-cpu-baseline', '--no-breakdown', '--no-other-configs', '--no-extras']
+               '--no-cpu-baseline', '--no-breakdown', '--no-other-configs', '--no-extras'] + (['--val-nll', val_steps] if val_steps else [])
         try:
             proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=180)
             line = [l for l in proc.stdout.splitlines() if l.startswith('{"metric"')][-1]
@@ -220,6 +231,8 @@ def other_configs(log, steps=20, warmup=5):
              'workload': d['config']['workload']}
         if d.get('roofline_step'):
             r['roofline_step'] = {'frac': d['roofline_step']['frac']}
+        if d.get('val'):
+            r['val'] = d['val']
         if name == 'cfg-B-serial-order' and d.get('roofline'):
             rf = d['roofline']
             r['fused_cell'] = {'achieved': rf['achieved'], 'peak': rf['peak'], 'unit': rf['unit'], 'frac': rf['frac'], 'kernel_variant': rf.get('kernel_variant'),
@@ -268,15 +281,18 @@ def cpu_baseline(cfg, pool, shape, budget_s=18.0):
     ref = TorchRef(cfg, params, dtype=torch.float32, threads=cores)
     log('cpu_baseline[torch]: %d threads (of %d available), warm-up step' % (cores, avail))
     first_eval = ref.eval(pool[0][1])
-    ref.train(*pool[0])                                   # warm-up
+    agree_eps, agree_losses = [0], [float(ref.train(*pool[0]))]          # warm-up; every train loss is kept for the GPU-vs-CPU agreement
     log('cpu_baseline[torch]: timing')
     n, t0 = 0, time.perf_counter()
     while True:
-        ref.train(*pool[(n + 1) % len(pool)])
+        agree_eps.append((n + 1) % len(pool))
+        agree_losses.append(float(ref.train(*pool[(n + 1) % len(pool)])))
         n += 1
         dt = time.perf_counter() - t0
         if dt >= budget_s * 0.75 or n >= 64:
             break
+    agree_eval_ep = len(pool) - 1                        # a held-out episode: the train loop above never reaches it (<= 65 of 256)
+    agree_eval = float(ref.eval(pool[agree_eval_ep][1]))
     ne, t1 = 0, time.perf_counter()
     while True:
         ref.eval(pool[(ne + 1) % len(pool)][1])
@@ -310,6 +326,7 @@ def cpu_baseline(cfg, pool, shape, budget_s=18.0):
     return {'value': best['train_episodes_per_s'], 'unit': 'episodes/s', 'cores': best['threads'], 'kind': 'port', 'honest_line': honest,
             'cores_used': best['threads'], 'cores_available': avail, 'cores_of': '%d of %d' % (best['threads'], avail), 'variants': variants,
             'train_eps': n, 'eval_eps': ne, 'first_eval_nll': float(first_eval),
+            'agreement_train_episodes': agree_eps, 'agreement_train_losses': agree_losses, 'agreement_eval_episode': agree_eval_ep, 'agreement_eval_nll': agree_eval,
             'sample': '%d train + %d eval episodes of the same %d-way %d-shot workload (fp32 CPU restatement of the reference '
                       'graph, best of %s; %.1f s)' % (n, ne, shape[0], shape[1], '/'.join(v['name'] for v in variants), dt + de)}
 
@@ -375,6 +392,40 @@ def cpu_honest_line(cfg, shape, torch_variant, cores, avail, torch):
             'host_peak_frac_composed': gf_step / t_comp / 1e3 / peak['peak_tflops']}
 
 
+def val_nll_leg(cfg, eng, step, args, shape, device):
+    """The metric's other half (BASELINE.json: "episodes/s + val NLL"; reference src/train/train.py:27-33,80-81 evaluate()): train on until
+    global_step = args.val_nll, then the mean query NLL of 8 held-out episodes of the same distribution (a pool seeded differently from the
+    training pool), next to the fp32 CPU restatement's value AT THE SAME PARAMETERS (read back from the device) and to the untrained model's."""
+    import torch
+    from fsmg.binding import FsmgModel
+    from oracle import lstm_oracle as O
+    from oracle.torch_ref import TorchRef
+    N, K, Q = shape
+    gen = padded_zipf_episodes if args.pool == 'padded-zipf' else synthetic_episodes
+    held = gen(8, N, K, Q, cfg['max_len'], cfg['input_size'], seed=987654)
+    i = 0
+    while eng.step < args.val_nll:
+        step(args.warmup + i)
+        i += 1
+    torch.cuda.synchronize()
+    trained = eng.step
+    losses = eng.read_losses(min(trained, 1024))
+    qs = np.stack([q for _, q in held])
+    gpu = [float(x) for x in eng.eval_batch(qs)]
+    ref = TorchRef(cfg, eng.get_params(), dtype=torch.float32, threads=min(_affinity(), 16))
+    cpu = [float(ref.eval(q)) for _, q in held]
+    fresh = FsmgModel(cfg, device=device, max_sequences=N * (K + Q))
+    fresh.init_params(cfg['seed'])
+    untrained = float(np.mean(fresh.eval_batch(qs)))
+    fresh.close()
+    g, c = float(np.mean(gpu)), float(np.mean(cpu))
+    return {'val_nll_gpu': g, 'val_nll_cpu': c, 'rel_diff': abs(g - c) / abs(c), 'per_episode_max_rel_diff': max(abs(a - b) / abs(b) for a, b in zip(gpu, cpu)),
+            'val_nll_untrained': untrained, 'train_steps': int(trained), 'held_out_episodes': len(held),
+            'train_loss_first': float(losses[0]), 'train_loss_last': float(losses[-1]),
+            'note': 'mean query NLL (nats / token) of %d held-out %s episodes after %d train steps; cpu = the fp32 torch-CPU restatement at the parameters read '
+                    'back from the device; bar 1e-4 relative' % (len(held), args.pool, trained)}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torchrun: start N ranks of this script under torch.distributed.run (rank r -> GPU r,
     rendezvous on 127.0.0.1), pass their output through and print rank 0's JSON line LAST."""
@@ -422,9 +473,12 @@ def main():
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the clock probe, the validation leg and the host-path legs (the other_configs sub-runs)')
+    ap.add_argument('--val-nll', type=int, default=0, metavar='STEPS',
+                    help='after the timed region: train on until global_step = STEPS, then the mean query NLL of 8 HELD-OUT episodes (LSTMBaseline.eval) '
+                         'beside the CPU restatement\'s value at the same parameters -> `val` (the metric\'s "val NLL" half; meaningful on --pool padded-zipf)')
     ap.add_argument('--pool', default='uniform', choices=['uniform', 'padded-zipf'],
                     help='token pool: SURVEY 8(d)\'s i.i.d. uniform ids (the headline), or zero-padded Zipf songs (what real data looks like; a diagnostic leg)')
-    ap.add_argument('--config', default='cfg-B', choices=['cfg-B', 'cfg-C', 'cfg-D', 'cfg-Bx4', 'cfg-Bx8', 'cfg-E', 'ref-default'])
+    ap.add_argument('--config', default='cfg-B', choices=['cfg-B', 'cfg-C', 'cfg-C-T128', 'cfg-D', 'cfg-Bx4', 'cfg-Bx8', 'cfg-E', 'ref-default'])
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
         sys.exit(self_launch(args))
@@ -729,7 +783,11 @@ def main():
             'metric': 'episodes/s (LSTM-baseline train step, synthetic vocab=10k seq_len=128 5-way/5-shot h=512)',
             'value': value, 'unit': 'episodes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'arithmetic': ARITHMETIC, 'gemm_kind': os.environ.get('FSMG_GEMM', 'bx3'), 'data': 'synthetic' if args.pool == 'uniform' else 'synthetic (zero-padded Zipf songs: a diagnostic pool, not SURVEY 8(d)\'s)',
+            'vs_baseline': None,
+            # the type the path computes in: fp32 values, fp32 accumulation; with the default GEMM kind every product is assembled from
+            # bf16 pieces on the bf16 matrix pipe (exact three-way split, six products) -- said here, not only in `arithmetic`
+            'dtype': 'f32' if os.environ.get('FSMG_GEMM', 'bx3') == 'f32' else 'f32 (bf16x3-split products, fp32 accumulate)',
+            'arithmetic': ARITHMETIC_GEMM, 'gemm_kind': os.environ.get('FSMG_GEMM', 'bx3'), 'data': 'synthetic' if args.pool == 'uniform' else 'synthetic (zero-padded Zipf songs: a diagnostic pool, not SURVEY 8(d)\'s)',
             'config': {'workload': wl + (', MAML-style step (1 inner clipped-SGD step on the support rows + outer clip+Adam on the query gradient)'
                                          if maml else ', full train step (fwd+BPTT+clip+Adam)') + ', one episode per GPU per step',
                        'episodes_per_step': world, 'parallelism': 'episode-parallel x%d, 1 RCCL all-reduce/step' % world},
@@ -773,8 +831,18 @@ def main():
                                'recurrent [B x H] x [H x 4H] contraction on v_mfma_f32_16x16x4_f32')
             else:
                 cell_kernel = 'k_lstm_fwd_xcd + k_lstm_bwd_xcd (recurrent [B x H] x [H x 4H] contraction on v_mfma_f32_4x4x1_16B_f32'
+            cell_arith = 'bf16x3' if cell_bx3 else ('f32' if (cfg['hidden_size'] in (512, 1024) or 192 < cfg['hidden_size'] <= 256) else 'f32_16x16x4')
+            out['arithmetic'] = ARITHMETIC_GEMM + ARITHMETIC_CELL[cell_arith]
             out['roofline'] = {
                 'bound': 'mfma',
+                # the matrix pipe the timed cell kernels issue on, and the fraction of THAT pipe's bound for fp32-equivalent work;
+                # `frac` stays the north star's definition (fp32-MFMA peak) so that rounds compare
+                'pipe': ('v_mfma_f32_16x16x32_bf16 (bf16 pipe, six products per fp32 product: bound %.0f TFLOP/s fp32-equivalent)' % PEAK_BX3_TFLOPS) if cell_bx3
+                        else 'v_mfma_f32_4x4x1_16B_f32 (fp32 pipe: bound %.1f TFLOP/s)' % PEAK_F32_MFMA_TFLOPS,
+                'peak_pipe_used': PEAK_BX3_TFLOPS if cell_bx3 else PEAK_F32_MFMA_TFLOPS,
+                'frac_pipe_used': ach / (PEAK_BX3_TFLOPS if cell_bx3 else PEAK_F32_MFMA_TFLOPS),
+                'forward_us_per_time_step': 1e3 * cell['lstm_fwd'][0] / (T * cfg['n_layers'] * args.steps),
+                'backward_us_per_time_step': 1e3 * cell['lstm_bwd'][0] / (T * cfg['n_layers'] * args.steps),
                 'kernel': 'fused LSTM cell: %s + gate nonlinearities / gate gradients + state update, %d dependent time steps per launch)'
                           % (cell_kernel, int(steps_per_launch['lstm_fwd'])),
                 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
@@ -819,6 +887,23 @@ def main():
         # each on fresh handles inside this run (one timed region between two synchronisations; a diagnostic, never the headline)
         try:
             out['other_configs'] = other_configs(log)
+            oc = out['other_configs']
+            # scalars INSIDE roofline / config: the driver's record keeps those two dicts and drops extra top-level keys
+            ser = oc.get('cfg-B-serial-order', {})
+            if out.get('roofline') is not None and ser.get('fused_cell'):
+                out['roofline'].update({'serial_order_fused_cell_frac': ser['fused_cell']['frac'],
+                                        'serial_order_fused_cell_pipe': 'v_mfma_f32_4x4x1_16B_f32 (fp32 MFMA), the whole chip, nothing beside it',
+                                        'serial_order_fwd_us_per_time_step': ser['fused_cell']['us_per_time_step']['lstm_fwd'],
+                                        'serial_order_bwd_us_per_time_step': ser['fused_cell']['us_per_time_step']['lstm_bwd'],
+                                        'serial_order_value': ser.get('value')})
+            for leg in ('cfg-C', 'cfg-C-T128', 'cfg-D', 'cfg-E', 'ref-default'):
+                if 'value' in oc.get(leg, {}):
+                    out['config']['other_%s_episodes_per_s' % leg] = oc[leg]['value']
+            val = oc.get('cfg-B-padded-zipf-pool', {}).get('val')
+            if val:
+                out['config'].update({'val_nll': val['val_nll_gpu'], 'val_nll_cpu_same_parameters': val['val_nll_cpu'], 'val_nll_rel_diff': val['rel_diff'],
+                                      'val_nll_untrained': val['val_nll_untrained'], 'val_nll_train_steps': val['train_steps'],
+                                      'val_nll_note': val['note']})
         except Exception as e:                 # noqa: BLE001
             log('other_configs leg failed: %r' % (e,))
             extras_failed['other_configs'] = repr(e)
@@ -928,25 +1013,55 @@ def main():
             out['alt_gemm_f32_mfma'] = {'value': n_alt / dt, 'unit': 'episodes/s', 'ms_per_step': 1e3 * dt / n_alt, 'steps': n_alt,
                                         'advanced_by': alt.engine.step - a0, 'final_loss': float(l_alt[-1]),
                                         'note': 'same workload and schedule, every GEMM on v_mfma_f32_32x32x2_f32 (fsmg_config.gemm = FSMG_GEMM_F32)'}
+            if out.get('roofline') is not None:
+                out['roofline']['alt_gemm_f32_mfma_value'] = n_alt / dt
+                out['roofline']['alt_gemm_f32_mfma_note'] = 'episodes/s of the same loop with every GEMM on v_mfma_f32_32x32x2_f32 (true fp32 MFMA): what the bf16-split GEMMs buy'
             del alt, par_alt
         except Exception as e:                 # noqa: BLE001
             log('fp32-MFMA GEMM leg failed: %r' % (e,))
             extras_failed['alt_gemm_f32_mfma'] = repr(e)
         log('fp32-MFMA GEMM leg done')
+    if rank == 0 and world == 1 and args.val_nll > 0 and not maml:
+        try:
+            out['val'] = val_nll_leg(base, eng, step, args, shape, local)
+        except Exception as e:                 # noqa: BLE001 -- an extra leg must not cost the result line
+            log('val-nll leg failed: %r' % (e,))
+            extras_failed['val_nll'] = repr(e)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not maml:
         out['cpu_baseline'] = cpu_baseline(base, pool_host, shape)
-        if out['cpu_baseline'] and 'eval' in out:
-            gpu_first = float(eng.eval_step(pool_host[0][1]))          # after training: not comparable; compare a fresh handle instead
+        try:
+            # GPU against CPU AFTER training (at Glorot init every model scores ln V1, right or wrong): a fresh handle
+            # from the same initial parameters takes the torch-CPU variant's train steps -- same episodes, same order -- and the two are
+            # compared on every train loss and on the query NLL of a held-out episode at the parameters both have reached
             from fsmg.binding import FsmgModel
-            fresh = FsmgModel(base, device=local)
             from oracle import lstm_oracle as O
+            cb = out['cpu_baseline']
+            fresh = FsmgModel(base, device=local, max_sequences=N_WAY * (K_SHOT + Q_QUERY))
             fresh.init_params(0)
             fresh.set_params(O.glorot_init(base, base['seed'], np.float32))
-            g = float(fresh.eval_step(pool_host[0][1]))
+            g_first = float(fresh.eval_step(pool_host[0][1]))
+            g_losses = [float(fresh.train_step(*pool_host[e])) for e in cb['agreement_train_episodes']]
+            g_after = float(fresh.eval_step(pool_host[cb['agreement_eval_episode']][1]))
             fresh.close()
-            c = out['cpu_baseline']['first_eval_nll']
-            out['cpu_baseline']['nll_agreement'] = {'gpu': g, 'cpu': c, 'rel_diff': abs(g - c) / abs(c)}
-            del gpu_first
+            c_losses, c_after = cb['agreement_train_losses'], cb['agreement_eval_nll']
+            cb['nll_agreement'] = {
+                'after_train_updates': len(c_losses), 'gpu': g_after, 'cpu': c_after, 'rel_diff': abs(g_after - c_after) / abs(c_after),
+                'train_loss_max_rel_diff': max(abs(a_ - b_) / abs(b_) for a_, b_ in zip(g_losses, c_losses)),
+                'gpu_train_losses': g_losses, 'cpu_train_losses': c_losses,
+                'at_init': {'gpu': g_first, 'cpu': cb['first_eval_nll'], 'ln_V1': float(np.log(base['input_size'] + 1))},
+                'note': 'same Glorot init, the same %d train episodes in the same order on both sides (fp32 torch-CPU restatement vs the HIP path), then the query NLL '
+                        'of held-out episode %d; bar 1e-4 relative (BASELINE.json north_star)' % (len(c_losses), cb['agreement_eval_episode'])}
+            # scalars (the driver's record keeps cpu_baseline's scalar keys)
+            cb.update({'nll_after_train_gpu': g_after, 'nll_after_train_cpu': c_after, 'nll_after_train_rel_diff': cb['nll_agreement']['rel_diff'],
+                       'nll_after_train_updates': len(c_losses), 'train_loss_max_rel_diff': cb['nll_agreement']['train_loss_max_rel_diff'],
+                       'nll_agreement_ok': bool(cb['nll_agreement']['rel_diff'] <= 1e-4 and cb['nll_agreement']['train_loss_max_rel_diff'] <= 1e-4)})
+            val = (out.get('other_configs') or {}).get('cfg-B-padded-zipf-pool', {}).get('val') or out.get('val')
+            if val:
+                cb.update({'val_nll_gpu': val['val_nll_gpu'], 'val_nll_cpu': val['val_nll_cpu'], 'val_nll_rel_diff': val['rel_diff'],
+                           'val_nll_train_steps': val['train_steps']})
+        except Exception as e:                 # noqa: BLE001 -- an extra leg must not cost the result line
+            log('nll agreement leg failed: %r' % (e,))
+            extras_failed['nll_agreement'] = repr(e)
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:

@@ -687,6 +687,8 @@ FULL = {
     'cfg-B': (dict(input_size=10000, max_len=128, embedding_size=250, hidden_size=512, n_layers=1), 5, 5, 4),
     'cfg-C': (dict(input_size=4708, max_len=50, embedding_size=250, hidden_size=1024, n_layers=2), 5, 5, 4),
     'cfg-D': (dict(input_size=10000, max_len=128, embedding_size=250, hidden_size=512, n_layers=1), 20, 1, 4),
+    # "cfg-C: ... T = 50 (YAML) and 128" -- the two layers of 1024 at the headline's sequence length (637 GFLOP per episode)
+    'cfg-C-T128': (dict(input_size=4708, max_len=128, embedding_size=250, hidden_size=1024, n_layers=2), 5, 5, 4),
 }
 # BASELINE.json configs[4]: the MAML-style loop at its own size (freemidi vocabulary, 2-layer LSTM h=1024, 5-way / 5-shot);
 # it has its own test (a baseline step at these dims IS cfg-C)
@@ -710,7 +712,10 @@ def test_full_size_properties(name):
     both = model.eval_batch(np.stack([qry, qry2]))
     assert both[0] == np.float32(nll0) and both[1] == np.float32(model.eval_step(qry2))
     losses = [model.train_step(sup, qry) for _ in range(4)]
-    assert np.all(np.isfinite(losses)) and losses[0] > losses[1] > losses[2] > losses[3]
+    assert np.all(np.isfinite(losses)) and losses[0] > losses[1] > losses[2]
+    # (the fourth update overshoots at cfg-C's T = 128 -- two layers of 1024 at lr 5e-3 on one repeated episode: 8.457, 8.447, 8.170, 8.844;
+    # the gradients and the update of that size are pinned against the fp64 oracle in test_full_size_gradients_match_oracle)
+    assert losses[2] > losses[3] or name == 'cfg-C-T128'
     again = new_model(cfg)
     assert [again.train_step(sup, qry) for _ in range(4)] == losses
 
@@ -909,6 +914,17 @@ def test_full_size_gradients_match_oracle(name, gemm_kind):
     assert abs(tail[0] - aux['embedding_slices_sq']) <= 1e-4 * aux['embedding_slices_sq']
     for name_ in grads:
         assert rel_max(model.get_grad(name_), grads[name_]) < 2e-4, name_
+    # element-wise on the embedding gradient (the max-norm above is blind to one wrong small row, e.g. a rare token's): rows of tokens
+    # that do not occur are exact zeros, and every element of the rows that do is within 2e-4 of its own value plus 1e-7 of the
+    # tensor's largest element (the heavy rows -- padding, START -- are sums over ~1000 positions and set that maximum)
+    got_e, want_e = model.get_grad('embedding').astype(np.float64), grads['embedding']
+    used = np.zeros(want_e.shape[0], bool)
+    used[np.unique(cache['X'])] = True
+    assert not got_e[~used].any() and not want_e[~used].any()
+    err = np.abs(got_e[used] - want_e[used])
+    bound = 2e-4 * np.abs(want_e[used]) + 1e-7 * np.abs(want_e).max()
+    worst = np.unravel_index(np.argmax(err / bound), err.shape)
+    assert (err <= bound).all(), ('embedding row %d' % np.flatnonzero(used)[worst[0]], err[worst], bound[worst], want_e[used][worst])
     got = model.apply_update(1.0)
     opt = O.new_opt_state(params)
     O.apply_update(params, grads, aux, opt, cfg)
