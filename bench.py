@@ -14,8 +14,9 @@ With N > 1 every rank trains on its own episode per step and one RCCL all-reduce
 buffer (weak scaling: per-GPU work fixed); value = N * K / max-over-ranks time.  `python bench.py --gpus N` WITHOUT a
 torchrun environment starts its own N ranks (re-executes itself under torch.distributed.run on 127.0.0.1, rank r on GPU r)
 and prints rank 0's line; under torchrun (RANK / WORLD_SIZE set) it is one rank of the job.  For N > 1 the timed loop runs
-once per exchange schedule IN THE SAME RUN (`schedules`): "graph_end" (one graph per backward pass, the three gradient
-buckets reduced on the communication stream when it ends), "split_bucket0" (two graphs: bucket 0 = softmax gradients, 56 %
+the DEFAULT exchange schedule only -- "graph_end" (one graph per backward pass, the three gradient
+buckets reduced on the communication stream when it ends) --; FSMG_BENCH_SCHEDULES=all (or a comma list) times the others
+behind it IN THE SAME RUN (`schedules`), each only after graph_end has produced a guarded result: "split_bucket0" (two graphs: bucket 0 = softmax gradients, 56 %
 of the bytes, is released behind the projection-gradient GEMMs and travels under BPTT), "split_after_chain" (the same with
 the cut behind the last recurrent chain: an XCD-local chain needs every CU, so a collective started in front of it only
 delays it; behind it bucket 0 travels beside the weight- / input-gradient GEMMs) and "one_collective" (a single
@@ -426,6 +427,27 @@ def val_nll_leg(cfg, eng, step, args, shape, device):
                     'back from the device; bar 1e-4 relative' % (len(held), args.pool, trained)}
 
 
+def exchange_plans(world, env, same_gpu=False):
+    """The gradient-exchange schedules a run times, in order: [(name, model-config overrides)].  One GPU: nothing to exchange.  N > 1: by
+    DEFAULT only "graph_end" -- what `train.train` and the shipped configuration run (one graph per backward pass, the three buckets
+    reduced on the communication stream when it ends); it is the conservative one: no RCCL kernel ever runs beside a persistent chain
+    that needs every CU of its XCDs.  FSMG_BENCH_SCHEDULES=all, or a comma list of split_bucket0 / split_after_chain / one_collective /
+    library_rccl, adds the others BEHIND it (main() times them only after graph_end has produced a guarded result on every rank); the
+    library-owned exchange (fsmg_comm_*: one rank is all it has ever seen) additionally needs FSMG_BENCH_LIBRARY_RCCL=1 and real GPUs."""
+    if world == 1:
+        return [('single_gpu', {})]
+    optional = [('split_bucket0', {'dp_split_backward': True}), ('split_after_chain', {'dp_split_backward': 2}), ('one_collective', {'bucketed': False})]
+    if env.get('FSMG_BENCH_LIBRARY_RCCL', '0') == '1' and not same_gpu:
+        optional.append(('library_rccl', {'dp_exchange': 'library', 'dp_split_backward': True}))
+    want = [w.strip() for w in env.get('FSMG_BENCH_SCHEDULES', '').split(',') if w.strip()]
+    plans = [('graph_end', {})]
+    if 'all' in want:
+        plans += optional
+    else:
+        plans += [pl for pl in optional if pl[0] in want]
+    return plans
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torchrun: start N ranks of this script under torch.distributed.run (rank r -> GPU r,
     rendezvous on 127.0.0.1), pass their output through and print rank 0's JSON line LAST."""
@@ -582,27 +604,19 @@ def main():
              'persistent_path': bool(stats['persistent_path']), 'fallback_steps_left': stats['fallback_steps_left'],
              'xcd_local_kernels': stats['xcd_launches'] > 0,
              'xov_selfcheck_mismatches': stats.get('xov_selfcheck_mismatches'), 'softmax_range_rows': stats.get('softmax_range_rows'),
+             'steps_skipped_softmax_range': stats.get('steps_skipped_softmax_range'),
+             # [passes whose gated projection was recomputed and compared, passes under the XCD-partitioned order, the period]
+             'xov_selfcheck': [int(v) for v in eng_.debug_read('xov_selfcheck', 3)], 'aux_stream_tries': stats.get('aux_stream_tries'),
              'fused_softmax_taken': bool(eng_.debug_read('fused_softmax', 2)[1]),
              'ok': (step_after - step_before == args.steps * REPEATS and step_before - step0 == args.warmup and stats['timeouts'] == 0
                     and stats['steps_skipped_timeout'] == 0 and stats['steps_skipped_token_range'] == 0
-                    and not stats.get('xov_selfcheck_mismatches') and not stats.get('softmax_range_rows'))}
+                    and not stats.get('xov_selfcheck_mismatches') and not stats.get('softmax_range_rows') and not stats.get('steps_skipped_softmax_range'))}
         return els, g
 
-    # exchange schedules timed in this run (N > 1); a single GPU has nothing to exchange: one graph per step
-    if world == 1:
-        plans = [('single_gpu', {})]
-    else:
-        plans = [('graph_end', {}), ('split_bucket0', {'dp_split_backward': True}), ('split_after_chain', {'dp_split_backward': 2}),
-                 ('one_collective', {'bucketed': False})]
-        if os.environ.get('FSMG_BENCH_LIBRARY_RCCL', '0') == '1' and not same_gpu:
-            # opt-in: the exchange issued by libfsmg itself (fsmg_comm_*; tested with one rank on the GPU box, never yet with
-            # N > 1 -- kept out of the default plans so that a first multi-GPU run cannot be lost to it)
-            os.environ['FSMG_ALLOW_LIBRARY_RCCL'] = '1'
-            plans.append(('library_rccl', {'dp_exchange': 'library', 'dp_split_backward': True}))
-        if os.environ.get('FSMG_BENCH_SCHEDULES'):
-            keep = os.environ['FSMG_BENCH_SCHEDULES'].split(',')
-            plans = [pl for pl in plans if pl[0] in keep] or plans[:1]
-    schedules, built, failed_plans = {}, {}, {}
+    plans = exchange_plans(world, os.environ, same_gpu)
+    if any(pl[0] == 'library_rccl' for pl in plans):
+        os.environ['FSMG_ALLOW_LIBRARY_RCCL'] = '1'
+    schedules, built, failed_plans, skipped_plans = {}, {}, {}, {}
     keeper = None          # the ONE handle that stays alive: the first plan that ran, replaced by the first whose guard holds (what `used` picks)
 
     def drop(m_):
@@ -611,6 +625,11 @@ def main():
         except Exception:                      # noqa: BLE001
             pass
     for name, env_over in plans:
+        # the opt-in schedules are timed only once the default one has produced a guarded result on every rank: the first minutes
+        # on an N-GPU node belong to the schedule the shipped configuration runs, not to fall-backs of its variants
+        if name != plans[0][0] and not (plans[0][0] in schedules and schedules[plans[0][0]]['guard_ok']):
+            skipped_plans[name] = 'not timed: the default schedule %r did not produce a guarded result first' % plans[0][0]
+            continue
         # a schedule that cannot be built or run on this box must not cost the run its result line: every rank reports whether
         # it got through, and the schedule counts only if all did (the first plan is the one the step has always used)
         err = None
@@ -804,7 +823,7 @@ def main():
             'per_rank_ms_per_step': [1e3 * t / max(args.steps, 1) for t in per_rank], 'comm': comm,
             'schedule_used': used,
             'schedules': {n: {k: v for k, v in sc.items() if k != 'guard_per_rank'} for n, sc in schedules.items()},
-            'schedules_failed': failed_plans,
+            'schedules_failed': failed_plans, 'schedules_skipped': skipped_plans,
             'guard_per_rank': schedules[used]['guard_per_rank'], 'world': world_info,
         }
         if cell:

@@ -50,6 +50,11 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
     if (!std::strcmp(what, "aux_tries")) { host[0] = (float)h->aux_tries; return FSMG_OK; }       // streams drawn until one ran beside the handle's (-1: none did)
     if (!std::strcmp(what, "fused_softmax")) { host[0] = h->fused_softmax ? 1.0f : 0.0f; if (count > 1) host[1] = h->fs_call ? 1.0f : 0.0f; return FSMG_OK; }   // [0] the knob, [1] whether the last train pass took it
     if (!std::strcmp(what, "xcd_bx3")) { host[0] = h->xcd_bx3 ? 1.0f : 0.0f; return FSMG_OK; }      // a host-side fact: which XCD-local kernel family this handle runs
+    if (!std::strcmp(what, "xov_selfcheck")) {        // [0] passes that recomputed and compared the gated projection, [1] passes that took the XCD-partitioned order, [2] the period
+        const float v[3] = {(float)h->xov_selfcheck_runs, (float)h->xov_passes, (float)h->xov_selfcheck_every};
+        for (int64_t i = 0; i < count && i < 3; ++i) host[i] = v[i];
+        return FSMG_OK;
+    }
     if (!std::strcmp(what, "xcd_partitioned")) {      // ... and whether its train passes take the XCD-partitioned order: [0] yes / no, [1] XCDs the chains occupy, [2] the last pass
         host[0] = h->xov ? 1.0f : 0.0f;
         if (count > 1) { const int b = h->lastB > 0 ? h->lastB : 45, rpx = lstm_xcd16_packed_rows(b); host[1] = (h->xov && rpx > 0) ? (float)((b + rpx - 1) / rpx) : 8.0f; }

@@ -106,6 +106,7 @@ int logits_and_ce(fsmg_model* h, const Lane& ln, int B, int t0, int t1, int64_t 
 // fsmg_stats.xov_selfcheck_mismatches, and on_timeout() parks the order for the handle.  ~0.4 ms per checked pass.
 int xov_selfcheck(fsmg_model* h, int B) {
     --h->xov_selfcheck_left;
+    ++h->xov_selfcheck_runs;
     const int64_t rows = (int64_t)h->T * B;
     if (!h->xov_selfcheck_fault) {
         GemmArgs g = logits_args(h, B, 0, h->T);
@@ -302,6 +303,11 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
 #endif
             HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));    // the restricted launch and its tiles in flight
         }
+        // ... and one pass in every `xov_selfcheck_every` (1000: ~0.4 ms per 1.6 s of training, 0.03 %) for the handle's whole life: the
+        // property the unfenced read rests on belongs to the runtime / firmware, and a stale line on step 40 000 would be as silent
+        // as one on step 2.  Re-armed here, on the host, by the count of passes that took this order.
+        ++h->xov_passes;
+        if (h->xov_selfcheck_every > 0 && h->xov_selfcheck_left <= 0 && h->xov_passes % h->xov_selfcheck_every == 0) h->xov_selfcheck_left = 1;
         if (h->xov_selfcheck_left > 0) GEMMCK(xov_selfcheck(h, B));
         if (h->fs_call) GEMMCK(ce_finish(h, s, B, rows));
         else if (!ce_tail) GEMMCK(ce_rows(h, s, B, 0, T, rows));

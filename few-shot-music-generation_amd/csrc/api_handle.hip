@@ -27,23 +27,34 @@ static int pick_concurrent_aux(fsmg_model* h, int priority, int max_tries) {
     }
     int* d = nullptr;
     if (hipMalloc((void**)&d, 256) != hipSuccess) return fail(h, FSMG_ERR_NOMEM, "hipMalloc(queue probe) failed");
+    // does `cand` run beside the main stream?  1 / 0, or -1 when the probe itself failed.  `ticks`: how long the waiter polls (100 MHz)
+    auto probe = [&](hipStream_t cand, long long ticks) -> int {
+        int seen = 0;
+        const int init[2] = {0, -1};
+        if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess ||
+            launch_queue_probe(h->stream, d, d + 1, 0, ticks) != hipSuccess || launch_queue_probe(cand, d, d + 1, 1, 0) != hipSuccess ||
+            hipStreamSynchronize(cand) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
+            hipMemcpy(&seen, d + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return seen == 1 ? 1 : 0;
+    };
     std::vector<hipStream_t> rejected;
     int rc = FSMG_OK, found = 0;
     for (int t = 1; t <= max_tries && rc == FSMG_OK && !found; ++t) {
         hipStream_t cand = nullptr;
         if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, priority) != hipSuccess) { rc = fail(h, FSMG_ERR_HIP, "aux stream create failed"); break; }
-        int seen = 0;
-        const int init[2] = {0, -1};
-        if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess ||
-            launch_queue_probe(h->stream, d, d + 1, 0, 30000) != hipSuccess || launch_queue_probe(cand, d, d + 1, 1, 0) != hipSuccess ||
-            hipStreamSynchronize(cand) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
-            hipMemcpy(&seen, d + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
-            hipStreamDestroy(cand);
-            rc = fail(h, FSMG_ERR_HIP, "queue probe failed");
-            break;
-        }
+        const int seen = probe(cand, 30000);
+        if (seen < 0) { hipStreamDestroy(cand); rc = fail(h, FSMG_ERR_HIP, "queue probe failed"); break; }
         if (seen == 1) { h->aux = cand; h->aux_tries = t; found = 1; }
         else rejected.push_back(cand);
+    }
+    // Nobody ran beside the waiter within 300 us: either the process's streams really share the hardware queues, or the GPU was busy
+    // with somebody else's work at that moment (another rank or process on the same device, shared CI) and the setter simply was not
+    // scheduled in time (a false negative here switched the XCD-partitioned order off for the handle's whole life).  Ask the
+    // same candidates once more with a 5 ms window before settling for the serial order.
+    for (size_t i = 0; rc == FSMG_OK && !found && i < rejected.size(); ++i) {
+        const int seen = probe(rejected[i], 500000);
+        if (seen < 0) { rc = fail(h, FSMG_ERR_HIP, "queue probe failed"); break; }
+        if (seen == 1) { h->aux = rejected[i]; h->aux_tries = (int)(max_tries + i + 1); found = 1; rejected.erase(rejected.begin() + (long)i); }
     }
     if (rc == FSMG_OK && !found) {          // no stream of this process runs beside the main one: keep one for the API's sake, remember it is serial
         h->aux = rejected.back(); rejected.pop_back();
@@ -63,17 +74,23 @@ int settle_pending(fsmg_model* h) {
     return FSMG_OK;
 }
 
+std::mutex& turn_mutex() { static std::mutex mu; return mu; }
 namespace {
-std::mutex g_turn_mu;
 fsmg_model* g_turn_last[16] = {};         // per device: the handle whose call returned last
 bool turnstile_on() { static const bool on = !(std::getenv("FSMG_TURNSTILE") && std::atoi(std::getenv("FSMG_TURNSTILE")) == 0); return on; }
 }
 // (begin_call) behind what the handle that had the device before this one has issued so far
 static int take_turn(fsmg_model* h) {
     if (!turnstile_on() || h->ev_turn == nullptr) return FSMG_OK;
-    std::lock_guard<std::mutex> lk(g_turn_mu);
+    std::lock_guard<std::mutex> lk(turn_mutex());
     fsmg_model*& last = g_turn_last[h->device & 15];
-    if (last != nullptr && last != h && last->stream != nullptr && !last->capturing.load()) {
+    // a stream that is capturing takes no event record from outside its capture: the library's own captures hold turn_mutex() from
+    // BeginCapture to EndCapture (run_graphed), a caller capturing the stream it handed over in fsmg_config is asked here
+    auto capturing = [](hipStream_t s) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        return s != nullptr && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+    };
+    if (last != nullptr && last != h && last->stream != nullptr && !last->capturing.load() && !capturing(last->stream) && !capturing(last->aux)) {
         HIPCK(h, hipEventRecord(last->ev_turn, last->stream));
         HIPCK(h, hipEventRecord(last->ev_turn_aux, last->aux != nullptr ? last->aux : last->stream));
         HIPCK(h, hipStreamWaitEvent(h->stream, last->ev_turn, 0));
@@ -87,7 +104,7 @@ static int take_turn(fsmg_model* h) {
     return FSMG_OK;
 }
 static void forget_turn(fsmg_model* h) {          // fsmg_destroy: nobody may wait on this handle's events any more
-    std::lock_guard<std::mutex> lk(g_turn_mu);
+    std::lock_guard<std::mutex> lk(turn_mutex());
     if (g_turn_last[h->device & 15] == h) g_turn_last[h->device & 15] = nullptr;
 }
 
@@ -172,6 +189,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
 
         if (const char* e = std::getenv("FSMG_INPLACE_DLOGITS")) h->inplace_dlogits = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_XOV_SELFCHECK")) h->xov_selfcheck_left = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("FSMG_XOV_SELFCHECK_EVERY")) h->xov_selfcheck_every = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("FSMG_PERSISTENT")) h->persist = (e[0] != '0');
         h->persist_cfg = h->persist;
         if (const char* e = std::getenv("FSMG_FALLBACK_STEPS")) h->fallback_steps = std::max(1, std::atoi(e));
@@ -207,7 +225,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (hipEventCreateWithFlags(&h->ev_turn, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_turn_aux, hipEventDisableTiming) != hipSuccess) return bail(FSMG_ERR_HIP, "event create failed");
         if (turnstile_on()) {      // the probe below asks whether two streams of this handle run side by side: not while another handle's pass has the chip
-            std::lock_guard<std::mutex> lk(g_turn_mu);
+            std::lock_guard<std::mutex> lk(turn_mutex());
             fsmg_model* last = g_turn_last[h->device & 15];
             if (last != nullptr && last->stream != nullptr && !last->capturing.load()) { (void)hipStreamSynchronize(last->stream); if (last->aux) (void)hipStreamSynchronize(last->aux); }
         }
@@ -215,8 +233,9 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
             static const int tries = std::getenv("FSMG_AUX_TRIES") ? std::max(0, std::min(32, std::atoi(std::getenv("FSMG_AUX_TRIES")))) : 8;
             if (pick_concurrent_aux(h, 0, tries) != FSMG_OK) { std::string e = h->err; return bail(FSMG_ERR_HIP, e); }
             if (h->aux_tries < 0) {
-                fprintf(stderr, "[fsmg] no second stream of this process runs beside the handle's stream (%d candidates share its hardware queue: "
-                                "GPU_MAX_HW_QUEUES?): serial order, no overlapped tails for this handle\n", tries);
+                fprintf(stderr, "[fsmg] no second stream of this process runs beside the handle's stream (%d candidates, probed for 300 us and again for 5 ms: "
+                                "they share its hardware queue -- GPU_MAX_HW_QUEUES? -- or the device was busy with another process): serial order, no overlapped "
+                                "tails for this handle (fsmg_stats.aux_stream_tries = -1; fsmg_debug_set(\"reprobe_aux\", 1) asks again)\n", tries);
                 h->overlap = false; h->overlap_forced = true; h->tail_aside = false; h->upd_split = false;
             }
         }
@@ -296,6 +315,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
                                   4 + items <= fsmg_model::XOV_CTL;
             if (cfg->schedule == FSMG_SCHEDULE_AUTO && std::getenv("FSMG_XCD_OVERLAP") == nullptr && !h->overlap_forced) h->xov = eligible;
         }
+        h->xov_eligible = h->xov;
         if (h->aux_tries < 0) h->xov = false;           // its two launches would run one after the other (pick_concurrent_aux)
         // the XCD-partitioned schedule packs the rows on ceil(B / 16) XCDs: only the bf16-split kernels take 16 rows per XCD at one
         // MFMA phase's cost
@@ -428,6 +448,8 @@ int fsmg_get_stats(fsmg_handle h, fsmg_stats* out) {
     out->steps_skipped_peer_failure = h->host_counters ? h->host_counters[2] : 0;
     out->xov_selfcheck_mismatches = h->host_counters ? h->host_counters[3] : 0;
     out->softmax_range_rows = h->host_counters ? h->host_counters[4] : 0;
+    out->steps_skipped_softmax_range = h->host_counters ? h->host_counters[5] : 0;
+    out->aux_stream_tries = h->aux_tries; out->reserved0 = 0;
     out->xcd_launches = h->n_xcd_launches;
     out->persistent_launches = h->n_persist_launches;
     out->step_launches = h->n_step_launches;
@@ -447,11 +469,30 @@ int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value) {
     else if (!std::strcmp(what, "persistent")) { h->persist = h->persist_cfg = value != 0; h->fallback_left = 0; }
     else if (!std::strcmp(what, "inplace_dlogits")) h->inplace_dlogits = value != 0;
     else if (!std::strcmp(what, "upd_split")) h->upd_split = value != 0;
+    else if (!std::strcmp(what, "reprobe_aux")) {
+        // the create-time probe found no stream running beside the handle's own (aux_stream_tries = -1), possibly because the device was
+        // busy with somebody else's work at that moment: ask again.  On success the overlapped tails come back; the XCD-partitioned order
+        // only where the handle was created with the recurrent-kernel format it needs (xov_eligible: decided at creation)
+        if (value != 0 && h->aux_tries < 0) {
+            HIPCK(h, hipStreamSynchronize(h->stream));
+            if (h->aux) HIPCK(h, hipStreamSynchronize(h->aux));
+            hipStream_t old = h->aux; h->aux = nullptr;
+            const int rc = pick_concurrent_aux(h, 0, 8);
+            if (rc != FSMG_OK) { if (h->aux == nullptr) h->aux = old; return rc; }
+            if (old) hipStreamDestroy(old);
+            if (h->aux_tries > 0) {
+                h->overlap = true; h->overlap_forced = false; h->tail_aside = true;
+                if (h->xov_eligible && h->xcd_bx3) h->xov = true;
+                drop_graphs(h);
+            }
+        }
+    }
     else if (!std::strcmp(what, "tail_aside")) h->tail_aside = value != 0;
     else if (!std::strcmp(what, "fused_softmax")) h->fused_softmax = value != 0;
 
     else if (!std::strcmp(what, "xov_selfcheck")) h->xov_selfcheck_left = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (!std::strcmp(what, "xov_selfcheck_fault")) h->xov_selfcheck_fault = value != 0;
+    else if (!std::strcmp(what, "xov_selfcheck_every")) h->xov_selfcheck_every = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else return fail(h, FSMG_ERR_NAME, std::string("unknown knob '") + what + "'");
     drop_graphs(h);
     return FSMG_OK;

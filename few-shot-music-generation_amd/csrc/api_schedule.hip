@@ -89,14 +89,15 @@ int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g, OpBatc
         HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_side, 0));
         h->side_pending = false;
     }
+    if (deferred && sq != nullptr && g.row_scale != nullptr) return fail(h, FSMG_ERR_STATE, "internal: row-scaled GEMM with squared-norm partials");
     float* C = g.C; float* colsum = g.colsum;
     g.C = slabs; g.c_slab = mn; g.ksplit = S;
     if (colsum) { g.colsum = cslabs; g.colsum_slab = g.N; }
     HIPCK(h, launch_gemm(s, amode, bmode, g, ln.lds_pad));
     if (deferred) {
-        GEMMCK(defer->room(colsum ? 2 : 1));
-        GEMMCK(defer->reduce(slabs, mn, S, C, mn, sq, sq == nullptr ? g.row_scale : nullptr, g.N));
         if (sq != nullptr && g.row_scale != nullptr) return fail(h, FSMG_ERR_STATE, "internal: row-scaled GEMM with squared-norm partials");
+        GEMMCK(defer->room(colsum ? 2 : 1));
+        GEMMCK(defer->reduce(slabs, mn, S, C, mn, sq, g.row_scale, g.N));
         if (colsum) GEMMCK(defer->reduce(cslabs, g.N, S, colsum, g.N));
         if (sq_done) *sq_done = sq != nullptr;
         return FSMG_OK;

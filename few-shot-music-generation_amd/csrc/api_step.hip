@@ -100,7 +100,7 @@ int dp_train_step(fsmg_model* h, float* loss, FB&& forward_backward) {
         if (local_rc != FSMG_OK) { h->err = local_msg; return local_rc; }
         // a time-out on ANY rank travelled in the reduced tail: every rank skipped the update, reports it here and repeats the
         // step on per-step launches, in lock-step
-        if (rc == FSMG_ERR_HIP && h->persist_timed_out && attempt == 0) { h->persist_timed_out = false; continue; }
+        if (is_retry(rc) && h->retry_armed && attempt == 0) { h->retry_armed = false; continue; }
         return rc;
     }
     return FSMG_OK;
@@ -112,11 +112,11 @@ int fused_train_step(fsmg_model* h, int32_t N, int32_t K, int32_t Q, float* loss
     if (h->comm != nullptr) return dp_train_step(h, loss, [&]() { return forward_backward_core(h, N, K, Q, stage, false); });
     int rc = forward_backward_core(h, N, K, Q, stage, true);
     if (rc == FSMG_OK) rc = after_update(h, 1.0f, loss);
-    if (rc == FSMG_ERR_HIP && h->persist_timed_out) {
+    if (is_retry(rc) && h->retry_armed) {
         // a persistent step kernel could not get all of its blocks resident (another workload holds the CUs): the
         // update kernels saw the flag and left parameters, Adam state and step counter alone, and the handle has
         // fallen back to one launch per time step -- repeat the step that way
-        h->persist_timed_out = false;
+        h->retry_armed = false;
         rc = forward_backward_core(h, N, K, Q, stage, true);
         if (rc == FSMG_OK) rc = after_update(h, 1.0f, loss);
     }
@@ -252,8 +252,8 @@ int fsmg_maml_step(fsmg_handle h, const int32_t* support, const int32_t* query, 
     int rc = fsmg_maml_forward_backward(h, support, query, N, K, Q, inner_steps, inner_lr, tokens_on_device);
     if (rc != FSMG_OK) return rc;
     rc = fsmg_apply_update(h, 1.0f, loss);
-    if (rc == FSMG_ERR_HIP && h->persist_timed_out) {        // same recovery as fsmg_train_step: nothing was updated, repeat per step
-        h->persist_timed_out = false;
+    if (is_retry(rc) && h->retry_armed) {        // same recovery as fsmg_train_step: nothing was updated, repeat per step
+        h->retry_armed = false;
         rc = fsmg_maml_forward_backward(h, support, query, N, K, Q, inner_steps, inner_lr, tokens_on_device);
         if (rc == FSMG_OK) rc = fsmg_apply_update(h, 1.0f, loss);
     }
@@ -312,8 +312,8 @@ int fsmg_maml_eval(fsmg_handle h, const int32_t* support, const int32_t* query, 
         const int rc2 = h->P_saved ? restore_theta(h) : FSMG_OK;
         h->have_grads = false;
         if (rc == FSMG_OK) rc = rc2;
-        if (!(rc == FSMG_ERR_HIP && h->persist_timed_out)) break;
-        h->persist_timed_out = false;                        // adapted with garbage (skipped) steps: repeat on per-step launches
+        if (!(is_retry(rc) && h->retry_armed)) break;
+        h->retry_armed = false;                        // adapted with garbage (skipped) steps: repeat on per-step launches
     }
     return rc;
 }
@@ -354,10 +354,10 @@ int fsmg_eval_batch(fsmg_handle h, const int32_t* queries, int32_t n_episodes, i
         if (rc != FSMG_OK) return rc;
         h->lastB = B;
         rc = check_tokens_and_read(h, h->d_eval, 1.0f, nll + e0, ne);
-        if (rc == FSMG_ERR_HIP && h->persist_timed_out && !retried) {
+        if (is_retry(rc) && h->retry_armed && !retried) {
             // a persistent kernel could not get its blocks resident: the handle has switched to one launch per time
             // step; repeat this chunk that way (validation must not abort a training run, nor leave peer ranks hanging)
-            h->persist_timed_out = false;
+            h->retry_armed = false;
             retried = true;
             e0 -= chunk_eps;
             continue;

@@ -154,7 +154,7 @@ int restore_theta(fsmg_model* h) {
 // for the next `fallback_steps` train steps, then the persistent path is tried again
 void on_timeout(fsmg_model* h) {
     ++h->n_timeouts;
-    h->persist_timed_out = true;
+    h->retry_armed = true;
     if (h->persist) {
         // reached from the asynchronous path too (after_update with loss == NULL polls the host-mapped tallies): later replays
         // of the same execs may still be queued or running, so drain both streams before the execs are destroyed
@@ -174,19 +174,6 @@ void on_timeout(fsmg_model* h) {
                             "(stale operand rows in an XCD's L2?): the step is repeated, serial order from here on\n", (long long)h->host_counters[3]);
         }
     }
-    // ... or a row's largest logit left the range the shift-free fused softmax is used for (k_ce_finish): the handle takes the
-    // cross-entropy pass with the shifted softmax from here on
-    if (h->host_counters && h->host_counters[4] != h->seen_softmax_range) {
-        h->seen_softmax_range = h->host_counters[4];
-        if (h->fused_softmax) {
-            h->fused_softmax = false;
-            hipStreamSynchronize(h->stream);
-            if (h->aux) hipStreamSynchronize(h->aux);
-            drop_graphs(h);                       // (a captured pass holds the fused path)
-            fprintf(stderr, "[fsmg] fused softmax: a row's sum of exp(logit) or its target's exp(logit) left the fp32 range of the shift-free form (%lld rows so far): the step is repeated, "
-                            "cross-entropy pass with the shifted softmax from here on\n", (long long)h->host_counters[4]);
-        }
-    }
     // two launches that must run side by side are one more way to time out (something serialises the dispatches: a counter-collecting
     // profiler, a debugger): a handle that has seen it twice keeps the serial order
     if (h->xov_last && ++h->xov_strikes >= 2 && h->xov) {
@@ -204,6 +191,23 @@ void on_timeout(fsmg_model* h) {
     h->tok_table_open = true;           // and the occurrence table may hold entries of a pass whose embed_grad was cut short
 }
 
+// A row's sum of exp(logit) or its target's exp(logit) left the range the shift-free fused softmax is used for (k_ce_finish raised
+// flag 4, k_step_increment tallied the skipped step in counters[5] -- on every rank of a data-parallel job: the indicator travels in the
+// reduced tail): the handle takes the cross-entropy pass with the shifted softmax from here on.  Nothing timed out: the persistent
+// kernels, the fallback period, the time-out tallies and the BPTT inboxes are left alone.
+void on_softmax_range(fsmg_model* h) {
+    h->retry_armed = true;
+    if (h->host_counters) h->seen_softmax_range = h->host_counters[4];
+    if (!h->fused_softmax) return;
+    h->fused_softmax = false;
+    hipStreamSynchronize(h->stream);
+    if (h->aux) hipStreamSynchronize(h->aux);
+    drop_graphs(h);                       // (a captured pass holds the fused path)
+    fprintf(stderr, "[fsmg] fused softmax: a row's sum of exp(logit) or its target's exp(logit) left the fp32 range of the shift-free form (%lld rows so far, "
+                    "this rank's): the step is repeated, cross-entropy pass with the shifted softmax from here on\n",
+            h->host_counters ? (long long)h->host_counters[4] : 0LL);
+}
+
 // Compares the host-mapped tallies of k_step_increment with what this handle has already seen (no synchronisation: the
 // caller decides whether the stream has been drained).  0 = nothing new, 2 = a train step was skipped after a time-out,
 // 1 = after a token-range error.
@@ -211,8 +215,9 @@ int poll_skipped(fsmg_model* h) {
     if (!h->host_counters) return 0;
     const long long to = h->host_counters[0], tk = h->host_counters[1];
     int what = 0;
-    const long long pf = h->host_counters[2];
+    const long long pf = h->host_counters[2], rg = h->host_counters[5];
     if (pf != h->seen_peer_failures) { h->seen_peer_failures = pf; what = 3; }
+    if (rg != h->seen_range_skips) { h->seen_range_skips = rg; on_softmax_range(h); what = 4; }
     if (tk != h->seen_token_errors) { h->seen_token_errors = tk; what = 1; }
     if (to != h->seen_timeouts) { h->seen_timeouts = to; on_timeout(h); what = 2; }
     return what;
@@ -220,8 +225,11 @@ int poll_skipped(fsmg_model* h) {
 
 int report(fsmg_model* h, int what) {
     if (what == 2)
-        return fail(h, FSMG_ERR_HIP, "persistent recurrent kernel timed out waiting for a peer block (blocks not co-resident); "
-                                     "this handle now uses one launch per time step");
+        return fail(h, FSMG_ERR_TIMEOUT, "persistent recurrent kernel timed out waiting for a peer block (blocks not co-resident); "
+                                         "the step was skipped, this handle now uses one launch per time step: repeat the step");
+    if (what == 4)
+        return fail(h, FSMG_ERR_SOFTMAX_RANGE, "a row's sum of exp(logit) or its target's exp(logit) left the fp32 range of the shift-free fused softmax; "
+                                               "the step was skipped, this handle now takes the cross-entropy pass with the shifted softmax: repeat the step");
     if (what == 1) return fail(h, FSMG_ERR_TOKEN_RANGE, "token id outside [0, input_size)");
     if (what == 3) return fail(h, FSMG_ERR_STATE, "a rank of the episode-parallel job failed before the gradient exchange: the step was skipped on every rank");
     return FSMG_OK;
@@ -240,6 +248,7 @@ int check_tokens_and_read(fsmg_model* h, const float* d_src, float scale, float*
     else if (err) {
         HIPCK(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
         if (err == 2) on_timeout(h);
+        else if (err == 4) on_softmax_range(h);
     }
     if (err) return report(h, err);
     for (int i = 0; i < n; ++i) host_out[i] = tmp[i] * scale;
@@ -253,7 +262,7 @@ int after_update(fsmg_model* h, float grad_scale, float* loss) {
     // handle to per-step launches; the skipped episodes stay skipped -- fsmg_get_stats counts them)
     const int what = poll_skipped(h);
     if (what == 1 || what == 3) return report(h, what);
-    return FSMG_OK;
+    return FSMG_OK;         // (2 / 4: the handle has switched already; the skipped episode stays skipped -- fsmg_get_stats counts it)
 }
 
 }  // namespace fsmg_host

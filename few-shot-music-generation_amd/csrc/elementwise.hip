@@ -454,6 +454,8 @@ __global__ __launch_bounds__(256) void k_ce_finish(const float2* __restrict__ pa
                                                    const float* __restrict__ hs, float* __restrict__ hs_scaled, int hp,
                                                    int* err_flag, unsigned long long* range_counter) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the weighted column sums of dW read crow[K .. K + 15] past this pass's rows (times zero-filled B rows): never a stale Inf / NaN there
+    if (blockIdx.x == 0 && threadIdx.x < 32) crow[rows + threadIdx.x] = 0.0f;
     if (row >= rows) return;
     const float2* p = part + (long long)row * nparts;
     float S = 0.0f;                               // = sum_v exp(x_v): the partials are un-shifted sums of the stored E values
@@ -469,7 +471,10 @@ __global__ __launch_bounds__(256) void k_ce_finish(const float2* __restrict__ pa
         crow[row] = c;
         // outside (or NaN / Inf): E, S or c left the normal fp32 range, or the target's E is too small to take its log
         if (!(S >= CE_SUM_MIN && S <= CE_SUM_MAX && et >= CE_TGT_MIN)) {           // this step takes the shifted softmax
-            *err_flag = 2;
+            // 4 = "a row left the fused softmax's range": its own flag value -- nothing timed out, no hand-off is left half-done, and
+            // the recurrent kernels' schedule is not at fault; a time-out or token-range flag already raised stays
+            atomicCAS(err_flag, 0, 4);
+            crow[row] = 0.0f;                         // (never an Inf / NaN weight in a later, smaller pass's column sums: NaN * 0 = NaN)
             atomicAdd_system(range_counter, 1ull);
             __threadfence_system();
         } else {
@@ -530,7 +535,10 @@ __device__ __forceinline__ void sum_partials_body(const double* __restrict__ par
     __syncthreads();
     if (tid == 0) {
         dst[0] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
-        if (flag_src != nullptr) { dst[2] = (*flag_src == 2) ? 1.0f : 0.0f; dst[3] = (*flag_src == 1) ? 1.0f : 0.0f; dst[4] = 0.0f; }
+        if (flag_src != nullptr) {
+            dst[2] = (*flag_src == 2) ? 1.0f : 0.0f; dst[3] = (*flag_src == 1) ? 1.0f : 0.0f; dst[4] = 0.0f;
+            dst[5] = (*flag_src == 4) ? 1.0f : 0.0f;        // fused-softmax range: travels in the reduced tail, every rank switches together
+        }
     }
     if (ce == nullptr) return;
     // the mean loss of a train pass (k_loss_reduce with one group: same order, same bits) -- nobody reads it before the
@@ -736,7 +744,7 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
         if (a.consume[0] == 0.0f) return;
         if (tid == 0) { s_scale = a.consume[1]; s_alpha = a.consume[2]; }
     } else {
-    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f || a.tail[4] != 0.0f) {
+    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f || a.tail[4] != 0.0f || a.tail[5] != 0.0f) {
         if (a.publish != nullptr && blockIdx.x == 0 && tid == 0) a.publish[0] = 0.0f;
         return;
     }
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(256) void k_adam_update(const UpdateArgs a) {
 __global__ __launch_bounds__(256) void k_sgd_update(const UpdateArgs a) {
     __shared__ double sh[4];
     __shared__ float s_scale;
-    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f || a.tail[4] != 0.0f) return;
+    if ((a.err_flag != nullptr && *a.err_flag != 0) || a.tail[2] != 0.0f || a.tail[3] != 0.0f || a.tail[4] != 0.0f || a.tail[5] != 0.0f) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;
     for (int i = tid; i < a.n_partials; i += 256) s += a.partials[i];

@@ -330,7 +330,7 @@ hipError_t launch_sqnorm_partials(hipStream_t s, const float* x, long long n, do
 struct UpdateArgs {
     float* p; float* m; float* v; const float* g; long long n;   // flat buffers
     const double* partials; int n_partials;       // squared-norm partials of everything that counts
-    const float* tail;                            // grad tail scalars (tail[0] = slices_sq, used when slices; tail[2] / tail[3] / tail[4] != 0: no update)
+    const float* tail;                            // grad tail scalars (tail[0] = slices_sq, used when slices; tail[2] .. tail[5] != 0: no update)
     int use_slices;                               // add tail[0]*grad_scale^2 to the norm
     float grad_scale;                             // 1/world (g is a SUM over ranks)
     float lr, n_decay, clip;
@@ -361,9 +361,11 @@ __device__ __forceinline__ void step_increment_body(const StepIncArgs& a) {
     const bool peer_timeout = a.loss_src != nullptr && a.loss_src[1] != 0.0f;      // loss_src is tail[1]; tail[2] is the indicator
     const bool peer_token = a.loss_src != nullptr && a.loss_src[2] != 0.0f;        // tail[3]: some rank's batch held an out-of-range id
     const bool peer_failed = a.loss_src != nullptr && a.loss_src[3] != 0.0f;       // tail[4]: some rank's pass failed on the host before the exchange
-    if (e != 0 || peer_timeout || peer_token || peer_failed) {
+    const bool peer_range = a.loss_src != nullptr && a.loss_src[4] != 0.0f;        // tail[5]: some rank's logits left the fused softmax's range
+    if (e != 0 || peer_timeout || peer_token || peer_failed || peer_range) {
         if (a.counters != nullptr) {
-            if (e == 2 || peer_timeout) a.counters[0] += 1; else if (e == 1 || peer_token) a.counters[1] += 1; else a.counters[2] += 1;
+            if (e == 2 || peer_timeout) a.counters[0] += 1; else if (e == 1 || peer_token) a.counters[1] += 1;
+            else if (e == 4 || peer_range) a.counters[5] += 1; else a.counters[2] += 1;
             __threadfence_system();
         }
         if (a.err_flag != nullptr) *a.err_flag = 0;

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -94,13 +95,14 @@ struct fsmg_model {
     int64_t inbox_floats = 0;
     bool bwd_rs = true;                 // FSMG_BWD_RS=0 selects the all-gather form
     int chain_spin_limit = 1 << 18;     // FSMG_CHAIN_SPIN_LIMIT (0 forces the timeout + fallback path: tests)
-    bool persist_timed_out = false;     // set when a persistent kernel gave up (the handle has switched to per-step launches)
+    bool retry_armed = false;           // a train step was skipped on the device and the handle has changed its schedule for the repeat: a persistent kernel
+                                        // gave up (per-step launches now) or a row left the fused softmax's range (cross-entropy pass now)
     bool persist_cfg = true;            // what the configuration asked for; `persist` is what is in force right now
     int fallback_steps = 200;           // FSMG_FALLBACK_STEPS: train steps on per-step launches after a time-out, then the persistent path is tried again
     int fallback_left = 0;
     long long* host_counters = nullptr; // host-mapped tallies written by k_step_increment: [0] steps skipped after a time-out, [1] after a token-range error
     long long* d_counters = nullptr;    // the same memory as the device sees it
-    long long seen_timeouts = 0, seen_token_errors = 0, seen_peer_failures = 0;
+    long long seen_timeouts = 0, seen_token_errors = 0, seen_peer_failures = 0, seen_range_skips = 0;
     bool force_fwd_rt = false;          // FSMG_FWD_RT=1: take the all-row-tiles forward kernel wherever it applies (tests)
     bool persist_fwd = true, persist_bwd = true;   // FSMG_PERSIST_FWD / FSMG_PERSIST_BWD = 0: that direction launches per step
     bool persist = true;                // FSMG_PERSISTENT=0: one launch per time step instead of one persistent launch per chain chunk
@@ -181,6 +183,7 @@ struct fsmg_model {
     // it leaves free
     int bx3 = 1;                        // FSMG_GEMM=f32 selects the fp32-MFMA GEMM, default: bf16-split (k_gemm_bx3)
     bool xov = false, xov_call = false;
+    bool xov_eligible = false;          // what `xov` was decided to be at creation before the second-stream probe had its say (fsmg_debug_set("reprobe_aux"))
     bool bucket0_recorded = false;      // backward() recorded ev_bucket[0] itself (two-stream / XCD-partitioned order)
     int xov_dw_split = 4;               // K split of dW under this schedule: an item must be short against the chain it runs beside
     int xov_tail = 0;                   // FSMG_XOV_TAIL: time steps whose projection rows are left to a chip-wide launch behind the chain (0: none)
@@ -227,6 +230,9 @@ struct fsmg_model {
     // self-check of the gated projection (XCD-partitioned order): the first passes of a handle compute the logits a second time on the
     // serial path and compare the words; a difference skips the step like a time-out and parks the order for this handle
     int xov_selfcheck_left = 2;         // FSMG_XOV_SELFCHECK=n
+    int xov_selfcheck_every = 1000;     // FSMG_XOV_SELFCHECK_EVERY / fsmg_debug_set("xov_selfcheck_every"): one more checked pass every this many passes
+                                        // under the XCD-partitioned order, for the handle's whole life (0: the first passes only)
+    long long xov_passes = 0, xov_selfcheck_runs = 0;      // passes that took the order / passes that were checked (fsmg_debug_read("xov_selfcheck"))
     bool xov_selfcheck_fault = false;   // fsmg_debug_set("xov_selfcheck_fault"): compare against a buffer that is NOT the recomputed logits (tests)
     long long seen_selfcheck_mismatch = 0;
     // cross entropy writes dlogits over the logits it has just read (one 230 MB buffer instead of two at cfg-B: the pair no longer
@@ -354,6 +360,10 @@ inline void drain_timers(fsmg_model* h) {
 // points pass keep_pending: their forward pass orders itself behind the update where it first reads the softmax parameters.
 int begin_call(fsmg_model* h, bool keep_pending = false);
 int settle_pending(fsmg_model* h);
+// the turnstile's lock (api_handle.hip take_turn).  run_graphed holds it from `capturing = true` to `capturing = false`: take_turn
+// reads the flag and records an event on the last handle's stream under the same lock, so it can never record into a capture that
+// began between its check and its record (check-then-act race between threads)
+std::mutex& turn_mutex();
 // One handle's passes at a time per device (begin_call -> take_turn, api_handle.hip).  The persistent kernels -- recurrence chains with
 // cross-CU hand-offs, gated work-queue GEMMs -- spin on CUs they hold and assume that their peers are resident; two handles of a process
 // whose calls overlap on the GPU (calls return before the work is done) time-share those CUs at best and run into the hand-off time-out
@@ -424,6 +434,10 @@ struct OpBatch {
     // row_scale (without sq only): out[i] = row_scale[i / row_len] * sum
     int reduce(const float* slabs, long long stride, int nslab, float* out, long long n, double* sq = nullptr, const float* row_scale = nullptr, int row_len = 0) {
         if (n <= 0) return FSMG_OK;
+        // the row scale is applied by k_multi_op's float4 branch only (elementwise.hip): refuse what would take another branch and come
+        // out UNSCALED instead of queueing it (today Hp % 16 == 0 keeps every caller on that branch)
+        if (row_scale != nullptr && (sq != nullptr || row_len <= 0 || ((n | stride | (long long)row_len) & 3) != 0))
+            return fail(h, FSMG_ERR_STATE, "internal: a row-scaled slab sum needs n, stride and row_len multiples of 4 and no squared-norm partials");
         const int rc = room(1); if (rc != FSMG_OK) return rc;
         MultiOp& o = r.op[r.count++];
         o = MultiOp{}; o.kind = MULTI_REDUCE; o.dst = out; o.src = slabs; o.stride = stride; o.nslab = nslab; o.n = n; o.sq = sq;
@@ -467,12 +481,16 @@ int run_graphed(fsmg_model* h, const std::string& key, F&& body) {
     if (it == h->graphs.end()) {
         hipGraph_t graph = nullptr;
         const int64_t x0 = h->n_xcd_launches, p0 = h->n_persist_launches, s0 = h->n_step_launches;
-        h->capturing.store(true);
-        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { h->capturing.store(false); return fail(h, FSMG_ERR_HIP, "hipStreamBeginCapture failed"); }
-        const int rc = body();
-        { auto& c = h->graph_counts[key]; c.xcd = h->n_xcd_launches - x0; c.persist = h->n_persist_launches - p0; c.step = h->n_step_launches - s0; c.bwd_xcd = h->last_bwd_xcd; }
-        const hipError_t e = hipStreamEndCapture(h->stream, &graph);
-        h->capturing.store(false);
+        int rc; hipError_t e;
+        {
+            std::lock_guard<std::mutex> turn_lk(turn_mutex());        // nobody records on this handle's streams while they capture (take_turn)
+            h->capturing.store(true);
+            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { h->capturing.store(false); return fail(h, FSMG_ERR_HIP, "hipStreamBeginCapture failed"); }
+            rc = body();
+            { auto& c = h->graph_counts[key]; c.xcd = h->n_xcd_launches - x0; c.persist = h->n_persist_launches - p0; c.step = h->n_step_launches - s0; c.bwd_xcd = h->last_bwd_xcd; }
+            e = hipStreamEndCapture(h->stream, &graph);
+            h->capturing.store(false);
+        }
         if (rc != FSMG_OK) { if (graph) hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess || graph == nullptr)
             return fail(h, FSMG_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -576,6 +594,8 @@ int sgd_update(fsmg_model* h, float lr);
 int save_theta(fsmg_model* h);
 int restore_theta(fsmg_model* h);
 void on_timeout(fsmg_model* h);
+void on_softmax_range(fsmg_model* h);
+inline bool is_retry(int rc) { return rc == FSMG_ERR_TIMEOUT || rc == FSMG_ERR_SOFTMAX_RANGE; }
 int poll_skipped(fsmg_model* h);
 int report(fsmg_model* h, int what);
 int check_tokens_and_read(fsmg_model* h, const float* d_src, float scale, float* host_out, int n, bool train_tail = false);

@@ -18,7 +18,10 @@ SCHEDULES = {'auto': 0, 'single_stream': 1, 'two_stream': 2, 'xcd_partitioned': 
 RECURRENCES = {'auto': 0, 'per_step': 1, 'column_split': 2, 'xcd_local': 3}
 
 ERRORS = {-1: 'FSMG_ERR_INVALID', -2: 'FSMG_ERR_NO_DEVICE', -3: 'FSMG_ERR_HIP', -4: 'FSMG_ERR_NOMEM',
-          -5: 'FSMG_ERR_NAME', -6: 'FSMG_ERR_SIZE', -7: 'FSMG_ERR_TOKEN_RANGE', -8: 'FSMG_ERR_STATE'}
+          -5: 'FSMG_ERR_NAME', -6: 'FSMG_ERR_SIZE', -7: 'FSMG_ERR_TOKEN_RANGE', -8: 'FSMG_ERR_STATE',
+          -9: 'FSMG_ERR_TIMEOUT', -10: 'FSMG_ERR_SOFTMAX_RANGE'}
+# the step was skipped on the device and the handle has changed how it runs the next one: repeat the call (include/fsmg.h)
+RETRY_CODES = (-9, -10)
 
 
 class FsmgError(RuntimeError):
@@ -41,7 +44,8 @@ class FsmgStats(C.Structure):
     _fields_ = [('timeouts', C.c_int64), ('steps_skipped_timeout', C.c_int64), ('steps_skipped_token_range', C.c_int64),
                 ('xcd_launches', C.c_int64), ('persistent_launches', C.c_int64), ('step_launches', C.c_int64),
                 ('persistent_path', C.c_int32), ('fallback_steps_left', C.c_int32), ('steps_skipped_peer_failure', C.c_int64),
-                ('xov_selfcheck_mismatches', C.c_int64), ('softmax_range_rows', C.c_int64)]
+                ('xov_selfcheck_mismatches', C.c_int64), ('softmax_range_rows', C.c_int64), ('steps_skipped_softmax_range', C.c_int64),
+                ('aux_stream_tries', C.c_int32), ('reserved0', C.c_int32)]
 
 
 _P = C.c_void_p

@@ -16,6 +16,8 @@ aliasing the flat gradient buffer) and apply_update(grad_scale) -> loss: the HIP
 import torch
 import torch.distributed as dist
 
+RETRY_CODES = (-9, -10)        # FSMG_ERR_TIMEOUT, FSMG_ERR_SOFTMAX_RANGE (fsmg.binding.RETRY_CODES; repeated here: no import of the binding on CPU-only ranks)
+
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world)."""
@@ -58,9 +60,11 @@ class EpisodeParallel(object):
         try:
             return self._train_step_once(support, query, want_loss, **kw)
         except Exception as e:
-            # a persistent recurrent kernel of SOME rank timed out: the indicator travelled in the reduced gradient
-            # tail, so every rank skipped the update, raised here and has fallen back to one launch per time step
-            if 'persistent recurrent kernel timed out' not in str(e):
+            # "the step was skipped on the device, repeat it" (include/fsmg.h: FSMG_ERR_TIMEOUT = -9, FSMG_ERR_SOFTMAX_RANGE = -10): a
+            # persistent kernel of SOME rank timed out, or a row of some rank's logits left the fused softmax's range.  The indicator
+            # travelled in the reduced gradient tail, so every rank skipped the update, raised here with the same status code and has
+            # switched (one launch per time step / the cross-entropy pass) -- every rank repeats the step, in lock-step
+            if getattr(e, 'code', None) not in RETRY_CODES:
                 raise
             return self._train_step_once(support, query, want_loss, **kw)
 

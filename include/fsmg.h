@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FSMG_VERSION 500 /* 0.5.0 */
+#define FSMG_VERSION 600 /* 0.6.0 */
 /* layout of struct fsmg_config AND of every other struct / flat-buffer layout a caller may hold (struct fsmg_stats, the padded
  * sizes fsmg_debug_dims reports): fsmg_create rejects any other value in .config_version, so a caller built against an older
  * header fails at create time instead of being overrun later.  4 (0.5.0): fsmg_stats grew (steps_skipped_peer_failure in 0.4.0,
@@ -52,7 +52,13 @@ enum {
     FSMG_ERR_NAME = -5,        /* unknown parameter / buffer name                    */
     FSMG_ERR_SIZE = -6,        /* element count does not match the named tensor      */
     FSMG_ERR_TOKEN_RANGE = -7, /* a token id was outside [0, input_size)             */
-    FSMG_ERR_STATE = -8        /* call sequence error (e.g. apply without backward)  */
+    FSMG_ERR_STATE = -8,       /* call sequence error (e.g. apply without backward)  */
+    /* the step was SKIPPED on the device (parameters, Adam state and global_step untouched) and the handle has changed how it runs
+     * the next one: repeat the call.  fsmg_train_step / _indexed / fsmg_maml_* repeat it themselves when a loss is read back. */
+    FSMG_ERR_TIMEOUT = -9,         /* a persistent kernel's hand-off or gate timed out (its blocks were not co-resident, or two launches that must
+                                      run side by side did not): the handle runs one launch per time step for `fallback_steps` steps */
+    FSMG_ERR_SOFTMAX_RANGE = -10   /* a row's sum of exp(logit) or its target's exp(logit) left the fp32 range of the shift-free fused softmax:
+                                      the handle takes the cross-entropy pass with the shifted softmax from here on (nothing else changes) */
 };
 
 enum { FSMG_CLIP_TF1_SLICES = 0, FSMG_CLIP_DENSE = 1 };
@@ -154,11 +160,13 @@ int fsmg_forward_backward(fsmg_handle h, const int32_t* support, const int32_t* 
  * are scalars that must be reduced with it: [0] = sum of squared embedding-slice gradients,
  * [1] = loss, [2] = non-zero when a persistent recurrent kernel of this rank timed out (its gradients are garbage):
  * fsmg_apply_update then leaves parameters, Adam state and step counter alone on every rank and, when it reads the
- * loss back, returns FSMG_ERR_HIP after switching the handle to one launch per time step -- repeat the step;
+ * loss back, returns FSMG_ERR_TIMEOUT after switching the handle to one launch per time step -- repeat the step;
  * [3] = non-zero when this rank's batch held a token id outside [0, input_size): summed like [2], so EVERY rank skips the
  * update (replicas stay identical) and every rank's read-back returns FSMG_ERR_TOKEN_RANGE;
  * [4] = non-zero when this rank's pass failed on the host before the exchange (library-owned exchange: the rank still joins
- * the collectives so that no peer blocks): every rank skips the update, peers' read-backs return FSMG_ERR_STATE */
+ * the collectives so that no peer blocks): every rank skips the update, peers' read-backs return FSMG_ERR_STATE;
+ * [5] = non-zero when a row of this rank's logits left the range of the shift-free fused softmax: summed like [2], every rank skips
+ * the update, switches to the cross-entropy pass with the shifted softmax and returns FSMG_ERR_SOFTMAX_RANGE -- repeat the step */
 #define FSMG_GRAD_TAIL 16
 int fsmg_grad_buffer(fsmg_handle h, void** device_ptr, int64_t* count);
 int fsmg_apply_update(fsmg_handle h, float grad_scale, float* loss);
@@ -279,6 +287,12 @@ typedef struct fsmg_stats {
     int64_t softmax_range_rows;         /* rows outside the range of the shift-free fused softmax (sum_v exp(logit) within [e^-60, 1e30],
                                            exp(target logit) >= 1e-30): the step that held them was skipped and repeated with the
                                            cross-entropy pass, which the handle keeps from then on */
+    int64_t steps_skipped_softmax_range; /* train steps the device skipped for that reason (own rows or a peer rank's: the indicator travels in
+                                           the reduced gradient tail, so every rank of a data-parallel job switches in the same step) */
+    int32_t aux_stream_tries;           /* second streams fsmg_create drew until one ran BESIDE the handle's own (the process's streams share a few
+                                           hardware queues); -1: none did -- the XCD-partitioned / two-stream orders are off for this handle, it runs
+                                           the serial order (slower, same results); fsmg_debug_set("reprobe_aux", 1) probes again */
+    int32_t reserved0;
 } fsmg_stats;
 int fsmg_get_stats(fsmg_handle h, fsmg_stats* out);
 
@@ -310,6 +324,12 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
  *   "xov_selfcheck"     XCD-partitioned order: the next `value` train passes recompute the gated projection on the serial path and
  *                       compare the words (default: the first 2 passes of a handle)
  *   "xov_selfcheck_fault" 1: the comparison runs against a buffer that is NOT the recomputed logits (tests of the recovery path)
+ *   "xov_selfcheck_every" XCD-partitioned order: besides the first passes, one pass in every `value` is checked the same way for the handle's
+ *                       whole life (default 1000: 0.03 % of the training time; 0: never again).  fsmg_debug_read("xov_selfcheck", 3) = [passes
+ *                       checked so far, passes that took the order, the period]
+ *   "reprobe_aux"       1: a handle whose create-time probe found no second stream running beside its own (fsmg_stats.aux_stream_tries = -1)
+ *                       probes again (300 us, then 5 ms per candidate); on success the overlapped tails -- and the XCD-partitioned order where the
+ *                       handle was created in the format it needs -- come back
  * Synchronises the stream and drops the captured graphs. */
 int fsmg_debug_set(fsmg_handle h, const char* what, int64_t value);
 /* shader clock the chip sustains while the handle works: _begin starts a one-wave probe on a stream of its own that compares the

@@ -32,7 +32,7 @@ def test_header_and_binding_and_library_agree(lib):
     out = subprocess.check_output(['nm', '-D', '--defined-only', library_path()], universal_newlines=True)
     exported = sorted(set(re.findall(r' T (fsmg_[a-z_]+)$', out, flags=re.M)))
     assert exported == declared, (set(exported) ^ set(declared))
-    assert lib.fsmg_version() == 500
+    assert lib.fsmg_version() == 600
 
 
 def test_library_contains_gfx950_code_object():

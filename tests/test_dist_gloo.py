@@ -147,7 +147,9 @@ class _TimeoutEngine(OracleEngine):
     def apply_update(self, grad_scale=1.0, want_loss=True):
         if float(self.grad_tensor[-self.TAIL + 2]) != 0.0:
             self.skipped += 1
-            raise RuntimeError('FSMG_ERR_HIP: persistent recurrent kernel timed out waiting for a peer block')
+            e = RuntimeError('FSMG_ERR_TIMEOUT: persistent recurrent kernel timed out waiting for a peer block')
+            e.code = -9           # the status code is the contract (include/fsmg.h FSMG_ERR_TIMEOUT; fsmg.binding.FsmgError.code), not the text
+            raise e
         return super(_TimeoutEngine, self).apply_update(grad_scale, want_loss)
 
 

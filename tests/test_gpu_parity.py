@@ -386,9 +386,10 @@ def test_persistent_kernel_timeout_falls_back_and_repeats_the_step(monkeypatch):
     # the split entry points report the failure instead of repeating (the caller owns the gradient exchange)
     model2 = new_model(cfg)
     model2.forward_backward(*eps[0])
-    with pytest.raises(Exception, match='persistent recurrent kernel timed out'):
+    from fsmg.binding import FsmgError, RETRY_CODES
+    with pytest.raises(FsmgError, match='persistent recurrent kernel timed out') as ei:
         model2.apply_update(1.0)
-    assert model2.step == 0
+    assert ei.value.code == -9 and ei.value.code in RETRY_CODES and model2.step == 0      # FSMG_ERR_TIMEOUT: "skipped, repeat the call"
     model2.forward_backward(*eps[0])
     assert model2.apply_update(1.0) == want[0]
 
@@ -915,21 +916,26 @@ def test_full_size_gradients_match_oracle(name, gemm_kind):
     for name_ in grads:
         assert rel_max(model.get_grad(name_), grads[name_]) < 2e-4, name_
     # element-wise on the embedding gradient (the max-norm above is blind to one wrong small row, e.g. a rare token's): rows of tokens
-    # that do not occur are exact zeros, and every element of the rows that do is within 2e-4 of its own value plus 1e-7 of the
-    # tensor's largest element (the heavy rows -- padding, START -- are sums over ~1000 positions and set that maximum)
+    # that do not occur are exact zeros, and every element of the rows that do is within 2e-4 of its own value plus 1e-6 of the
+    # tensor's largest element (the heavy rows -- padding, START -- are sums over ~1000 positions and set that maximum; a rare token's
+    # row is 1e-3 .. 1e-4 of it, so this floor still sees a wrong rare row where the max-norm's 2e-4 of the maximum is the size of the
+    # row itself.  Measured worst: 2.1e-7 of the maximum, on a heavily cancelling element of the padding row)
     got_e, want_e = model.get_grad('embedding').astype(np.float64), grads['embedding']
     used = np.zeros(want_e.shape[0], bool)
     used[np.unique(cache['X'])] = True
     assert not got_e[~used].any() and not want_e[~used].any()
     err = np.abs(got_e[used] - want_e[used])
-    bound = 2e-4 * np.abs(want_e[used]) + 1e-7 * np.abs(want_e).max()
+    bound = 2e-4 * np.abs(want_e[used]) + 1e-6 * np.abs(want_e).max()
     worst = np.unravel_index(np.argmax(err / bound), err.shape)
     assert (err <= bound).all(), ('embedding row %d' % np.flatnonzero(used)[worst[0]], err[worst], bound[worst], want_e[used][worst])
     got = model.apply_update(1.0)
     opt = O.new_opt_state(params)
     O.apply_update(params, grads, aux, opt, cfg)
+    # one Adam step: the update is sign-like, m / (sqrt(v) + eps) = g / (|g| + 1e-8), so it amplifies the gradient's error where |g| ~ eps --
+    # the bottom layer's bias at T = 128 under two layers (gate-gradient sums of ~1e-8): 2.9e-4 measured there, <= 1e-4 everywhere else
+    upd_tol = 5e-4 if name == 'cfg-C-T128' else 1e-4
     for name_, ref in params.items():
-        assert rel_max(model.get_param(name_), ref) < 1e-4, name_      # one Adam step (update is sign-like: sensitive where |g| ~ eps)
+        assert rel_max(model.get_param(name_), ref) < upd_tol, name_
     assert abs(got - loss) <= NLL_RTOL * abs(loss)
 
 
@@ -1238,6 +1244,32 @@ def test_xov_selfcheck_passes_on_this_runtime_and_a_fault_parks_the_order(monkey
     np.testing.assert_allclose(la, lb, rtol=2e-6)
 
 
+def test_xov_selfcheck_comes_back_periodically_and_a_late_fault_parks_the_order(monkeypatch):
+    """the self-check screened a handle's first two passes and then trusted the unfenced cross-XCD read forever.  It
+    now also runs on one pass in every `xov_selfcheck_every` (default 1000) for the handle's whole life.  Here with a period of 3: passes
+    1, 2 (the start-up screen), 3 and 6 are checked, 4 and 5 are not; a fault injected after pass 4 goes unnoticed on pass 5 (by design:
+    that pass is not checked) and is caught on pass 6 -- the step is skipped, repeated, and the order parked for the handle."""
+    monkeypatch.setenv('FSMG_XCD_OVERLAP', '1')
+    cfg = small_config(hidden_size=512, embedding_size=32, input_size=3000, max_len=32)
+    eps = O.synthetic_episodes(7, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=37)
+    a = new_model(cfg, max_sequences=45)
+    assert a.debug_read('xcd_partitioned', 2)[0] == 1.0 and a.debug_read('xov_selfcheck', 3)[2] == 1000.0      # the default period
+    a.debug_set('xov_selfcheck_every', 3)
+    for e in eps[:4]:
+        a.train_step(*e)
+    assert [int(v) for v in a.debug_read('xov_selfcheck', 3)] == [3, 4, 3]
+    st = a.stats()
+    assert st['xov_selfcheck_mismatches'] == 0 and st['timeouts'] == 0
+    a.debug_set('xov_selfcheck_fault', 1); a.debug_set('fallback_steps', 2)
+    a.train_step(*eps[4])                            # pass 5: not a checked pass
+    assert a.stats()['xov_selfcheck_mismatches'] == 0 and int(a.debug_read('xov_selfcheck', 3)[0]) == 3
+    a.train_step(*eps[5])                            # pass 6: checked -- skipped, repeated on per-step launches, parked
+    st = a.stats()
+    assert st['xov_selfcheck_mismatches'] > 0 and st['steps_skipped_timeout'] == 1 and a.step == 6
+    assert a.debug_read('xcd_partitioned', 1)[0] == 0.0 and int(a.debug_read('xov_selfcheck', 3)[0]) == 4
+    assert np.isfinite(a.train_step(*eps[6])) and a.step == 7 and int(a.debug_read('xcd_partitioned', 3)[2]) == 0
+
+
 @pytest.mark.parametrize('hidden,layers', [(512, 1), (1024, 2)])
 def test_lazy_column_split_copies_are_refreshed_before_anybody_reads_them(hidden, layers, monkeypatch):
     """Round 5: a handle whose passes take the XCD-local kernels refreshes only their register images behind an update; the
@@ -1386,8 +1418,20 @@ def test_fused_softmax_falls_back_when_a_logit_leaves_its_range(case):
     a.debug_set('fallback_steps', 1)
     la, lb = a.train_step(*eps[1]), b.train_step(*eps[1])
     st = a.stats()
-    assert st['softmax_range_rows'] > 0 and st['steps_skipped_timeout'] == 1 and a.step == b.step == 2
+    # its own cause with its own tally: nothing timed out, the persistent kernels stay in force, no fallback period starts
+    assert st['softmax_range_rows'] > 0 and st['steps_skipped_softmax_range'] == 1 and a.step == b.step == 2
+    assert st['steps_skipped_timeout'] == 0 and st['timeouts'] == 0 and st['persistent_path'] == 1 and st['fallback_steps_left'] == 0
     assert list(a.debug_read('fused_softmax', 2)) == [0.0, 0.0]
     assert abs(la - lb) <= 5e-6 * abs(lb)
     la, lb = a.train_step(*eps[2]), b.train_step(*eps[2])
-    assert abs(la - lb) <= 2e-5 * abs(lb) and a.stats()['steps_skipped_timeout'] == 1
+    assert abs(la - lb) <= 2e-5 * abs(lb) and a.stats()['steps_skipped_softmax_range'] == 1
+    # the split call sequence (episode-parallel path) reports the cause by status code, and the update it refused left the step alone
+    from fsmg.binding import FsmgError
+    c = new_model(cfg, max_sequences=N * (K + Q))
+    c.set_param('softmax_b', a.get_param('softmax_b'))
+    c.forward_backward(*eps[1])
+    with pytest.raises(FsmgError) as ei:
+        c.apply_update(1.0)
+    assert ei.value.code == -10 and c.step == 0 and c.stats()['steps_skipped_softmax_range'] == 1
+    c.forward_backward(*eps[1])
+    assert np.isfinite(c.apply_update(1.0)) and c.step == 1
