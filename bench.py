@@ -124,7 +124,8 @@ def hbm_traffic(variant=None):
     No x2 on FETCH_SIZE: the guide's gfx950 correction is calibrated for 16-B/lane streaming loads, and these kernels' raw
     FETCH_SIZE (47.7 MB forward) already equals their algorithmic read (Z: 47.2 MB).  (None, None) when no record exists."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r05_pmc.json')) as f:
+        pmc_name = 'r06_pmc.json' if os.path.isfile(os.path.join(ROOT, 'profiles', 'r06_pmc.json')) else 'r05_pmc.json'
+        with open(os.path.join(ROOT, 'profiles', pmc_name)) as f:
             rec = json.load(f)['kernels']
         per = {}
         for d in ('fwd', 'bwd'):
@@ -132,8 +133,8 @@ def hbm_traffic(variant=None):
             if hits:
                 per[d] = 1024.0 * (hits[0]['FETCH_SIZE_KB'] + hits[0]['WRITE_SIZE_KB'])
         if variant and len(per) == 2:
-            return sum(per.values()) / 2, ('recorded (profiles/r05_pmc.json, k_lstm_*_%s...>: raw FETCH_SIZE + WRITE_SIZE per launch, mean of forward '
-                                           '%.1f MB and backward %.1f MB)' % (variant, per['fwd'] / 1e6, per['bwd'] / 1e6))
+            return sum(per.values()) / 2, ('recorded (profiles/%s, k_lstm_*_%s...>: raw FETCH_SIZE + WRITE_SIZE per launch, mean of forward '
+                                           '%.1f MB and backward %.1f MB)' % (pmc_name, variant, per['fwd'] / 1e6, per['bwd'] / 1e6))
     except Exception:
         pass
     for name in ('r04_lstm_cell_pmc.json', 'r03_lstm_cell_pmc.json', 'r02_lstm_cell_pmc.json'):
@@ -187,11 +188,12 @@ def step_roofline(cfg, B, gf, ms_per_step, fused_softmax=False):
                    'fused softmax: exp(logit) written once + read twice, c*h written + read; '
                    'split-K slabs not included); frac_r04_definition = the round-4 figure, whose HBM term counted one logits round trip as necessary'}
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r05_pmc.json')) as f:
+        pmc_name = 'r06_pmc.json' if os.path.isfile(os.path.join(ROOT, 'profiles', 'r06_pmc.json')) else 'r05_pmc.json'
+        with open(os.path.join(ROOT, 'profiles', pmc_name)) as f:
             rec = json.load(f)
         if rec.get('step_hbm_bytes_measured') and rec.get('workload', '').startswith('cfg-B') and (E, H, L, T) == (250, 512, 1, 128):
             out['hbm_bytes_measured_recorded'] = rec['step_hbm_bytes_measured']
-            out['hbm_bytes_measured_source'] = 'profiles/r05_pmc.json: sum over the kernels of one train step of FETCH_SIZE + WRITE_SIZE (separate --pmc passes), recorded -- not a measurement of this run'
+            out['hbm_bytes_measured_source'] = 'profiles/' + pmc_name + ': sum over the kernels of one train step of FETCH_SIZE + WRITE_SIZE (separate --pmc passes), recorded -- not a measurement of this run'
     except Exception:
         pass
     return out

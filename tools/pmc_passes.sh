@@ -2,7 +2,7 @@
 # Counter passes of round 5: one counter set per rocprofv3 run, each under `timeout`, on the bare train loop
 # (tools/pmc_workload.py) so that FETCH and WRITE describe the SAME kernel instantiations.  Run on the GPU box:
 #   gpurun -- 'bash tools/pmc_passes.sh r05'        -> gpurun_out/r05_pmc*.{csv,txt,json}
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 ARGS=""

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the round artefacts on the GPU box into gpurun_out/ (copy the ones to keep into profiles/).
-#   gpurun -- 'bash tools/refresh_profiles.sh r05'
+#   gpurun -- 'bash tools/refresh_profiles.sh r06'
 # Every profiler invocation runs under `timeout` (round 4, call 47: a --pmc pass never returned); the counter passes live in
 # tools/pmc_passes.sh (one counter set per run, on the bare train loop).
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
@@ -11,7 +11,7 @@ rm -rf /tmp/prof_st; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_s
 python $R/tools/rocpd_stats.py $(find /tmp/prof_st -name "*.db" | head -1) > $O/${TAG}_bench_rocprofv3_kernel_stats.txt 2>&1
 python $R/tools/step_timeline.py $(find /tmp/prof_st -name "*.db" | head -1) 40 > $O/${TAG}_step_timeline.txt 2>&1
 # the other BASELINE.json configurations: bench line (un-profiled), per-kernel statistics and device timeline (profiled)
-for c in cfg-C cfg-E cfg-D ref-default; do
+for c in cfg-C cfg-C-T128 cfg-E cfg-D ref-default; do
   t=$(echo $c | tr -d '-')
   python $R/bench.py --config $c --steps 40 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_$c.json
   rm -rf /tmp/prof_$t; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$t -o st -- python $R/bench.py --config $c --steps 20 --warmup 6 --no-cpu-baseline --no-breakdown 2>/dev/null | tail -1 > /dev/null
