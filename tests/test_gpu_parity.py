@@ -1323,6 +1323,10 @@ def test_every_handle_of_a_process_gets_a_second_stream_that_runs_beside_its_own
     assert all(t >= 1 for t in tries), tries
     assert max(ms) < 1.25 * min(ms), (ms, tries)            # a serialised pair is +45 % at this shape
     assert all(m.stats()['timeouts'] == 0 for m in models)
+    # the probe's outcome is part of fsmg_stats, and asking again on a handle that has its stream changes nothing
+    assert [m.stats()['aux_stream_tries'] for m in models] == tries
+    models[0].debug_set('reprobe_aux', 1)
+    assert models[0].stats()['aux_stream_tries'] == tries[0] and np.isfinite(models[0].train_step(*eps[0]))
 
 
 def test_handles_of_one_process_take_turns_on_the_device():
