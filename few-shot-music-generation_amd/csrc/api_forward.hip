@@ -237,7 +237,7 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
                 { const int dbg = xov_debug(); a.progress_lag = ((dbg & 2) ? 2 : 0) | ((dbg & 256) ? 256 : 0); if ((dbg & 128) && (dbg & 1)) a.progress = nullptr; }
 #endif
                 a.progress_every = h->xov_pub; a.bx3 = h->xcd_bx3 ? 1 : 0;
-                a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, true, Hp, a.rpx);
+                a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, true, Hp, a.rpx, h->xcd_bx3);
                 a.KhX = h->khx + (size_t)(2 * l) * lstm_xcd_weight_floats((int)Hp, h->xcd_bx3); a.HX = h->HX; a.Z = h->Z[l]; a.Cs = h->Cs[l]; a.Hs = h->Hs[l];
                 a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_fwd_xcd(s, a));

@@ -320,7 +320,9 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         // the XCD-partitioned schedule packs the rows on ceil(B / 16) XCDs: only the bf16-split kernels take 16 rows per XCD at one
         // MFMA phase's cost
         if (h->xov && h->bx3 && h->Hp == 512) h->xcd_bx3 = true;
-        if (const char* e = std::getenv("FSMG_XCD_BX3")) h->xcd_bx3 = std::atoi(e) != 0 && h->Hp == 512;
+        // (hidden 1024: the bf16-split pair kernels share the arithmetic of the bf16-split GEMMs; a handle on the fp32 MFMA keeps the fp32 chains)
+        if (h->Hp == 1024 && !h->bx3) h->xcd_bx3 = false;
+        if (const char* e = std::getenv("FSMG_XCD_BX3")) h->xcd_bx3 = std::atoi(e) != 0 && (h->Hp == 512 || h->Hp == 1024);
         if (hipMalloc((void**)&h->khx, sizeof(float) * (size_t)h->L * 2 * lstm_xcd_weight_floats(h->Hp, h->xcd_bx3)) != hipSuccess)
             return bail(FSMG_ERR_NOMEM, "hipMalloc(XCD-local weight images) failed");
     }

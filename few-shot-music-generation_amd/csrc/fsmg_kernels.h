@@ -196,8 +196,14 @@ hipError_t launch_repack_kh(hipStream_t s, const float* Kh, float* fwd, float* b
 // variants of the XCD-local kernels (same results, different schedules of the cell threads' memory traffic)
 enum { XCD_DEFER_OUTPUTS = 16,      // forward: c / h / gate stores of step t are issued behind the poll of step t+1; backward: dz stores behind the drain
        XCD_NO_POLL_SLEEP = 32,      // no s_sleep between two polls of a hand-off
-       XCD_CHAINS = 64 };           // hidden 1024: the row groups of an XCD pair as independent chains (k_lstm_*_pair_chains)
-int lstm_xcd_default_variant(int B, bool forward, int Hp = 512, int rpx = 0);
+       XCD_CHAINS = 64,             // hidden 1024: the row groups of an XCD pair as independent chains (k_lstm_*_pair_chains)
+       XCD_PROBE = 128,             // k_lstm_*_pair16: a wave polls ONE word per lane (chosen so that the wave's lanes cover every producer of its
+                                    // fragments) and fetches the rest only when none of those shows the fill pattern
+       XCD_LOCAL_PLAIN = 256,       // k_lstm_bwd_pair16: partials / resets between CUs of the SAME XCD stay in its L2 (plain stores)
+       XCD_LATE_DRAIN = 1024,       // k_lstm_bwd_pair16: the wait for the inbox resets stands in front of the first partial store, not the MFMAs
+       XCD_STREAM = 512 };          // k_lstm_fwd_pair16 (with XCD_PROBE): behind a successful probe the fragments are ordinary (compiler-counted) loads
+                                    // consumed k step by k step under the MFMAs, checked afterwards; a miss redoes the step behind the sc1 poll
+int lstm_xcd_default_variant(int B, bool forward, int Hp = 512, int rpx = 0, bool bx3 = false);
 struct LstmFwdXcdArgs {
     const float* KhX;     // forward register image of K_h (launch_repack_kh_xcd)
     float* HX;            // [T+1][8][4][RG][2][64][4] hand-off buffer; index 0 = zero state, t0+1 .. t1 = 0xFF fill

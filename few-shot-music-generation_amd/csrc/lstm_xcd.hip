@@ -2028,6 +2028,8 @@ __global__ void k_repack_kh_pair(const float* __restrict__ Kh, float* __restrict
     repack_kh_pair_body(Kh, fwd, bwd, blockIdx.x, gridDim.x);
 }
 
+#include "lstm_pair16.h"        // hidden 1024 on the bf16 matrix pipe (k_lstm_*_pair16): textually part of this file
+
 // every layer's K_h into every layout the recurrent kernels read, ONE launch (blockIdx.y = 2 * layer + {0: the column-split
 // kernels' fragment order, 1: the XCD / XCD-pair register image}): the four repacks of a two-layer model were 56 us of a
 // 2.85 ms cfg-C step as separate launches
@@ -2037,6 +2039,7 @@ __global__ void k_repack_kh_all(const RepackAllArgs a, const StepIncArgs inc) {
     if (kind == 0) { if (a.mode != 1) repack_kh_chunked(a.Kh[l], a.cf[l], a.cb[l], a.Hp, blockIdx.x, gridDim.x); return; }
     if (a.xf[l] == nullptr || a.mode == 2) return;
     if (a.Hp == SH) repack_kh_slice_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
+    else if (a.Hp == PH && a.bx3) repack_kh_pair16_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
     else if (a.Hp == PH) repack_kh_pair_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
     else if (a.bx3) repack_kh_xcd16_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
     else repack_kh_xcd_body(a.Kh[l], a.xf[l], a.xb[l], blockIdx.x, gridDim.x);
@@ -2050,7 +2053,7 @@ hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a, const Ste
     for (int l = 0; l < a.n; ++l) if (a.xf[l] != nullptr && !(a.Hp == XH || a.Hp == PH || a.Hp == SH)) return hipErrorInvalidValue;
     const long long total = (long long)a.Hp * 4 * a.Hp / 4;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
-    if (a.bx3 && a.Hp != XH) return hipErrorInvalidValue;
+    if (a.bx3 && a.Hp != XH && a.Hp != PH) return hipErrorInvalidValue;
     StepIncArgs none{};
     hipLaunchKernelGGL(k_repack_kh_all, dim3(blocks, 2 * a.n), dim3(256), 0, s, a, inc ? *inc : none);
     return hipGetLastError();
@@ -2082,6 +2085,7 @@ bool lstm_xcd_supported(int B, int Hp) {
 int lstm_xcd_max_rows(int Hp) { return Hp == PH ? 16 * PGRP : (Hp == XH ? 16 * NXCD : (Hp == SH ? 8 * NSL : 0)); }
 
 long long lstm_xcd_hx_floats(int B, int T, int Hp, bool bx3, int rpx) {
+    if (Hp == PH && bx3) return (long long)(T + 1) * (4 * xcd_row_groups(B, Hp)) * PGRP * HXW16P * 4;       // rows x pairs x 6 KiB, see lstm_pair16.h
     if (Hp == PH) return (long long)(T + 1) * PGRP * 4 * xcd_row_groups(B, Hp) * PNQ * 64 * 4;
     if (Hp == SH) return (long long)(T + 1) * NSL * 4 * xcd_row_groups(B, Hp) * 64 * 4;
     if (bx3) return (long long)(T + 1) * (4 * xcd_row_groups_packed(B, rpx)) * NXCD * HXW16 * 4;      // rows x XCDs x 3 KiB, see k_lstm_fwd_xcd16
@@ -2094,16 +2098,20 @@ long long lstm_xcd_inbox_floats(int B, int Hp, int rpx) {
 }
 // the bf16-split kernels take up to 16 rows per XCD at the same MFMA cost: the fewest XCDs that hold B rows, rows spread evenly
 int lstm_xcd16_packed_rows(int B) { const int nx = (B + 15) / 16; return nx >= 1 && nx <= NXCD ? (B + nx - 1) / nx : 0; }
-long long lstm_xcd_weight_floats(int Hp, bool bx3) { return (bx3 && Hp == XH) ? (long long)Hp * 4 * Hp * 3 / 2 : (long long)Hp * 4 * Hp; }   // three bf16 planes
+long long lstm_xcd_weight_floats(int Hp, bool bx3) { return (bx3 && (Hp == XH || Hp == PH)) ? (long long)Hp * 4 * Hp * 3 / 2 : (long long)Hp * 4 * Hp; }   // three bf16 planes
 // The bf16-split kernels pay 1536 MFMA cycles per step for any row count, the fp32 ones 1024 per row group, and the bf16 hand-off
 // is 1.5x the bytes in 3x the load instructions: measured (profiles/r03_xcd16_probe3.log, us per step forward / backward)
 // B = 20: 2.68 / 2.17 against 1.81 / 1.64, B = 45: 2.57 / 2.35 against 2.17 / 2.38, B = 100: 2.98 / 3.22 against 3.86 / 4.35.
-bool lstm_xcd_bx3_pays(int B, int Hp) { return Hp == XH && xcd_row_groups(B) >= 3; }
+// Hidden 1024 (k_lstm_*_pair16, profiles/r06_pair16_*.log, us per step forward / backward against the fp32 pair kernels' best variants):
+// B = 45: 5.65 / 5.85 against 6.1-6.3 / 7.3, B = 64: 5.6 / 7.2 against 7.5 / 9.65, but B = 20-25: 5.2 / 5.6 against 4.2 / 5.1-5.2 --
+// the same rule: from three row groups per weight copy on.
+bool lstm_xcd_bx3_pays(int B, int Hp) { return (Hp == XH && xcd_row_groups(B) >= 3) || (Hp == PH && xcd_row_groups(B, PH) >= 3); }
 // Rows per XCD that fill the row groups the 8-way split already pays for: the batch then sits on the first
 // ceil(B / rows) XCDs and the others are free for another stream's GEMMs (B = 45: 8 rows on 6 XCDs instead of 6 on 8).
 int lstm_xcd_packed_rows(int B) { return 4 * xcd_row_groups(B); }
 hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, float* bwd, int Hp, bool bx3) {
     if (Hp == SH) hipLaunchKernelGGL(k_repack_kh_slice, dim3(256), dim3(256), 0, s, Kh, fwd, bwd);
+    else if (Hp == PH && bx3) hipLaunchKernelGGL(k_repack_kh_pair16, dim3(2048), dim3(256), 0, s, Kh, fwd, bwd);
     else if (Hp == PH) hipLaunchKernelGGL(k_repack_kh_pair, dim3(2048), dim3(256), 0, s, Kh, fwd, bwd);
     else if (bx3) hipLaunchKernelGGL(k_repack_kh_xcd16, dim3(512), dim3(256), 0, s, Kh, fwd, bwd);
     else hipLaunchKernelGGL(k_repack_kh_xcd, dim3(1024), dim3(256), 0, s, Kh, fwd, bwd);
@@ -2112,7 +2120,10 @@ hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, floa
 
 // Variants chosen per shape (tools/xcd_chain_bench, profiles/r03_xcd_probe6*.log; B = 45: forward 2.21 -> 2.14 us per step with
 // the outputs deferred, backward 2.40 -> 2.34 without the sleep; B = 100: deferring costs 4 %, no sleep is neutral)
-int lstm_xcd_default_variant(int B, bool forward, int Hp, int rpx) {
+int lstm_xcd_default_variant(int B, bool forward, int Hp, int rpx, bool bx3) {
+    // hidden 1024 on the bf16 pipe (lstm_pair16.h): forward probe + streamed fetch (6.35 -> 5.82 -> 5.65 us per step at B = 45), outputs
+    // deferred behind the fetch; backward same-XCD partials through the L2 and the reset wait behind the first tile group (6.65 -> 5.85)
+    if (Hp == PH && bx3) return forward ? (XCD_NO_POLL_SLEEP | XCD_PROBE | XCD_STREAM | XCD_DEFER_OUTPUTS) : (XCD_NO_POLL_SLEEP | XCD_LOCAL_PLAIN | XCD_LATE_DRAIN);
     // hidden 1024 (profiles/r03_pair_probe3..5.log, us per step without / with chains): backward 9.0 -> 7.2 (three row groups),
     // 6.75 -> 5.1 (two), 12.2 -> 9.4 (four); forward 4.65 -> 4.2 with two row groups, but 6.1 -> 6.35 / 7.4 -> 8.4 with three / four
     // (its early polls are ready 95 % of the time: the hand-off IS hidden, the per-phase instruction overhead is what is left).
@@ -2136,6 +2147,22 @@ hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {
         switch (xcd_row_groups(a.B, SH)) {
             case 1: hipLaunchKernelGGL((k_lstm_fwd_slice<1>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((k_lstm_fwd_slice<2>), grid, block, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    if (a.Hp == PH && a.bx3) {
+        if (a.progress) return hipErrorInvalidValue;
+        if (a.prof) {
+            if (xcd_row_groups(a.B, PH) != 3) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((k_lstm_fwd_pair16<3, true>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+        switch (xcd_row_groups(a.B, PH)) {
+            case 1: hipLaunchKernelGGL((k_lstm_fwd_pair16<1, false>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((k_lstm_fwd_pair16<2, false>), grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((k_lstm_fwd_pair16<3, false>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((k_lstm_fwd_pair16<4, false>), grid, block, 0, s, a); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -2196,6 +2223,21 @@ hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a) {
         switch (xcd_row_groups(a.B, SH)) {
             case 1: hipLaunchKernelGGL((k_lstm_bwd_slice<1>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((k_lstm_bwd_slice<2>), grid, block, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    if (a.Hp == PH && a.bx3) {
+        if (a.prof) {
+            if (xcd_row_groups(a.B, PH) != 3) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((k_lstm_bwd_pair16<3, true>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+        switch (xcd_row_groups(a.B, PH)) {
+            case 1: hipLaunchKernelGGL((k_lstm_bwd_pair16<1, false>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((k_lstm_bwd_pair16<2, false>), grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((k_lstm_bwd_pair16<3, false>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((k_lstm_bwd_pair16<4, false>), grid, block, 0, s, a); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

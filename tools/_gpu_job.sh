@@ -1,7 +1,16 @@
 #!/bin/bash
 # scratch runner for one gpurun call (edit, then: gpurun -- 'bash tools/_gpu_job.sh'); what it leaves under gpurun_out/ comes back
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
-bash tools/sanitize_run.sh
-cp $O/san_ubsan.log $O/r06_sanitizer_ubsan_pytest.log; cp $O/san_asan_abi.log $O/r06_sanitizer_asan_abi_smoke.log
-FSMG_XCD_BX3=1 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_golden_g5.py -q -m gpu 2>&1 | tail -8 > $O/r06_forced_xcd_bx3.log; tail -3 $O/r06_forced_xcd_bx3.log
-FSMG_GEMM_H=2 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_golden_g5.py -q -m gpu 2>&1 | tail -8 > $O/r06_forced_gemm_h2.log; tail -3 $O/r06_forced_gemm_h2.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "cfg-C or cfg_C or 1024 or full_size or maml or every_tensor" 2>&1 | tail -8 > $O/p16_tests.log; tail -4 $O/p16_tests.log
+for v in 0 1; do FSMG_XCD_BX3=$v timeout 300 python bench.py --config cfg-C --no-cpu-baseline --no-other-configs --no-extras --no-breakdown > $O/p16_bench_cfgC_bx3_$v.json 2>$O/p16_bench_cfgC_bx3_$v.err; python - <<PY
+import json
+d=json.loads(open('$O/p16_bench_cfgC_bx3_$v.json').read().strip().splitlines()[-1])
+print('cfg-C FSMG_XCD_BX3=$v', d['value'], d['ms_per_step'], d.get('guard'))
+PY
+done
+for v in 0 1; do FSMG_XCD_BX3=$v timeout 300 python bench.py --config cfg-C-T128 --no-cpu-baseline --no-other-configs --no-extras --no-breakdown > $O/p16_bench_cfgCT128_bx3_$v.json 2>$O/p16_bench_cfgCT128_bx3_$v.err; python - <<PY
+import json
+d=json.loads(open('$O/p16_bench_cfgCT128_bx3_$v.json').read().strip().splitlines()[-1])
+print('cfg-C-T128 FSMG_XCD_BX3=$v', d['value'], d['ms_per_step'])
+PY
+done

@@ -262,8 +262,8 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
 
     Dev d;
     const size_t Bp16 = (size_t)(B + 15) / 16 * 16;
-    CK(hipMalloc(&d.Kh, 4ull * H * G4)); CK(hipMalloc(&d.KhXf, 4ull * lstm_xcd_weight_floats(H, g_bx3 && H == 512))); CK(hipMalloc(&d.KhXb, 4ull * lstm_xcd_weight_floats(H, g_bx3 && H == 512))); CK(hipMalloc(&d.KhF, 8ull * H * G4));
-    CK(hipMalloc(&d.HX, 4ull * lstm_xcd_hx_floats((g_rpx && H == 512) ? 128 : B, Tmax, H, g_bx3 && H == 512))); CK(hipMalloc(&d.inboxX, 4ull * lstm_xcd_inbox_floats((g_rpx && H == 512) ? 128 : B, H)));
+    CK(hipMalloc(&d.Kh, 4ull * H * G4)); CK(hipMalloc(&d.KhXf, 4ull * lstm_xcd_weight_floats(H, g_bx3))); CK(hipMalloc(&d.KhXb, 4ull * lstm_xcd_weight_floats(H, g_bx3))); CK(hipMalloc(&d.KhF, 8ull * H * G4));
+    CK(hipMalloc(&d.HX, 4ull * lstm_xcd_hx_floats((g_rpx && H == 512) ? 128 : B, Tmax, H, g_bx3))); CK(hipMalloc(&d.inboxX, 4ull * lstm_xcd_inbox_floats((g_rpx && H == 512) ? 128 : B, H)));
     CK(hipMalloc(&d.Z, 4ull * Tmax * B * G4)); CK(hipMalloc(&d.Zsave, 4ull * Tmax * B * G4));
     CK(hipMalloc(&d.Cs, 4ull * (Tmax + 1) * B * H)); CK(hipMalloc(&d.Hs, 4ull * (Tmax + 1) * B * H));
     CK(hipMalloc(&d.dC, 4ull * B * H)); CK(hipMalloc(&d.dH, 4ull * Tmax * B * H));
@@ -275,21 +275,21 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
     CK(hipMemcpy(d.dH, dH.data(), 4ull * Tmax * B * H, hipMemcpyHostToDevice));
     CK(hipMemset(d.err, 0, 256));
     hipStream_t s; CK(hipStreamCreate(&s));
-    CK(launch_repack_kh_xcd(s, d.Kh, d.KhXf, d.KhXb, H, g_bx3 && H == 512));
+    CK(launch_repack_kh_xcd(s, d.Kh, d.KhXf, d.KhXb, H, g_bx3));
     CK(launch_repack_kh(s, d.Kh, d.KhF, d.KhF + (size_t)H * G4, H));
     int rc = 0;
 
     auto fwd_xcd = [&](int T, int nchunk) {
         CK(hipMemcpyAsync(d.Z, Zin.data(), 4ull * T * B * G4, hipMemcpyHostToDevice, s));
         CK(hipMemsetAsync(d.Cs, 0, 4ull * B * H, s)); CK(hipMemsetAsync(d.Hs, 0, 4ull * B * H, s));
-        const size_t step_f = (size_t)lstm_xcd_hx_floats((g_rpx && H == 512) ? 128 : B, 0, H, g_bx3 && H == 512);
+        const size_t step_f = (size_t)lstm_xcd_hx_floats((g_rpx && H == 512) ? 128 : B, 0, H, g_bx3);
         CK(hipMemsetAsync(d.HX, 0, 4 * step_f, s));
         CK(hipMemsetAsync(d.HX + step_f, 0xFF, 4 * step_f * T, s));
         CK(hipMemsetAsync(d.tickets, 0, 64 * 4, s));
         for (int c = 0; c < nchunk; ++c) {
             LstmFwdXcdArgs a{};
             a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
+            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
             CK(launch_lstm_fwd_xcd(s, a));
         }
     };
@@ -300,7 +300,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
         for (int c = nchunk - 1; c >= 0; --c) {
             LstmBwdXcdArgs a{};
             a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
+            a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
             CK(launch_lstm_bwd_xcd(s, a));
         }
     };
@@ -342,7 +342,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                 for (int c = 0; c < nchunk; ++c) {
                     LstmFwdXcdArgs a{};
                     a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
+                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     CK(launch_lstm_fwd_xcd(s, a));
                 }
                 CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
@@ -352,7 +352,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                 for (int c = nchunk - 1; c >= 0; --c) {
                     LstmBwdXcdArgs a{};
                     a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets + 8 * c; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
+                    a.B = B; a.T = T; a.t0 = (int)((long long)c * T / nchunk); a.t1 = (int)((long long)(c + 1) * T / nchunk); a.spin_limit = 1 << 18; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     CK(launch_lstm_bwd_xcd(s, a));
                 }
                 CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
@@ -444,20 +444,20 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
             hipFree(A); hipFree(Bm); hipFree(slabs); hipFree(ctl);
         }
         {                    // variants (same results): 16 = XCD_DEFER_OUTPUTS, 32 = XCD_NO_POLL_SLEEP
-            for (int dbg : {16, 32, 48, 96}) {
-                if ((dbg & 64) && H != 1024) continue;          // XCD_CHAINS: hidden 1024 only
+            for (int dbg : {32, 160, 672, 688, 288, 1312, 1968}) {
+                if ((dbg & (64 | 128 | 256 | 512 | 1024)) && H != 1024) continue;          // XCD_CHAINS: hidden 1024 only
                 float best_f = 1e9f, best_b = 1e9f;
                 for (int rep = 0; rep < 5; ++rep) {
                     fwd_xcd(T, 0);
                     CK(hipEventRecord(e0, s));
                     { LstmFwdXcdArgs a{}; a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0; CK(launch_lstm_fwd_xcd(s, a)); }
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; a.Hp = H; a.bx3 = (g_bx3) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0; CK(launch_lstm_fwd_xcd(s, a)); }
                     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best_f = std::min(best_f, ms);
                     bwd_xcd(T, 0);
                     CK(hipEventRecord(e0, s));
                     { LstmBwdXcdArgs a{}; a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0; CK(launch_lstm_bwd_xcd(s, a)); }
+                      a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.variant = dbg; a.Hp = H; a.bx3 = (g_bx3) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0; CK(launch_lstm_bwd_xcd(s, a)); }
                     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
                     CK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
                 }
@@ -466,7 +466,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                 CK(hipMemset(d.err, 0, 4));
             }
         }
-        if (H == 1024) {     // chain kernels: how many of the early-issued polls were NOT ready when their phase started
+        if (H == 1024 && !g_bx3) {     // chain kernels: how many of the early-issued polls were NOT ready when their phase started
             unsigned long long* prof; CK(hipMalloc(&prof, 8ull * 64));
             unsigned long long hp[16];
             for (int dir = 0; dir < 2; ++dir) {
@@ -474,12 +474,12 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                 if (dir == 0) {
                     fwd_xcd(T, 0);
                     LstmFwdXcdArgs a{}; a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = 96; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = 96; a.Hp = H; a.bx3 = (g_bx3) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     if (launch_lstm_fwd_xcd(s, a) != hipSuccess) continue;
                 } else {
                     bwd_xcd(T, 0);
                     LstmBwdXcdArgs a{}; a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = 96; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = 96; a.Hp = H; a.bx3 = (g_bx3) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     if (launch_lstm_bwd_xcd(s, a) != hipSuccess) continue;
                 }
                 CK(hipStreamSynchronize(s));
@@ -490,7 +490,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
             hipFree(prof);
             CK(hipMemset(d.err, 0, 4));
         }
-        if (B == 45 && H == 512) {       // phase profile of the instrumented build (RG = 2)
+        if ((B == 45 && H == 512) || (B == 45 && H == 1024 && g_bx3)) {       // phase profile of the instrumented build (RG = 2; hidden 1024 bf16-split: RG = 3)
             unsigned long long* prof; CK(hipMalloc(&prof, 8ull * 256 * 4 * 8));
             std::vector<unsigned long long> hp(256 * 4 * 8);
             for (int dir = 0; dir < 2; ++dir) {
@@ -499,13 +499,13 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                     fwd_xcd(T, 0);
                     LstmFwdXcdArgs a{};
                     a.KhX = d.KhXf; a.HX = d.HX; a.Z = d.Z; a.Cs = d.Cs; a.Hs = d.Hs; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     CK(hipEventRecord(e0, s)); CK(launch_lstm_fwd_xcd(s, a)); CK(hipEventRecord(e1, s));
                 } else {
                     bwd_xcd(T, 0);
                     LstmBwdXcdArgs a{};
                     a.KhXb = d.KhXb; a.inbox = d.inboxX; a.Z = d.Z; a.Cs = d.Cs; a.dc = d.dC; a.dH = d.dH; a.tickets = d.tickets; a.err_flag = d.err;
-                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3 && H == 512) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
+                    a.B = B; a.T = T; a.t0 = 0; a.t1 = T; a.spin_limit = 1 << 18; a.prof = prof; a.variant = g_variant; a.Hp = H; a.bx3 = (g_bx3) ? 1 : 0; a.rpx = (H == 512) ? g_rpx : 0;
                     CK(hipEventRecord(e0, s)); CK(launch_lstm_bwd_xcd(s, a)); CK(hipEventRecord(e1, s));
                 }
                 CK(hipStreamSynchronize(s));
@@ -515,6 +515,12 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
                 const char* names_b0[5] = {"wait inbox", "psum+barrier", "cell+dzA+barrier", "LDS read+MFMA", "drain+stores+rest"};
                 const char** names_f = names_f0;
                 const char** names_b = names_b0;
+                if (H == 1024) for (int w = 0; w < 4; ++w) {       // per wave: phases + probe / full poll rounds per step
+                    double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int b = 0; b < 256; ++b) for (int i = 0; i < 8; ++i) m[i] += (double)hp[((size_t)b * 4 + w) * 8 + i];
+                    printf("[4] %s wave %d ticks per step: %.0f %.0f %.0f %.0f %.0f | probe rounds %.2f full rounds %.2f probe ticks %.0f\n", dir ? "bwd" : "fwd", w,
+                           m[0] / 256 / T, m[1] / 256 / T, m[2] / 256 / T, m[3] / 256 / T, m[4] / 256 / T, m[5] / 256 / T, m[6] / 256 / T, m[7] / 256 / T);
+                }
                 for (int wc = 0; wc < 2; ++wc) {        // cell waves (0,1) vs the others (2,3)
                     double m[5] = {0, 0, 0, 0, 0};
                     for (int b = 0; b < 256; ++b) for (int w = 2 * wc; w < 2 * wc + 2; ++w) for (int i = 0; i < 5; ++i) m[i] += (double)hp[((size_t)b * 4 + w) * 8 + i];
