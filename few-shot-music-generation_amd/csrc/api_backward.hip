@@ -77,7 +77,7 @@ int backward(fsmg_model* h, int B, int part) {
         gdw.colsum = mainl.colsum_slabs; gdw.colsum_slab = gdw.N;
     }
     const bool xov = h->xov_call && (h->xov_parts & 2) && xcd && !ov && dw_split > 1 && xov_fits(gdw);
-    const int rpx = xov ? lstm_xcd16_packed_rows(B) : 0;
+    const int rpx = xov ? lstm_xcd16_packed_rows(B, Hp) : 0;
     const bool cut = !ov && !xov;           // the order that can be cut behind the projection gradients
     if (part == 2 && !cut) return FSMG_OK;
     // dp_split == 2: the cut sits behind the LAST recurrent chain instead -- an XCD-local chain needs every CU of the chip, so
@@ -123,7 +123,7 @@ int backward(fsmg_model* h, int B, int part) {
         GEMMCK(dhout_chunk(h, mainl, B, 0, T, d_now));
         HIPCK(h, hipEventRecord(h->ev_fork, s));
         HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-        GEMMCK(gemm_restricted(h, h->aux, OP_XC, OP_XC, gdw, xov_first_free(B), h->xov_ctl + fsmg_model::XOV_CTL));
+        GEMMCK(gemm_restricted(h, h->aux, OP_XC, OP_XC, gdw, xov_first_free(B, Hp), h->xov_ctl + fsmg_model::XOV_CTL));
         HIPCK(h, hipEventRecord(h->ev_join, h->aux));
     } else {
         GEMMCK(dhout_chunk(h, mainl, B, 0, T, d_now));
@@ -165,6 +165,13 @@ int backward(fsmg_model* h, int B, int part) {
         }
         return FSMG_OK;
     };
+    // XCD-partitioned order, stacked layers (hidden 1024, round 6): the weight gradient of layer l + 1 -- its operands are complete once
+    // that layer's chain is over -- waits as a work-queue GEMM and runs on the free XCD pair beside layer l's chain (dx of layer l + 1,
+    // which that chain reads, goes first); what the pair has not drawn when the chain ends is drained chip-wide.  Same K split, same
+    // slab sums in the same order whoever computes an item.
+    GemmArgs pend{};
+    bool pend_on = false;
+    int* const pend_ctl = h->xov_ctl;          // (the forward pair's queue words: free during the backward pass)
     for (int l = h->L - 1; l >= 0; --l) {
         const bool top = l == h->L - 1;
         if (part == 2 && cut_late && l > 0) continue;                       // done in part 1
@@ -172,8 +179,9 @@ int backward(fsmg_model* h, int B, int part) {
         if (!skip_chain) {
         if (top && ov) HIPCK(h, hipStreamWaitEvent(s, h->ev_chunk[nch - 1], 0));
         PHASE(4);
+        const bool packed = xov && (top || pend_on);      // this layer's chain sits on the first XCDs only
         if (!(top && top_fills_done)) {
-            GEMMCK(bptt_fills(h, fills, B, xcd, rs, chain, xov && top ? rpx : 0));
+            GEMMCK(bptt_fills(h, fills, B, xcd, rs, chain, packed ? rpx : 0));
             GEMMCK(fills.flush());
         }
         for (int c = nch - 1; c >= 0; --c) {
@@ -182,7 +190,7 @@ int backward(fsmg_model* h, int B, int part) {
             ScopedTimer tm(h, "lstm_bwd");
             if (xcd) {
                 LstmBwdXcdArgs a{};
-                a.rpx = (xov && top) ? rpx : 0; a.Hp = Hp; a.bx3 = h->xcd_bx3 ? 1 : 0; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, false, Hp, 0, h->xcd_bx3);
+                a.rpx = packed ? rpx : 0; a.Hp = Hp; a.bx3 = h->xcd_bx3 ? 1 : 0; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, false, Hp, 0, h->xcd_bx3);
                 a.KhXb = h->khx + (size_t)(2 * l + 1) * lstm_xcd_weight_floats((int)Hp, h->xcd_bx3); a.inbox = h->inboxX; a.Z = h->Z[l]; a.Cs = h->Cs[l];
                 a.dc = h->dC; a.dH = h->dH; a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_bwd_xcd(s, a));
@@ -240,6 +248,12 @@ int backward(fsmg_model* h, int B, int part) {
                 }
             }
         }
+        if (pend_on) {                        // the rest of the waiting weight gradient chip-wide (its slab sums ride in `late`)
+            ScopedTimer tm(h, "gemm_dk");
+            GEMMCK(gemm_cleanup(h, s, OP_XC, OP_XC, pend, pend_ctl));
+            HIPCK(h, hipStreamWaitEvent(s, h->ev_join, 0));
+            pend_on = false;
+        }
         }   // !skip_chain
         if (part == 1 && cut_late && l == 0) return FSMG_OK;                // bucket 0 travels beside what follows
         const int in_p = h->in_dim[l];
@@ -249,7 +263,7 @@ int backward(fsmg_model* h, int B, int part) {
         // beside the dK GEMM (below); everywhere else dK first (the layer below waits for dx only).
         OpBatch* dk_defer = d_late;
         // probe != nullptr: nothing is launched, *probe = whether dK_h runs on the 256 x 256-tile kernel
-        auto dk_gemm = [&](bool* probe) -> int {
+        auto dk_gemm = [&](bool* probe, bool* wait_for_chain = nullptr) -> int {
             {
                 ScopedTimer tm(h, "gemm_dk");
                 // dKx and dKh are one matrix of the flat gradient (the [in | h_prev] rows of `kernel_l`) and contract the same dZ over the
@@ -264,6 +278,10 @@ int backward(fsmg_model* h, int B, int part) {
                 const bool merged = h->merge_dk && in_p % 256 == 0 && Hp % 4 == 0 && h->off_kh[l] == h->off_kx[l] + (int64_t)in_p * G4 &&
                                     (l > 0 || 4LL * h->V1 * h->Ep < 0xfffff000LL) && 4LL * Hp * rows < 0xfffff000LL && 4LL * G4 * rows < 0xfffff000LL &&
                                     (((uintptr_t)m.A | (uintptr_t)m.A2 | (uintptr_t)m.B) & 15) == 0 && gemm_dma_enabled() && use_h_gemm(h, OP_XC, OP_XC, m, mainl);
+                if (merged && wait_for_chain != nullptr) {       // leave it to the queue beside the next chain
+                    GEMMCK(gemm_prepare_queue(h, m, h->xov_dw_split, dk_defer, wait_for_chain));
+                    if (*wait_for_chain) { pend = m; return FSMG_OK; }
+                }
                 if (merged) {
                     if (probe) { *probe = true; return FSMG_OK; }
                     GEMMCK(gemm(h, mainl, OP_XC, OP_XC, m, dk_defer));
@@ -317,6 +335,22 @@ int backward(fsmg_model* h, int B, int part) {
             HIPCK(h, hipStreamWaitEvent(s, h->ev_side, 0));
             h->side_pending = false;
             GEMMCK(late2.flush());
+        } else if (xov && l > 0 && defer_ok && (h->xov_parts & 4) && Hp == 1024) {
+            // dK_l as a queue launch on the free XCD pair, STARTED here: the launch must be running before the chain below is -- its blocks
+            // are dealt to all eight XCDs in turn, and behind a chain that holds every CU of the first six the dealing stops at the first
+            // block meant for one of them (measured: forked right in front of the chain it started 0.6 us behind it and the pair did
+            // nothing).  Beside dx_l it shares the pair's CUs with that GEMM's blocks; dx_l goes first on the main stream because the chain
+            // below reads dH.
+            GEMMCK(dk_gemm(nullptr, &pend_on));
+            if (pend_on) {
+                GEMMCK(fills.add(pend_ctl, 0u, 4 + gemm_items(pend)));
+                GEMMCK(fills.flush());
+                HIPCK(h, hipEventRecord(h->ev_fork, s));
+                HIPCK(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+                GEMMCK(gemm_restricted(h, h->aux, OP_XC, OP_XC, pend, xov_first_free(B, Hp), pend_ctl));
+                HIPCK(h, hipEventRecord(h->ev_join, h->aux));
+            }
+            GEMMCK(dx_gemm());
         } else {
             GEMMCK(dk_gemm(nullptr));
             GEMMCK(dx_gemm());

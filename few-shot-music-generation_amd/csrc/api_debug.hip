@@ -57,7 +57,7 @@ int fsmg_debug_read(fsmg_handle h, const char* what, float* host, int64_t count)
     }
     if (!std::strcmp(what, "xcd_partitioned")) {      // ... and whether its train passes take the XCD-partitioned order: [0] yes / no, [1] XCDs the chains occupy, [2] the last pass
         host[0] = h->xov ? 1.0f : 0.0f;
-        if (count > 1) { const int b = h->lastB > 0 ? h->lastB : 45, rpx = lstm_xcd16_packed_rows(b); host[1] = (h->xov && rpx > 0) ? (float)((b + rpx - 1) / rpx) : 8.0f; }
+        if (count > 1) { const int b = h->lastB > 0 ? h->lastB : 45, rpx = lstm_xcd16_packed_rows(b, h->Hp); host[1] = (h->xov && rpx > 0) ? (float)xov_first_free(b, h->Hp) : 8.0f; }
         if (count > 2) host[2] = h->xov_last ? 1.0f : 0.0f;       // [2] whether the LAST train pass took it (its row count decides per call)
         return FSMG_OK;
     }

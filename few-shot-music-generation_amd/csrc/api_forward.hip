@@ -175,8 +175,8 @@ int forward(fsmg_model* h, int B, int rows_per_group, int ngroups, float* loss_o
 #else
     constexpr bool ce_tail = false;
 #endif
-    const int xfree = xov_first_free(B);
-    const int rpx = xov ? lstm_xcd16_packed_rows(B) : 0;
+    const int xfree = xov_first_free(B, Hp);
+    const int rpx = xov ? lstm_xcd16_packed_rows(B, Hp) : 0;
     if (xov) xov_gate(h, ghead, B);
     PHASE(0);
     for (int l = 0; l < h->L; ++l) {

@@ -179,7 +179,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (env) { h->overlap = env[0] != '0'; h->overlap_forced = true; }
         if (const char* e = std::getenv("FSMG_GEMM")) h->bx3 = std::strcmp(e, "f32") != 0;
         if (const char* e = std::getenv("FSMG_XCD_OVERLAP")) h->xov = std::atoi(e) != 0;
-        if (const char* e = std::getenv("FSMG_XOV_PARTS")) h->xov_parts = std::max(1, std::min(3, std::atoi(e)));
+        if (const char* e = std::getenv("FSMG_XOV_PARTS")) h->xov_parts = std::max(1, std::min(7, std::atoi(e)));
         if (const char* e = std::getenv("FSMG_EAGER")) h->eager = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_MERGE_DK")) h->merge_dk = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_UPD_SPLIT")) h->upd_split = (e[0] != '0');
@@ -313,7 +313,14 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
             const long long items = (((long long)h->T * b0 + 255) / 256) * ((h->V1p + 255) / 256);
             const bool eligible = h->bx3 && h->Hp == 512 && h->L == 1 && rpx > 0 && (b0 + rpx - 1) / rpx <= 5 && b0 >= 16 && h->T >= 32 && items >= 320 &&
                                   4 + items <= fsmg_model::XOV_CTL;
+            // Hidden 1024 (round 6): the order EXISTS there (FSMG_SCHEDULE_XCD_PARTITIONED / FSMG_XCD_OVERLAP=1: the top layer's chains on three
+            // XCD pairs, 15 rows each, the projection / dW on the fourth; FSMG_XOV_PARTS bit 4: dK of layer l + 1 beside the BPTT chain of
+            // layer l) and is NOT what AUTO takes: measured at cfg-C against the serial order on the same kernels (profiles/r06_cfgC_xov_ab.txt)
+            // 408.6 -> 403.6 (dW pair only), 392.4 (+ dK pair), 385.3 (+ forward pair).  One pair is a quarter of the chip: it absorbs at
+            // most a quarter of a chain's length in GEMM time (~90 us), the packed chain pays a fourth row group for the 15th row (+30 us),
+            // and what the pair has not drawn when the chain ends is rounds of whole 256 x 256 tiles (95-190 us) on the whole chip.
             if (cfg->schedule == FSMG_SCHEDULE_AUTO && std::getenv("FSMG_XCD_OVERLAP") == nullptr && !h->overlap_forced) h->xov = eligible;
+            if (h->Hp == 1024 && std::getenv("FSMG_XOV_PARTS") == nullptr) h->xov_parts = 2;
         }
         h->xov_eligible = h->xov;
         if (h->aux_tries < 0) h->xov = false;           // its two launches would run one after the other (pick_concurrent_aux)

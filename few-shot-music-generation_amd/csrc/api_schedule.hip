@@ -120,16 +120,18 @@ void choose_schedule(fsmg_model* h, int B, bool train) {
                     (use_xcd(h, B) || lstm_fwd_chain_supported(B, h->Hp) || lstm_fwd_chain_rt_supported(B, h->Hp));
     // XCD-partitioned schedule (round 4 form): the bf16-split chains packed on ceil(B / 16) XCDs, the 256-tile work-queue GEMMs of
     // the projection / its weight gradient on the others
-    if (train && h->xov && h->Hp == 512 && h->xcd_bx3 && h->bx3 && h->L == 1 && !h->ov_call && h->aux != nullptr && use_xcd(h, B) && h->persist_fwd && h->persist_bwd &&
+    // hidden 1024 (round 6): the TOP layer's pair on three XCD pairs (the bf16-split pair kernels take 16 rows per pair at one MFMA
+    // phase's cost), the projection / its weight gradient on the fourth
+    if (train && h->xov && ((h->Hp == 512 && h->L == 1) || h->Hp == 1024) && h->xcd_bx3 && h->bx3 && !h->ov_call && h->aux != nullptr && use_xcd(h, B) && h->persist_fwd && h->persist_bwd &&
         (!h->timing || h->timing_only == "lstm_fwd" || h->timing_only == "lstm_bwd")) {
-        const int rpx = lstm_xcd16_packed_rows(B);
-        h->xov_call = rpx > 0 && (B + rpx - 1) / rpx <= 5;          // at least three XCDs for the GEMMs
+        const int rpx = lstm_xcd16_packed_rows(B, h->Hp);
+        h->xov_call = rpx > 0 && xov_first_free(B, h->Hp) <= (h->Hp == 1024 ? 6 : 5);          // at least three XCDs (hidden 1024: a pair) for the GEMMs
         if (h->xov_call) h->eager_call = true;
     }
 }
 void xov_gate(fsmg_model* h, GemmArgs& g, int B) {     // the projection's A rows arrive time step by time step
-    const int rpx = lstm_xcd16_packed_rows(B);
-    g.gate = h->xov_prog; g.gate_expect = lstm_xcd_active_blocks(B, rpx); g.gate_rows = B; g.gate_last = h->T - 1;       // (blocks below xcd_first join when the CHAIN is over)
+    const int rpx = lstm_xcd16_packed_rows(B, h->Hp);
+    g.gate = h->xov_prog; g.gate_expect = lstm_xcd_active_blocks(B, rpx, h->Hp); g.gate_rows = B; g.gate_last = h->T - 1;       // (blocks below xcd_first join when the CHAIN is over)
     // a tile waits for its rows for a fraction of the chain's 0.4 ms; 0.2 s of ~1 us polls without them (a host that was descheduled
     // between the two launches is back long before that) means the launches are not running side by side -- a profiler or debugger
     // that serialises dispatches: give up like any timed-out hand-off
@@ -146,6 +148,26 @@ int gemm_restricted(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs
     if (dbg & 32) g.dbg |= 64;                     // blocks below xcd_first never join
 #endif
     HIPCK(h, launch_gemm(s, amode, bmode, g, 0));
+    return FSMG_OK;
+}
+// A split-K GEMM for the work queue: slabs in the pass arena, the fixed-order slab sums (same order as gemm()'s) queued in `defer`;
+// the launches are the caller's (gemm_restricted beside a chain, gemm_cleanup behind it).  *ok = false: no room, nothing changed.
+int gemm_prepare_queue(fsmg_model* h, GemmArgs& g, int split, OpBatch* defer, bool* ok) {
+    *ok = false;
+    const int S = std::max(1, std::min(std::min(split, MAX_SPLIT), g.K / 256));
+    const int64_t mn = (int64_t)g.M * g.N;
+    const int64_t need = round_up((int64_t)S * mn, 64) + (g.colsum ? round_up((int64_t)S * g.N, 64) : 0);
+    if (S < 2 || defer == nullptr || h->arena == nullptr || g.ldc != g.N || h->arena_off + need > h->arena_cap || g.row_scale != nullptr) return FSMG_OK;
+    float* slabs = h->arena + h->arena_off; float* cslabs = slabs + round_up((int64_t)S * mn, 64);
+    h->arena_off += need;
+    float* C = g.C; float* colsum = g.colsum;
+    g.C = slabs; g.c_slab = mn; g.ksplit = S; g.bx3 = 3;
+    if (colsum) { g.colsum = cslabs; g.colsum_slab = g.N; }
+    if (!xov_fits(g)) { h->arena_off -= need; g.C = C; g.colsum = colsum; g.ksplit = 1; return FSMG_OK; }
+    GEMMCK(defer->room(colsum ? 2 : 1));
+    GEMMCK(defer->reduce(slabs, mn, S, C, mn));
+    if (colsum) GEMMCK(defer->reduce(cslabs, g.N, S, colsum, g.N));
+    *ok = true;
     return FSMG_OK;
 }
 int gemm_cleanup(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int* ctl) {

@@ -247,8 +247,8 @@ bool lstm_xcd_supported(int B, int Hp);        // Hp 512: up to 128 rows; Hp 102
 int lstm_xcd_max_rows(int Hp);                 // 128 / 64 / 0
 long long lstm_xcd_hx_floats(int B, int T, int Hp = 512, bool bx3 = false, int rpx = 0);   // bx3: for the bf16-split kernels (hidden 512); rpx: rows packed per XCD
 long long lstm_xcd_inbox_floats(int B, int Hp = 512, int rpx = 0);
-int lstm_xcd16_packed_rows(int B);             // bf16-split kernels: rows per XCD that put B rows on the fewest XCDs (up to 16 each)
-inline int lstm_xcd_active_blocks(int B, int rpx) { return 32 * ((B + rpx - 1) / rpx); }     // blocks of a packed launch that own rows
+int lstm_xcd16_packed_rows(int B, int Hp = 512);      // bf16-split kernels: rows per XCD (hidden 1024: per XCD pair) that put B rows on the fewest (up to 16 each)
+inline int lstm_xcd_active_blocks(int B, int rpx, int Hp = 512) { return (Hp == 1024 ? 64 : 32) * ((B + rpx - 1) / rpx); }     // blocks of a packed launch that own rows
 long long lstm_xcd_weight_floats(int Hp = 512, bool bx3 = false);   // floats per register image
 bool lstm_xcd_bx3_pays(int B, int Hp);         // the bf16-split kernels are the faster ones at this row count
 int lstm_xcd_packed_rows(int B);               // rows per XCD that leave whole XCDs free without adding row groups (hidden 512)

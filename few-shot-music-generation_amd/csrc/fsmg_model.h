@@ -190,7 +190,9 @@ struct fsmg_model {
     int xov_pub = 6;                    // FSMG_XOV_PUB: the forward chain publishes every this many steps (a 256-row tile is 5.7 steps of 45 rows)
     int xov_strikes = 0;                // time-outs of passes in the XCD-partitioned order: the second one parks the schedule for this handle
     bool xov_last = false;              // the pass in flight took the XCD-partitioned order
-    int xov_parts = 3;                  // FSMG_XOV_PARTS: 1 = forward pair only, 2 = backward pair only, 3 = both
+    int xov_parts = 3;                  // FSMG_XOV_PARTS: 1 = forward pair, 2 = backward pair (dW beside the top chain), 4 = stacked layers: dK of layer l + 1
+                                        // beside the BPTT chain of layer l (hidden 1024); default 3 at hidden 512, 2 at hidden 1024 (where the order is opt-in and
+                                        // every part was measured to lose: api_handle.hip, profiles/r06_cfgC_xov_ab.txt)
     int* xov_prog = nullptr;            // [T] progress counters of the forward chain (LstmFwdXcdArgs::progress), the projection's gate
     // forward projection / dW: [0..1] draw counters, [2] stop flag, [3] items, [4 ..] claim words (gemm_restricted)
     static constexpr int XOV_CTL = 8192;
@@ -548,7 +550,10 @@ inline bool use_xcd(const fsmg_model* h, int B, bool backward = false) {
 // where a train pass's cross entropy leaves dlogits (and the projection-gradient GEMMs read it)
 inline float* dlogits_buf(const fsmg_model* h) { return h->inplace_dlogits ? h->logits : h->dlogits; }
 // first XCD the packed recurrence leaves free
-inline int xov_first_free(int B) { const int rpx = lstm_xcd16_packed_rows(B); return rpx > 0 ? (B + rpx - 1) / rpx : 8; }
+inline int xov_first_free(int B, int Hp = 512) {      // (hidden 1024: a weight copy takes an XCD pair)
+    const int rpx = lstm_xcd16_packed_rows(B, Hp);
+    return rpx > 0 ? (Hp == 1024 ? 2 : 1) * ((B + rpx - 1) / rpx) : 8;
+}
 
 // every XCD-local launch of a pass gets its own 8 zeroed ticket counters
 inline int* next_tickets(fsmg_model* h) {
@@ -567,6 +572,7 @@ inline int gemm_items(const GemmArgs& g) { return ((g.M + 255) / 256) * ((g.N + 
 inline bool xov_fits(const GemmArgs& g) { return 4 + gemm_items(g) <= fsmg_model::XOV_CTL; }
 void choose_schedule(fsmg_model* h, int B, bool train = false);
 void xov_gate(fsmg_model* h, GemmArgs& g, int B);
+int gemm_prepare_queue(fsmg_model* h, GemmArgs& g, int split, OpBatch* defer, bool* ok);
 int gemm_restricted(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int first, int* ctl);
 int gemm_cleanup(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int* ctl);
 

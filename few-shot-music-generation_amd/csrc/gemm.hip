@@ -1545,8 +1545,16 @@ hipError_t launch_t(hipStream_t s, const GemmArgs& g, int lds_pad) {
         const bool a_dma = AMODE != OP_XC || (g.lda % 4 == 0 && g.M % 4 == 0 && ((uintptr_t)g.A & 15) == 0);
         const bool b_dma = BMODE != OP_XC || (g.ldb % 4 == 0 && g.N % 4 == 0 && ((uintptr_t)g.B & 15) == 0);
         if constexpr (AMODE == OP_XC && BMODE == OP_XC) {
+            if (g.m_split > 0) {       // two-part op(A) from the queue (round 6: dKx + dKh of the layer above beside a BPTT chain)
+                const bool ok = g.m_split % 256 == 0 && g.m_split < g.M && g.A2 != nullptr && b_dma && g.lda % 4 == 0 && g.lda2 % 4 == 0 &&
+                                (g.M - g.m_split) % 4 == 0 && (((uintptr_t)g.A | (uintptr_t)g.A2) & 15) == 0 && 4LL * g.lda2 * g.K < 0xfffff000LL;
+                if (!ok) return hipErrorInvalidValue;
+                hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 3, true, true>), dim3(blocks), dim3(512), 0, s, g);
+                return hipGetLastError();
+            }
             if (a_dma && b_dma) { hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 3, true>), dim3(blocks), dim3(512), 0, s, g); return hipGetLastError(); }
         }
+        if (g.m_split > 0) return hipErrorInvalidValue;
         hipLaunchKernelGGL((k_gemm_bx3h<AMODE, BMODE, false, 2, true>), dim3(blocks), dim3(512), 0, s, g);
         return hipGetLastError();
     }

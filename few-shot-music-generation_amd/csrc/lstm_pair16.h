@@ -85,6 +85,12 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair16(const LstmFwdXcdArgs
     const bool cellw = wave < rgc;
     const bool act = cellw && lrow < rpx && row < B;
     const bool pub = cellw && lrow < rpx;         // rows past B on the last pair publish zeros: the readers load every row < rpx
+    // XCD-partitioned step: a GEMM on the XCDs this launch leaves free draws row tiles as the time steps complete -- progress[t] and
+    // the write-through stores of the row-major h exactly as in k_lstm_fwd_xcd16 (every wave drains its memory queue in the probe of a
+    // later step, that step's barrier orders the four waves, thread 0 publishes `lag` steps behind)
+    const bool wt = a.progress != nullptr;
+    const int lag = ((a.variant & XCD_DEFER_OUTPUTS) ? 2 : 1) + (a.progress_lag & 7);
+    const int pk = a.progress_every > 0 ? a.progress_every : 1;
     float cp = act ? a.Cs[((size_t)a.t0 * B + row) * PH + unit] : 0.0f;
     // A operand: lane = (row l % 16, k group l / 16).  The lanes of pad rows load row 0 again (same cache lines, no extra traffic; no
     // divergent loads for the compiler to merge): their rows of D are never read
@@ -144,9 +150,12 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair16(const LstmFwdXcdArgs
                 // front of the first MFMA that reads each) so the matrix pipe starts on k step 0 while the rest of the 72 KiB a CU fetches per
                 // step is still on its way (a CU takes in 64 bytes per clock: the fetch alone is as long as the MFMAs).  Checked AFTER the
                 // products: a fragment that was not there yet shows the fill pattern, and the step is redone behind the sc1 poll.
+                // (hipcc clusters loads by base register: without the scheduling fences the first MFMA waits for 17 of the 28 loads in flight)
 #define P16_LD(J) av[J] = af[((J) >> 2) * (4 * HXR * 4) + ((J) & 3) * (HXR * 4)];
-                P16_LD(0) P16_LD(8) P16_LD(16) P16_LD(1) P16_LD(9) P16_LD(17) P16_LD(2) P16_LD(10) P16_LD(18) P16_LD(3) P16_LD(11) P16_LD(19)
-                P16_LD(4) P16_LD(12) P16_LD(20) P16_LD(5) P16_LD(13) P16_LD(21) P16_LD(6) P16_LD(14) P16_LD(22) P16_LD(7) P16_LD(15) P16_LD(23)
+#define P16_LD3(KS) P16_LD(KS) P16_LD(8 + KS) P16_LD(16 + KS) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
+                P16_LD3(0) P16_LD3(1) P16_LD3(2) P16_LD3(3) P16_LD3(4) P16_LD3(5) P16_LD3(6) P16_LD3(7)
+#undef P16_LD3
 #undef P16_LD
             } else {
                 bool fail = false;
@@ -168,13 +177,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair16(const LstmFwdXcdArgs
                     s_fail = 1;
                 }
             }
-            if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {       // outputs of the step before: behind the fetch, under the MFMAs
-                a.Cs[((size_t)t * B + row) * PH + unit] = o_c;
-                a.Hs[((size_t)t * B + row) * PH + unit] = o_hh;
-                float* zo = a.Z + ((size_t)(t - 1) * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
-                zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
-            }
-            o_have = false;
             P16_STAMP(0)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -195,6 +197,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair16(const LstmFwdXcdArgs
                 P16_TERMS_REG(P16_FWD)
 #undef P16_FWD
             }
+            if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {       // outputs of the step before: behind the fetch and the MFMAs' waits for it
+                a.Cs[((size_t)t * B + row) * PH + unit] = o_c;
+                store_h_row(a.Hs + ((size_t)t * B + row) * PH + unit, o_hh, wt);
+                float* zo = a.Z + ((size_t)(t - 1) * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
+                zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+            }
+            o_have = false;
             if (!stream) break;
             const bool ok = frags16_ready_n<P16NF>(av);
             if (__all(ok)) break;
@@ -236,6 +245,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair16(const LstmFwdXcdArgs
         }
         __syncthreads();
         if (s_fail) return;
+        if (wt && tid == 0 && t - lag >= a.t0 && (t - lag) % pk == pk - 1)
+            __hip_atomic_fetch_add(a.progress + (t - lag), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         P16_STAMP(2)
 
         if (cellw) {
@@ -268,16 +279,23 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair16(const LstmFwdXcdArgs
                 o_c = cp; o_hh = hn; o_g[0] = g_si; o_g[1] = g_tj; o_g[2] = g_sf; o_g[3] = g_so; o_have = true;
             } else if (act) {
                 a.Cs[((size_t)(t + 1) * B + row) * PH + unit] = cp;
-                a.Hs[((size_t)(t + 1) * B + row) * PH + unit] = hn;
+                store_h_row(a.Hs + ((size_t)(t + 1) * B + row) * PH + unit, hn, wt);
                 zp[0] = g_si; zp[4] = g_tj; zp[8] = g_sf; zp[12] = g_so;
             }
         }
     }
     if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {
         a.Cs[((size_t)a.t1 * B + row) * PH + unit] = o_c;
-        a.Hs[((size_t)a.t1 * B + row) * PH + unit] = o_hh;
+        store_h_row(a.Hs + ((size_t)a.t1 * B + row) * PH + unit, o_hh, wt);
         float* zo = a.Z + ((size_t)(a.t1 - 1) * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
         zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+    }
+    if (wt) {                                     // the last `lag` steps: drain, barrier, publish
+        drain_vmem();
+        __syncthreads();
+        if (tid == 0)
+            for (int tp = max(a.t0, a.t1 - lag); tp < a.t1; ++tp)
+                if (tp % pk == pk - 1 || tp == a.t1 - 1) __hip_atomic_fetch_add(a.progress + tp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (PROF && lane == 0 && a.prof) {
         P16_STAMP(4)
@@ -352,7 +370,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_pair16(const LstmBwdXcdArgs
         n_dh = a.dH[(size_t)t * B * PH + hi];
     }
 
-    unsigned long long pacc[5] = {0, 0, 0, 0, 0}, plast = PROF ? __builtin_amdgcn_s_memtime() : 0;
+    xbf16x8 b2g0[8];                              // plane 2 of the first tile group's B operands
+#pragma unroll
+    for (int i8 = 0; i8 < 8; ++i8) b2g0[i8] = as_bf16x8(w2p[((i8 >> 2) * 16 + (i8 & 3)) * 64]);
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = PROF ? __builtin_amdgcn_s_memtime() : 0;   // [5] stores of groups 0-2, [6] late drain, [7] phase C before the first group
     for (int t = a.t1 - 1; t >= a.t0; --t) {
         P16_STAMP(4)
         const float si = n_si, tj = n_tj, sf = n_sf, so = n_so, ct = n_ct, cpv = n_cp, dht = n_dh;
@@ -431,14 +452,18 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_pair16(const LstmBwdXcdArgs
         // producer that sees this CU's partials may write the slot this CU has just reset.  k_lstm_bwd_pair waits for them HERE; with
         // XCD_LATE_DRAIN the wait stands in front of the first partial store instead, behind the first tile group's MFMAs -- the
         // acknowledgements of the write-through resets (~0.6 us) arrive under the cell update and those products.
-        if (!(a.variant & XCD_LATE_DRAIN)) drain_vmem();
+        const bool late = (a.variant & XCD_LATE_DRAIN) != 0;
+        if (!late) drain_vmem();
         if ((a.variant & XCD_DEFER_OUTPUTS) && act) { gp[0] = di; gp[4] = dj; gp[8] = df; gp[12] = dg; }
-        if (act && t > a.t0) {
-            const float* gn = a.Z + ((size_t)(t - 1) * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
-            n_si = gn[0]; n_tj = gn[4]; n_sf = gn[8]; n_so = gn[12];
-            n_ct = cpv; n_cp = a.Cs[(size_t)(t - 1) * B * PH + hi];
-            n_dh = a.dH[(size_t)(t - 1) * B * PH + hi];
-        }
+        auto next_inputs = [&]() __attribute__((always_inline)) {       // gates, cell states and dH of the update one step down
+            if (act && t > a.t0) {
+                const float* gn = a.Z + ((size_t)(t - 1) * B + row) * PG4 + 64 * cu + 16 * cbb + ce;
+                n_si = gn[0]; n_tj = gn[4]; n_sf = gn[8]; n_so = gn[12];
+                n_ct = cpv; n_cp = a.Cs[(size_t)(t - 1) * B * PH + hi];
+                n_dh = a.dH[(size_t)(t - 1) * B * PH + hi];
+            }
+        };
+        if (!late) next_inputs();           // (late: behind the wait for the resets, so that the wait does not wait for THEM)
 
         // ---- C: produce the partials of dh_{t-1}: 256 destination units per wave = sixteen 16-unit tiles, in four groups of four so
         // that a group's stores leave while the next group multiplies
@@ -449,28 +474,45 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_pair16(const LstmBwdXcdArgs
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) av[pl][ks] = *reinterpret_cast<const xbf16x8*>(&dzA[pl][ks][lane][0]);
             f32x4* out = inbox + (size_t)(t & 1) * slot_w + out_ofs;
+            // plane 2 of a group's eight B operands comes out of LDS one group AHEAD (the first group's at the top of the phase): a
+            // ds_read_b128 next to the MFMA that reads it costs its full latency, 32 times a step (profiles/r06_pair16_probe2_variants.log:
+            // 5870 ticks for 3072 of MFMAs)
+            xbf16x8 b2[2][8];
+            if (PROF) pacc[7] += __builtin_amdgcn_s_memtime() - plast;
+#pragma unroll
+            for (int i8 = 0; i8 < 8; ++i8) b2[0][i8] = b2g0[i8];
+            // (Measured and dropped, profiles/r06_pair16_probe4_bwd.log: the four stores of a group issued one by one INSIDE the next group,
+            // each behind twelve of its MFMAs -- 5.62 -> 5.77 us per step.  The 48 KiB of partials a CU writes per step leave at ~32 bytes
+            // per clock whatever the order, and a wave's MFMAs do not issue past a store that waits for its slot.)
 #pragma unroll
             for (int grp4 = 0; grp4 < 4; ++grp4) {
+                if (grp4 < 3) {
+#pragma unroll
+                    for (int i8 = 0; i8 < 8; ++i8) b2[(grp4 + 1) & 1][i8] = as_bf16x8(w2p[((i8 >> 2) * 16 + 4 * (grp4 + 1) + (i8 & 3)) * 64]);
+                }
                 f32x4 acc[4];
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) acc[j4] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                    for (int j4 = 0; j4 < 4; ++j4)
-                        acc[j4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2][ks], W[0][ks][4 * grp4 + j4], acc[j4], 0, 0, 0);
-#pragma unroll
-                    for (int j4 = 0; j4 < 4; ++j4)
-                        acc[j4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0][ks], as_bf16x8(w2p[(ks * 16 + 4 * grp4 + j4) * 64]), acc[j4], 0, 0, 0);
-#define P16_BWD(PA, PB)                                                                                         \
+#define P16_BWD(AOP, BOP)                                                                                       \
                     _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4)                                            \
-                        acc[j4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[PA][ks], W[PB][ks][4 * grp4 + j4], acc[j4], 0, 0, 0);
-                    P16_TERMS_REG(P16_BWD)
+                        acc[j4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AOP, BOP, acc[j4], 0, 0, 0);
+                    P16_BWD(av[2][ks], W[0][ks][4 * grp4 + j4])
+                    P16_BWD(av[0][ks], b2[grp4 & 1][ks * 4 + j4])
+                    P16_BWD(av[1][ks], W[1][ks][4 * grp4 + j4])
+                    P16_BWD(av[1][ks], W[0][ks][4 * grp4 + j4])
+                    P16_BWD(av[0][ks], W[1][ks][4 * grp4 + j4])
+                    P16_BWD(av[0][ks], W[0][ks][4 * grp4 + j4])
 #undef P16_BWD
                 }
+                if (grp4 < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the next group's LDS reads first ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 48, 0);                    // ... then this group's MFMAs
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-                if (grp4 == 0 && (a.variant & XCD_LATE_DRAIN)) drain_vmem();
+                unsigned long long q0 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+                if (grp4 == 0 && late) { drain_vmem(); next_inputs(); }
+                if (PROF && grp4 == 0) { const unsigned long long q1 = __builtin_amdgcn_s_memtime(); pacc[6] += q1 - q0; q0 = q1; }
                 if (grp4 == 3) { P16_STAMP(3) }
                 if (outl) {
 #pragma unroll
@@ -479,13 +521,14 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_pair16(const LstmBwdXcdArgs
                         else store_sc1(out + (size_t)(4 * grp4 + j4) * RG * PCU * 16, acc[j4]);
                     }
                 }
+                if (PROF && grp4 < 3) pacc[5] += __builtin_amdgcn_s_memtime() - q0;
             }
         }
     }
     if (act) a.dc[hi] = dcv;
     if (PROF && lane == 0 && a.prof) {
         P16_STAMP(4)
-        for (int i = 0; i < 5; ++i) a.prof[((size_t)(role.xcd * NCU + role.cu) * 4 + wave) * 8 + i] = pacc[i];
+        for (int i = 0; i < 8; ++i) a.prof[((size_t)(role.xcd * NCU + role.cu) * 4 + wave) * 8 + i] = pacc[i];
     }
 }
 #undef P16_TERMS_REG

@@ -2064,10 +2064,11 @@ hipError_t launch_repack_kh_all(hipStream_t s, const RepackAllArgs& a, const Ste
 // row groups of a launch whose rows are packed `rpx` per XCD (0: spread over all eight): the bf16-split kernels take up to 16
 // rows per XCD at the same MFMA cost, so a batch may sit on fewer XCDs than the 8-way split would use
 static int xcd_row_groups(int B, int Hp = 512);
-static int xcd_row_groups_packed(int B, int rpx) {
-    const int rg = xcd_row_groups(B, XH);
+static int xcd_row_groups_packed(int B, int rpx, int Hp = 512) {
+    const int rg = xcd_row_groups(B, Hp);
     if (rpx <= 0) return rg;
     const int need = (rpx + 3) / 4;
+    if (Hp == PH) return std::max(rg, need);      // (the pair kernels take three row groups as they are)
     return std::max(rg, need == 3 ? 4 : need);
 }
 static int xcd_row_groups(int B, int Hp) {
@@ -2085,19 +2086,22 @@ bool lstm_xcd_supported(int B, int Hp) {
 int lstm_xcd_max_rows(int Hp) { return Hp == PH ? 16 * PGRP : (Hp == XH ? 16 * NXCD : (Hp == SH ? 8 * NSL : 0)); }
 
 long long lstm_xcd_hx_floats(int B, int T, int Hp, bool bx3, int rpx) {
-    if (Hp == PH && bx3) return (long long)(T + 1) * (4 * xcd_row_groups(B, Hp)) * PGRP * HXW16P * 4;       // rows x pairs x 6 KiB, see lstm_pair16.h
+    if (Hp == PH && bx3) return (long long)(T + 1) * (4 * xcd_row_groups_packed(B, rpx, PH)) * PGRP * HXW16P * 4;       // rows x pairs x 6 KiB, see lstm_pair16.h
     if (Hp == PH) return (long long)(T + 1) * PGRP * 4 * xcd_row_groups(B, Hp) * PNQ * 64 * 4;
     if (Hp == SH) return (long long)(T + 1) * NSL * 4 * xcd_row_groups(B, Hp) * 64 * 4;
     if (bx3) return (long long)(T + 1) * (4 * xcd_row_groups_packed(B, rpx)) * NXCD * HXW16 * 4;      // rows x XCDs x 3 KiB, see k_lstm_fwd_xcd16
     return (long long)(T + 1) * NXCD * 4 * xcd_row_groups_packed(B, rpx) * 2 * 64 * 4;
 }
 long long lstm_xcd_inbox_floats(int B, int Hp, int rpx) {
-    if (Hp == PH) return 2LL * PGRP * PCU * xcd_row_groups(B, Hp) * PCU * 16 * 4;
+    if (Hp == PH) return 2LL * PGRP * PCU * xcd_row_groups_packed(B, rpx, PH) * PCU * 16 * 4;
     if (Hp == SH) return 2LL * NSL * SCU * SCU * xcd_row_groups(B, Hp) * 16 * 4;
     return 2LL * NXCD * NCU * NCU * xcd_row_groups_packed(B, rpx) * 16 * 4;
 }
 // the bf16-split kernels take up to 16 rows per XCD at the same MFMA cost: the fewest XCDs that hold B rows, rows spread evenly
-int lstm_xcd16_packed_rows(int B) { const int nx = (B + 15) / 16; return nx >= 1 && nx <= NXCD ? (B + nx - 1) / nx : 0; }
+int lstm_xcd16_packed_rows(int B, int Hp) {      // (hidden 1024: per XCD PAIR)
+    const int nx = (B + 15) / 16;
+    return nx >= 1 && nx <= (Hp == PH ? PGRP : NXCD) ? (B + nx - 1) / nx : 0;
+}
 long long lstm_xcd_weight_floats(int Hp, bool bx3) { return (bx3 && (Hp == XH || Hp == PH)) ? (long long)Hp * 4 * Hp * 3 / 2 : (long long)Hp * 4 * Hp; }   // three bf16 planes
 // The bf16-split kernels pay 1536 MFMA cycles per step for any row count, the fp32 ones 1024 per row group, and the bf16 hand-off
 // is 1.5x the bytes in 3x the load instructions: measured (profiles/r03_xcd16_probe3.log, us per step forward / backward)
@@ -2152,13 +2156,12 @@ hipError_t launch_lstm_fwd_xcd(hipStream_t s, const LstmFwdXcdArgs& a) {
         return hipGetLastError();
     }
     if (a.Hp == PH && a.bx3) {
-        if (a.progress) return hipErrorInvalidValue;
         if (a.prof) {
-            if (xcd_row_groups(a.B, PH) != 3) return hipErrorInvalidValue;
+            if (xcd_row_groups_packed(a.B, a.rpx, PH) != 3 || a.progress) return hipErrorInvalidValue;
             hipLaunchKernelGGL((k_lstm_fwd_pair16<3, true>), grid, block, 0, s, a);
             return hipGetLastError();
         }
-        switch (xcd_row_groups(a.B, PH)) {
+        switch (xcd_row_groups_packed(a.B, a.rpx, PH)) {
             case 1: hipLaunchKernelGGL((k_lstm_fwd_pair16<1, false>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((k_lstm_fwd_pair16<2, false>), grid, block, 0, s, a); break;
             case 3: hipLaunchKernelGGL((k_lstm_fwd_pair16<3, false>), grid, block, 0, s, a); break;
@@ -2229,11 +2232,11 @@ hipError_t launch_lstm_bwd_xcd(hipStream_t s, const LstmBwdXcdArgs& a) {
     }
     if (a.Hp == PH && a.bx3) {
         if (a.prof) {
-            if (xcd_row_groups(a.B, PH) != 3) return hipErrorInvalidValue;
+            if (xcd_row_groups_packed(a.B, a.rpx, PH) != 3) return hipErrorInvalidValue;
             hipLaunchKernelGGL((k_lstm_bwd_pair16<3, true>), grid, block, 0, s, a);
             return hipGetLastError();
         }
-        switch (xcd_row_groups(a.B, PH)) {
+        switch (xcd_row_groups_packed(a.B, a.rpx, PH)) {
             case 1: hipLaunchKernelGGL((k_lstm_bwd_pair16<1, false>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((k_lstm_bwd_pair16<2, false>), grid, block, 0, s, a); break;
             case 3: hipLaunchKernelGGL((k_lstm_bwd_pair16<3, false>), grid, block, 0, s, a); break;
