@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair16(const LstmFwdXcdArgs
         }
         if (PROF) { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); acc[0][0] += 0.0f; }
         P16_STAMP(1)
-        if (PROF && (a.variant & 2048)) {          // diagnostics: the same 24 fragments again, now surely present: [5] sc1 loads, [7] plain loads (ticks)
+        if (PROF && (a.variant & 8192)) {          // diagnostics: the same 24 fragments again, now surely present: [5] sc1 loads, [7] plain loads (ticks)
             f32x4 bv[P16NF];
             unsigned long long q0 = __builtin_amdgcn_s_memtime();
 #define P16_LD(J) bv[J] = load_sc1_ofs<((J) & 3) * HXR * 64>(af + ((J) >> 2) * (4 * HXR * 4));

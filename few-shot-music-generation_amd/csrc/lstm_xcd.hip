@@ -901,6 +901,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd16(const LstmFwdXcdArgs 
     const bool ldl = arow < rpx;                  // lanes of pad rows never load: their A registers stay zero
     const size_t hx_step = (size_t)HXR * NXCD * HXW16;                      // 16-byte words per time index
     const f32x4* hx_in = reinterpret_cast<const f32x4*>(a.HX) + (((size_t)xcd * 4 + wave) * 12) * (HXR * 4) + arow * 4 + akg;
+    // XCD_STREAM: every lane loads (the lanes of pad rows row 0 again -- same cache lines, and no divergent loads for the compiler to merge)
+    const f32x4* hx_in_all = hx_in - (ldl ? 0 : arow * 4);
     // unit u = 16 cu + 4 cbb + ce -> w = u / 128, k step = u % 128 / 32, k group = u % 32 / 8, position u % 8
     f32x4* hx_out = reinterpret_cast<f32x4*>(a.HX) +
         ((((size_t)xcd * 4 + (cu >> 3)) * 12 + ((cu & 7) >> 1)) * (HXR * 4) + lrow * 4 + 2 * (cu & 1) + (cbb >> 1));
@@ -924,7 +926,39 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd16(const LstmFwdXcdArgs 
 
     for (int t = a.t0; t < a.t1; ++t) {
         XCD_STAMP(4)
-        {
+        // XCD_PROBE / XCD_STREAM as in k_lstm_fwd_pair16 (lstm_pair16.h, where both were measured first): a wave polls ONE word per lane -- plane 2
+        // (stored last) of k step (row % 4): its lanes cover every (producer CU, cell wave) of the wave's K range -- and behind a successful
+        // probe the twelve fragments are ordinary loads in k-step order that the MFMAs consume as they arrive; checked afterwards, a miss
+        // redoes the step behind the sc1 poll
+        bool stream = false;
+        if (a.variant & XCD_PROBE) {
+            const f32x4* sp = hx_in + (size_t)t * hx_step + (2 * 4 + (arow & 3)) * (HXR * 4);
+            for (int spins = 0; spins < a.spin_limit; ++spins) {
+                f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ldl) { sv = load_sc1(sp); drain_vmem(); }
+                asm volatile("" : "+v"(sv));
+                const unsigned m = pk_max_u16(pk_max_u16(__float_as_uint(sv[0]), __float_as_uint(sv[1])), pk_max_u16(__float_as_uint(sv[2]), __float_as_uint(sv[3])));
+                if (__all((m & 0xffffu) != 0xffffu && (m >> 16) != 0xffffu)) { stream = (a.variant & XCD_STREAM) != 0; break; }
+                if (!(a.variant & XCD_NO_POLL_SLEEP)) __builtin_amdgcn_s_sleep(FSMG_POLL_SLEEP);
+                if ((spins & 255) == 255 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2) break;
+            }
+        }
+        float zin[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { zin[g] = zq[0][g]; zq[0][g] = zq[1][g]; zq[1][g] = 0.0f; }
+        float* zp = a.Z + ((size_t)t * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
+        const bool outs_early = !(a.variant & XCD_STREAM);
+        f32x4 acc[4];
+        for (;;) {
+        if (stream) {
+            const f32x4* af = hx_in_all + (size_t)t * hx_step;
+#define X16_LDC(J) av[J] = af[((J) >> 2) * (4 * HXR * 4) + ((J) & 3) * (HXR * 4)];
+#define X16_LD3(KS) X16_LDC(KS) X16_LDC(4 + KS) X16_LDC(8 + KS) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+            X16_LD3(0) X16_LD3(1) X16_LD3(2) X16_LD3(3)
+#undef X16_LD3
+#undef X16_LDC
+        } else {
             bool fail = false;
             const f32x4* af = hx_in + (size_t)t * hx_step;
             for (int spins = 0;; ++spins) {
@@ -946,23 +980,21 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd16(const LstmFwdXcdArgs 
                 s_fail = 1;
             }
         }
-        if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {
+        // outputs of the step before: behind a successful poll, under the MFMAs -- streamed fetch: behind the MFMAs, whose waits then count the
+        // fragments only
+        if (outs_early && (a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {
             a.Cs[((size_t)t * B + row) * XH + unit] = o_c;
             store_h_row(a.Hs + ((size_t)t * B + row) * XH + unit, o_hh, wt);
             float* zo = a.Z + ((size_t)(t - 1) * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
             zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+            o_have = false;
         }
-        float zin[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { zin[g] = zq[0][g]; zq[0][g] = zq[1][g]; zq[1][g] = 0.0f; }
-        float* zp = a.Z + ((size_t)t * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
-        if (act && t + 2 < a.t1) {
+        if (outs_early && act && t + 2 < a.t1) {
             const float* zn = zp + 2 * (size_t)B * XG4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) zq[1][g] = zn[4 * g];
         }
         XCD_STAMP(0)
-        f32x4 acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -972,6 +1004,24 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_xcd16(const LstmFwdXcdArgs 
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(av[(PA) * 4 + ks]), W[PB][ks][nt], acc[nt], 0, 0, 0);
             X16_TERMS(X16_FWD)
 #undef X16_FWD
+        }
+        if (!outs_early) {
+            if ((a.variant & XCD_DEFER_OUTPUTS) && o_have && act) {
+                a.Cs[((size_t)t * B + row) * XH + unit] = o_c;
+                store_h_row(a.Hs + ((size_t)t * B + row) * XH + unit, o_hh, wt);
+                float* zo = a.Z + ((size_t)(t - 1) * B + row) * XG4 + 64 * cu + 16 * cbb + ce;
+                zo[0] = o_g[0]; zo[4] = o_g[1]; zo[8] = o_g[2]; zo[12] = o_g[3];
+            }
+            o_have = false;
+        }
+        if (!stream) break;
+        if (__all(frags16_ready(av))) break;
+        stream = false;                                // a fragment was not there yet: redo the step behind the sc1 poll
+        }
+        if (!outs_early && act && t + 2 < a.t1) {
+            const float* zn = zp + 2 * (size_t)B * XG4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) zq[1][g] = zn[4 * g];
         }
         if (PROF) { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); acc[0][0] += 0.0f; }
         XCD_STAMP(1)
@@ -1182,6 +1232,32 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd16(const LstmBwdXcdArgs 
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) av[pl][ks] = *reinterpret_cast<const xbf16x8*>(&dzA[pl][ks][lane][0]);
+            if (a.variant & XCD_GROUP_STORES) {
+                // the eight destination tiles in two groups of four: the first group's partials leave (and reach their consumers) while the
+                // second multiplies (k_lstm_bwd_pair16, where the grouping was measured first: 6.76 -> 5.85 us per step)
+                f32x4* out = inbox + (size_t)(t & 1) * slot_w + out_ofs;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    f32x4 acc[4];
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) acc[j4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+#define X16_BWD(PA, PB)                                                                                         \
+                        _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4)                                        \
+                            acc[j4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[PA][ks], W[PB][ks][4 * g2 + j4], acc[j4], 0, 0, 0);
+                        X16_TERMS(X16_BWD)
+#undef X16_BWD
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                    if (g2 == 1) { XCD_STAMP(3) }
+                    if (outl) {
+#pragma unroll
+                        for (int j4 = 0; j4 < 4; ++j4) store_l2(out + (size_t)(4 * g2 + j4) * NCU * RG * 16, acc[j4]);
+                    }
+                }
+            } else {
             f32x4 acc[8];
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1200,6 +1276,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_xcd16(const LstmBwdXcdArgs 
                 f32x4* out = inbox + (size_t)(t & 1) * slot_w + out_ofs;
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) store_l2(out + (size_t)nt * NCU * RG * 16, acc[nt]);
+            }
             }
         }
     }
@@ -2138,7 +2215,9 @@ int lstm_xcd_default_variant(int B, bool forward, int Hp, int rpx, bool bx3) {
         if (rg >= 2 && (!forward || rg == 2)) return XCD_CHAINS | XCD_NO_POLL_SLEEP;
         return XCD_NO_POLL_SLEEP;
     }
-    if (!forward) return XCD_NO_POLL_SLEEP;
+    // backward on the bf16 pipe at hidden 512: the partials of four destination tiles leave while the other four multiply (B = 45 packed 15 per XCD:
+    // 3.01 -> 2.78 us per step, profiles/r06_xcd16_probe_variants.log; the forward kernel's probe / streamed fetch: 3.06 -> 3.03, not taken)
+    if (!forward) return (bx3 && Hp == XH) ? (XCD_NO_POLL_SLEEP | XCD_GROUP_STORES) : XCD_NO_POLL_SLEEP;
     if (Hp == SH) return XCD_DEFER_OUTPUTS | XCD_NO_POLL_SLEEP;
     return xcd_row_groups_packed(B, rpx) <= 2 ? (XCD_DEFER_OUTPUTS | XCD_NO_POLL_SLEEP) : XCD_NO_POLL_SLEEP;
 }

@@ -896,6 +896,31 @@ def test_nccl_allreduce_runs_on_the_gradient_tensor_and_model_stream():
         dist.destroy_process_group()
 
 
+def test_partitioned_order_at_hidden_1024_matches_the_oracle_at_cfg_c(monkeypatch):
+    """The XCD-partitioned order at hidden 1024 (opt-in: measured to lose at cfg-C, profiles/r06_cfgC_xov_ab.txt) with every part on --
+    the top layer's chains packed on three XCD pairs (15 rows each, four row groups), the gated projection beside the forward chain, dW
+    beside the top BPTT chain, dK of layer 1 (two-part A, from the work queue) beside the BPTT chain of layer 0: loss and every gradient
+    of a full cfg-C episode against the fp64 oracle, same bounds as the serial order; no time-out, and the order was really taken."""
+    monkeypatch.setenv('FSMG_XCD_OVERLAP', '1')
+    monkeypatch.setenv('FSMG_XOV_PARTS', '7')
+    over, N, K, Q = FULL['cfg-C']
+    cfg = small_config(**over)
+    (sup, qry), = O.synthetic_episodes(1, N, K, Q, cfg['max_len'], cfg['input_size'], seed=8, realistic=True)
+    model = new_model(cfg, max_sequences=N * (K + Q))
+    params = f64_params(model)
+    loss, cache, grads, aux = cached_oracle_step(('full', 'cfg-C'), params, sup, qry, cfg)
+    for _ in range(2):                                          # (the second pass: queue words and inboxes left by the first)
+        model.forward_backward(sup, qry)
+        tail = model.debug_read('tail', 16)
+        assert abs(tail[1] - loss) <= NLL_RTOL * abs(loss)
+        for name_ in grads:
+            assert rel_max(model.get_grad(name_), grads[name_]) < 2e-4, name_
+    st = model.stats()
+    assert st['timeouts'] == 0 and model.debug_read('xcd_bx3', 1)[0] == 1.0
+    part = model.debug_read('xcd_partitioned', 3)
+    assert part[0] == 1.0 and part[1] == 6.0 and part[2] == 1.0     # the passes took the partitioned order, chains on XCDs 0-5
+
+
 @pytest.mark.parametrize('name', sorted(FULL))
 def test_full_size_gradients_match_oracle(name, gemm_kind):
     """One full train episode of every BASELINE config that fits one GPU -- cfg-B (B=45, T=128, V1=10001, H=512),
@@ -1030,10 +1055,14 @@ def test_ten_consecutive_train_losses_on_the_bf16_split_chain_at_cfg_d_rows():
 
 FORCED = [(env, i) for env in ({'FSMG_XCD_BX3': '1'}, {'FSMG_GEMM_H': '2'}, {'FSMG_XCD_OVERLAP': '0'}) for i in (2, 4, 9, 10, 11, 12)] + [({'FSMG_GEMM_H': '2'}, 20)] + \
          [({'FSMG_XCD_OVERLAP': '1'}, i) for i in (9, 10)] + \
-         [({'FSMG_XCD': '0'}, i) for i in (8, 16)]              # ... the XCD-partitioned order at shapes AUTO finds too small for it; the column-split persistent kernels at hidden 256 / 512
+         [({'FSMG_XCD': '0'}, i) for i in (8, 16)] + \
+         [({'FSMG_XCD_BX3': '1'}, 13), ({'FSMG_XCD_BX3': '1', 'FSMG_XCD_VARIANT': '32'}, 13), ({'FSMG_XCD_BX3': '1', 'FSMG_XCD_VARIANT': '176'}, 13)]
+         # ... the XCD-partitioned order at shapes AUTO finds too small for it; the column-split persistent kernels at hidden 256 / 512; hidden 1024 on the
+         # bf16 matrix pipe (k_lstm_*_pair16) where AUTO keeps the fp32 pair kernels (4 rows), with its default variants, with none of them
+         # (32: every poll fetches all 24 fragments, write-through partials everywhere, early reset wait) and with probe but no streamed fetch (176)
 
 
-@pytest.mark.parametrize('env,idx', FORCED, ids=['%s-%d' % (next(iter(e)) + '=' + next(iter(e.values())), i) for e, i in FORCED])
+@pytest.mark.parametrize('env,idx', FORCED, ids=['%s-%d' % ('+'.join(k + '=' + v for k, v in e.items()), i) for e, i in FORCED])
 def test_forced_kernel_families_on_a_reduced_shape_list(env, idx, monkeypatch):
     """The kernel families a default run only picks at some shapes, forced at a reduced list of SHAPES (B = 45 rows, two stacked
     layers, hidden 512 with 1 / 2 / 4 row groups and stacked): the bf16-split XCD-local recurrence (FSMG_XCD_BX3=1), the
