@@ -85,7 +85,7 @@ ARITHMETIC_GEMM = ('fp32 storage, fp32 accumulation everywhere.  GEMMs (default,
                    'v_mfma_f32_32x32x2_f32 (timed in the same run: roofline.alt_gemm_f32_mfma_value).  ')
 # the fused cell's arithmetic depends on the kernel family the timed schedule ran (the line said 4x4x1 for every schedule)
 ARITHMETIC_CELL = {
-    'bf16x3': 'Fused LSTM cell (this schedule: k_lstm_*_xcd16): the recurrent contraction as the same exact three-way bf16 split, six products per '
+    'bf16x3': 'Fused LSTM cell (this schedule: k_lstm_*_xcd16 at hidden 512, k_lstm_*_pair16 at hidden 1024): the recurrent contraction as the same exact three-way bf16 split, six products per '
               'fp32 product on v_mfma_f32_16x16x32_bf16, fp32 accumulation; gates, state update and gate gradients in fp32.',
     'f32': 'Fused LSTM cell (this schedule): v_mfma_f32_4x4x1_16B_f32 (fp32 MFMA); gates, state update and gate gradients in fp32.',
     'f32_16x16x4': 'Fused LSTM cell (this schedule: column-split persistent kernels): v_mfma_f32_16x16x4_f32 (fp32 MFMA).',
@@ -839,7 +839,10 @@ def main():
                 cell_bx3 = bool(eng.debug_read('xcd_bx3', 1)[0])
             except Exception:                  # noqa: BLE001
                 cell_bx3 = False
-            if cell_bx3:      # hidden 512, > 64 rows: the recurrent product as six bf16 products per fp32 product (csrc/lstm_xcd.hip)
+            if cell_bx3 and cfg['hidden_size'] > 512:      # hidden 1024, three row groups per weight copy and up (csrc/lstm_pair16.h, round 6)
+                cell_kernel = ('k_lstm_fwd_pair16 + k_lstm_bwd_pair16 (recurrent [B x H] x [H x 4H] contraction as an exact three-way bf16 split on '
+                               'v_mfma_f32_16x16x32_bf16, fp32 accumulation; K_h planes 0-1 in the registers of an XCD pair, plane 2 in 128 KiB of LDS per CU')
+            elif cell_bx3:    # hidden 512, > 64 rows: the recurrent product as six bf16 products per fp32 product (csrc/lstm_xcd.hip)
                 cell_kernel = ('k_lstm_fwd_xcd16 + k_lstm_bwd_xcd16 (recurrent [B x H] x [H x 4H] contraction as an exact three-way bf16 split on '
                                'v_mfma_f32_16x16x32_bf16, fp32 accumulation')
             elif cfg['hidden_size'] > 512:
@@ -871,7 +874,7 @@ def main():
                 # what one launch has to move (per direction, mean of the two): forward reads Z and writes the four gates, c and h; backward reads
                 # gates, c and dH and writes dZ -- 4H + 4H + 2H floats per row and time step either way
                 'algorithmic_bytes_per_launch': 4.0 * B * T * 10 * cfg['hidden_size'] * cfg['n_layers'] / max(cell['lstm_fwd'][1] / max(args.steps, 1), 1),
-                'traffic_note': ('forward = its algorithmic bytes; the bf16-split backward hands dh over as a reduce-scatter (32 partial [16 x 512] tiles per '
+                'traffic_note': None if cfg['hidden_size'] > 512 else ('forward = its algorithmic bytes; the bf16-split backward hands dh over as a reduce-scatter (32 partial [16 x 512] tiles per '
                                  'XCD and time step, 1 MB, plus the sentinel refill): about a third of those L2 writes are written back (WRITE_SIZE 334 MB against '
                                  '47 MB of dZ) = 0.7 TB/s during a latency-bound chain (DESIGN.md 9.3)') if cell_bx3 else None,
                 'algorithmic_gflop_per_launch': gf['lstm_fwd'] / max(cell['lstm_fwd'][1] / max(args.steps, 1), 1),
@@ -892,7 +895,8 @@ def main():
                 xp = eng.debug_read('xcd_partitioned', 2)
             except Exception:                  # noqa: BLE001
                 xp = [0.0, 8.0]
-            variant = ('xcd16<4' if xp[0] else 'xcd16<2') if cell_bx3 else ('xcd<2' if cfg['hidden_size'] == 512 else None)
+            variant = (('pair16<3' if cfg['hidden_size'] > 512 else ('xcd16<4' if xp[0] else 'xcd16<2')) if cell_bx3
+                       else ('xcd<2' if cfg['hidden_size'] == 512 else None))
             out['roofline']['traffic'], out['roofline']['traffic_source'] = hbm_traffic(variant)
             out['roofline']['kernel_variant'] = variant
             if xp[0]:
