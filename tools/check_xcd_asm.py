@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static check of the row-group-chain kernels of the XCD-pair recurrence (csrc/lstm_xcd.hip: k_lstm_fwd_pair_chains /
-k_lstm_bwd_pair_chains).
+k_lstm_bwd_pair_chains) and of the bf16-split pair kernels (csrc/lstm_pair16.h: check_pair16 below).
 
 Those kernels issue loads in one phase and consume them in a later one, with `s_waitcnt vmcnt(N)` counted by hand.  Two things
 must hold on the FINAL ISA, whatever the compiler felt like doing, and this script checks both on a fresh `hipcc -S`:
@@ -110,6 +110,49 @@ def check(name, lines):
     return problems
 
 
+def check_pair16(asm):
+    """k_lstm_fwd_pair16 / k_lstm_bwd_pair16 (csrc/lstm_pair16.h): 256 weight registers per lane leave the compiler ~200 for everything
+    else, and the forward kernel's streamed fetch rests on the ORDER hipcc gives its own loads and waits.  On the final ISA of every
+    product instantiation:
+      1. nothing is spilled (no scratch_ instruction; a spill in the time loop is a memory operation in front of a poll);
+      2. a step is 192 v_mfma_f32_16x16x32_bf16 (six products x eight k steps x four column tiles / two k steps x sixteen tiles);
+      3. forward: the 24 streamed fragment loads (global_load_dwordx4 without sc1, in one run) are consumed progressively -- the first
+         compiler-inserted wait behind them still leaves >= 18 loads in flight (hipcc used to cluster them by base register: 11)."""
+    problems, found = [], 0
+    for m in re.finditer(r'^(_ZN4fsmg\S*k_lstm_(fwd|bwd)_pair16ILi(\d)ELb0E\S*):', asm, re.M):
+        name, direction = m.group(1), m.group(2)
+        body = asm[m.end():asm.index('.Lfunc_end', m.end())]
+        lines = [l.strip() for l in body.splitlines()]
+        code = [l for l in lines if l and not l.startswith((';', '.'))]
+        found += 1
+        tag = 'k_lstm_%s_pair16<%s>' % (direction, m.group(3))
+        if any(l.startswith('scratch_') for l in code):
+            problems.append('%s: spills (scratch_ instructions)' % tag)
+        n_mfma = sum(1 for l in code if l.startswith('v_mfma_f32_16x16x32_bf16'))
+        if n_mfma != 192:
+            problems.append('%s: %d MFMAs, expected 192' % (tag, n_mfma))
+        if direction == 'fwd':
+            idx = [i for i, l in enumerate(code) if l.startswith('global_load_dwordx4') and 'sc1' not in l]
+            runs, cur = [], []
+            for i in idx:
+                if cur and i - cur[-1] > 12:
+                    runs.append(cur); cur = []
+                cur.append(i)
+            if cur:
+                runs.append(cur)
+            runs = [r for r in runs if len(r) == 24]
+            if len(runs) != 1:
+                problems.append('%s: the run of 24 streamed fragment loads was not found' % tag)
+                continue
+            first_wait = next((l for l in code[runs[0][-1] + 1:] if l.startswith('s_waitcnt') and 'vmcnt' in l), None)
+            n = int(re.search(r'vmcnt\((\d+)\)', first_wait).group(1)) if first_wait else -1
+            if n < 18:
+                problems.append('%s: the first wait behind the streamed loads is "%s": the fetch is not consumed k step by k step' % (tag, first_wait))
+    if found != 8:
+        problems.append('expected 8 product instantiations of the pair16 kernels, found %d' % found)
+    return problems
+
+
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, 'xcd.s')
@@ -132,6 +175,11 @@ def main():
         for p in problems:
             print('   ' + p)
         bad += len(problems)
+    p16 = check_pair16(asm)
+    print('k_lstm_*_pair16: %s' % ('ok' if not p16 else '%d problem(s)' % len(p16)))
+    for p in p16:
+        print('   ' + p)
+    bad += len(p16)
     return 1 if bad else 0
 
 
