@@ -425,6 +425,47 @@ def test_inbox_refill_flag_survives_the_fallback_period():
         np.testing.assert_array_equal(a.get_param(k), v)
 
 
+@pytest.mark.parametrize('order', ['serial', 'partitioned'])
+def test_pair16_kernels_time_out_and_recover(order, monkeypatch):
+    """Hidden 1024 on the bf16 matrix pipe (k_lstm_*_pair16, 45 rows, two stacked layers) under a forced time-out: the chain gives up at
+    its first wait (spin limit 0: no probe, the sc1 poll fails at once), the step is skipped on the device and repeated on per-step
+    launches, later steps go back to the pair kernels -- on BPTT inboxes that still hold the aborted pass's partials, which the
+    same-XCD half of them received through the L2 (XCD_LOCAL_PLAIN) and the other half write-through.  Against a handle that runs the
+    same kernel families without ever timing out: same bits.  `partitioned`: the opt-in XCD-partitioned order with every part on
+    (packed chains, gated projection, dW and the queued dK beside the BPTT chains)."""
+    if order == 'partitioned':
+        monkeypatch.setenv('FSMG_XCD_OVERLAP', '1')
+        monkeypatch.setenv('FSMG_XOV_PARTS', '7')
+    cfg = small_config(hidden_size=1024, embedding_size=32, input_size=600, max_len=32, n_layers=2)
+    eps = O.synthetic_episodes(5, 5, 5, 4, cfg['max_len'], cfg['input_size'], seed=36)
+    a, b = new_model(cfg, max_sequences=45), new_model(cfg, max_sequences=45)
+    assert bool(a.debug_read('xcd_bx3', 1)[0]) and (a.debug_read('xcd_partitioned', 2)[0] == 1.0) == (order == 'partitioned')
+    la, lb = [a.train_step(*eps[0])], [b.train_step(*eps[0])]
+    assert a.stats()['xcd_launches'] > 0
+    a.debug_set('fallback_steps', 2)
+    a.debug_set('chain_spin_limit', 0)
+    la.append(a.train_step(*eps[1]))                    # times out, is skipped on the device, repeated on per-step launches
+    st = a.stats()
+    assert st['timeouts'] == 1 and st['steps_skipped_timeout'] == 1 and not st['persistent_path'] and a.step == 2
+    a.debug_set('chain_spin_limit', 1 << 18)
+    b.debug_set('persistent', 0)
+    lb.append(b.train_step(*eps[1]))
+    b.debug_set('persistent', 1)
+    x0 = a.stats()['xcd_launches']
+    for e in eps[2:]:
+        la.append(a.train_step(*e)); lb.append(b.train_step(*e))
+    st = a.stats()
+    assert st['persistent_path'] and st['xcd_launches'] > x0 and st['timeouts'] == 1
+    if order == 'serial':
+        assert la == lb
+        for k, v in b.get_params().items():
+            np.testing.assert_array_equal(a.get_param(k), v)
+    else:                                               # (the fallback step of A ran the serial order's K splits: close, not the same bits)
+        assert np.allclose(la, lb, rtol=1e-5)
+        for k, v in b.get_params().items():
+            assert rel_max(a.get_param(k), v) < 1e-4, k
+
+
 def test_partitioned_schedule_times_out_and_recovers(monkeypatch):
     """The XCD-partitioned order under a forced time-out: the packed chain gives up at its first wait (spin limit 0), the gated
     projection tiles see the flag and leave, the step is skipped on the device and repeated on per-step launches; later steps go

@@ -1,5 +1,4 @@
 #!/bin/bash
 # scratch runner for one gpurun call (edit, then: gpurun -- 'bash tools/_gpu_job.sh'); what it leaves under gpurun_out/ comes back
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
-python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -2
-timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -12 > $O/r06_gputests_e.log; tail -4 $O/r06_gputests_e.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "pair16 or partitioned" 2>&1 | tail -25
