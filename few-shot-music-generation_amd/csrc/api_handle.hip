@@ -329,8 +329,9 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (h->xov && h->bx3 && h->Hp == 512) h->xcd_bx3 = true;
         // (hidden 1024: the bf16-split pair kernels share the arithmetic of the bf16-split GEMMs; a handle on the fp32 MFMA keeps the fp32 chains)
         if (h->Hp == 1024 && !h->bx3) h->xcd_bx3 = false;
-        if (const char* e = std::getenv("FSMG_XCD_BX3")) h->xcd_bx3 = std::atoi(e) != 0 && (h->Hp == 512 || h->Hp == 1024);
-        if (hipMalloc((void**)&h->khx, sizeof(float) * (size_t)h->L * 2 * lstm_xcd_weight_floats(h->Hp, h->xcd_bx3)) != hipSuccess)
+        if (const char* e = std::getenv("FSMG_XCD_BX3")) { h->xcd_bx3 = std::atoi(e) != 0 && (h->Hp == 512 || h->Hp == 1024); h->xcd_bx3_forced = true; }
+        // (hidden 1024: room for either format -- the one in use follows the row count of the train passes, select_xcd_format)
+        if (hipMalloc((void**)&h->khx, sizeof(float) * (size_t)h->L * 2 * lstm_xcd_weight_floats(h->Hp, h->xcd_bx3 || h->Hp == 1024)) != hipSuccess)
             return bail(FSMG_ERR_NOMEM, "hipMalloc(XCD-local weight images) failed");
     }
     const int b0 = cfg->max_sequences > 0 ? cfg->max_sequences : 45;

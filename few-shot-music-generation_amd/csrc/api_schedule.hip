@@ -111,6 +111,20 @@ int gemm(fsmg_model* h, const Lane& ln, int amode, int bmode, GemmArgs g, OpBatc
 // put a high-priority wave on every SIMD of the chip and spend half of their time in hand-offs; GEMM waves beside them
 // stretch both (measured at cfg-B: 374-379 episodes/s two-stream with 1-4 chunks against 383-385 single-stream), so a pass
 // that takes them runs single-stream; the per-step kernels of big validation batches keep the overlap.
+// Hidden 1024: which pair kernels a handle's TRAIN passes run follows their row count -- the bf16-split ones (k_lstm_*_pair16) from three
+// row groups per weight copy on, the fp32 row-group chains below (lstm_xcd_bx3_pays) -- not the episode size the handle was created
+// for: a MAML-style step (cfg-E) is created for 45 sequences and runs passes of 25 and 20 rows (measured with the format fixed at
+// creation: 266 -> 255-261 episodes/s).  A change of format rewrites the weight images (one repack, ~35 us) and drops the graphs;
+// evaluation passes take the format they find.
+int select_xcd_format(fsmg_model* h, int B) {
+    if (h->Hp != 1024 || !h->bx3 || h->xcd_bx3_forced || h->khx == nullptr || !(h->persist && h->xcd)) return FSMG_OK;
+    const bool want = lstm_xcd_bx3_pays(B, (int)h->Hp) && B <= h->xcd_max_rows;
+    if (want == h->xcd_bx3) return FSMG_OK;
+    h->xcd_bx3 = want;
+    drop_graphs(h);
+    return repack_recurrent_weights(h, h->stream);
+}
+
 void choose_schedule(fsmg_model* h, int B, bool train) {
     h->ov_call = h->overlap && (h->overlap_forced || !use_xcd(h, B));
     h->xov_call = false;

@@ -66,7 +66,7 @@ int ensure_scratch(fsmg_model* h, int B) {
     const int64_t o_inbox = place(want_inbox ? 4 * n_inbox : 256);
     // XCD-local kernels: sized for the largest row count they take (not for B, same reason)
     const int xrows = (h->persist && h->xcd && lstm_xcd_max_rows((int)Hp) > 0 && (Hp != 1024 || h->pair_mode >= 1)) ? std::min(h->xcd_max_rows, lstm_xcd_max_rows((int)Hp)) : 0;
-    const int64_t n_hx = xrows ? lstm_xcd_hx_floats(xrows, (int)T, (int)Hp, h->xcd_bx3) : 0;
+    const int64_t n_hx = xrows ? std::max(lstm_xcd_hx_floats(xrows, (int)T, (int)Hp, h->xcd_bx3), Hp == 1024 ? lstm_xcd_hx_floats(xrows, (int)T, (int)Hp, !h->xcd_bx3) : 0LL) : 0;
     const int64_t n_inx = (xrows && (Hp != 1024 || h->pair_mode >= 2)) ? lstm_xcd_inbox_floats(xrows, (int)Hp) : 0;
     const int64_t o_hx = place(xrows ? 4 * n_hx : 256), o_inx = place(n_inx ? 4 * n_inx : 256);
     const int64_t o_dc = place(4 * (int64_t)B * Hp), o_dh = place(4 * rows * Hp);

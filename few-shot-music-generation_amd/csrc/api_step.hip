@@ -26,6 +26,7 @@ int forward_backward_core(fsmg_model* h, int32_t N, int32_t K, int32_t Q, Stage&
         drop_graphs(h);
     }
     if ((rc = ensure_scratch(h, B)) != FSMG_OK) return rc;
+    if ((rc = select_xcd_format(h, B)) != FSMG_OK) return rc;
     choose_schedule(h, B, true);
     h->xov_last = h->xov_call;
     // an eager pass orders itself behind a pending update half inside forward(); a pass that is captured or replayed cannot hold

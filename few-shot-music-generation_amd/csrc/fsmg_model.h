@@ -123,7 +123,9 @@ struct fsmg_model {
                                         // (6.4 against 7.0 us per step; the backward pair kernel ties with the column-split one), 2 = both directions
     int xcd_variant = -1;               // FSMG_XCD_VARIANT: XCD_* bits for both directions (-1: lstm_xcd_default_variant)
     float* khx = nullptr;
-    bool xcd_bx3 = false;               // hidden 512: the XCD-local recurrence on the bf16 matrix pipe (k_lstm_*_xcd16); one format per handle
+    bool xcd_bx3 = false;               // the XCD-local recurrence on the bf16 matrix pipe (k_lstm_*_xcd16 at hidden 512, k_lstm_*_pair16 at hidden 1024); one format
+                                        // per handle at a time (weight images, hand-off buffer)
+    bool xcd_bx3_forced = false;        // FSMG_XCD_BX3 set: the format never follows the row count of the train passes (hidden 1024: select_xcd_format)
     float* HX = nullptr; int64_t hx_floats = 0;
     float* inboxX = nullptr; int64_t inboxx_floats = 0;
     int* d_inbox_dirty = nullptr;       // device word: != 0 -> the next BPTT pass refills the inboxes first (set at creation, when the scratch moves,
@@ -573,6 +575,7 @@ inline bool xov_fits(const GemmArgs& g) { return 4 + gemm_items(g) <= fsmg_model
 void choose_schedule(fsmg_model* h, int B, bool train = false);
 void xov_gate(fsmg_model* h, GemmArgs& g, int B);
 int gemm_prepare_queue(fsmg_model* h, GemmArgs& g, int split, OpBatch* defer, bool* ok);
+int select_xcd_format(fsmg_model* h, int B);
 int gemm_restricted(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int first, int* ctl);
 int gemm_cleanup(fsmg_model* h, hipStream_t s, int amode, int bmode, GemmArgs g, int* ctl);
 

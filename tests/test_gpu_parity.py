@@ -425,6 +425,31 @@ def test_inbox_refill_flag_survives_the_fallback_period():
         np.testing.assert_array_equal(a.get_param(k), v)
 
 
+def test_hidden_1024_recurrence_format_follows_the_train_passes(monkeypatch):
+    """One handle (created for 45 sequences, two layers of 1024), train passes of 45, 20, 25, 45 and 45 rows: the pair kernels' format follows
+    the row count -- bf16-split (k_lstm_*_pair16) from three row groups per weight copy on, fp32 row-group chains below (a MAML-style step
+    is created for 45 sequences and runs passes of 25 and 20) -- with the weight images rewritten at every change.  Losses and parameters
+    against a handle that stays on the fp32 pair kernels (FSMG_XCD_BX3=0): two arithmetics, both inside the parity bar."""
+    cfg = small_config(hidden_size=1024, embedding_size=32, input_size=500, max_len=16, n_layers=2)
+    shapes = [(5, 5, 4), (5, 2, 2), (5, 3, 2), (5, 5, 4), (5, 5, 4)]
+    eps = [O.synthetic_episodes(1, n, k, q, cfg['max_len'], cfg['input_size'], seed=40 + i)[0] for i, (n, k, q) in enumerate(shapes)]
+    a = new_model(cfg, max_sequences=45)
+    monkeypatch.setenv('FSMG_XCD_BX3', '0')
+    b = new_model(cfg, max_sequences=45)
+    monkeypatch.delenv('FSMG_XCD_BX3')
+    assert bool(a.debug_read('xcd_bx3', 1)[0]) and not bool(b.debug_read('xcd_bx3', 1)[0])
+    seen = []
+    for (n, k, q), ep in zip(shapes, eps):
+        la, lb = a.train_step(*ep), b.train_step(*ep)
+        assert abs(la - lb) <= NLL_RTOL * abs(lb), (n, k, q, la, lb)
+        seen.append(bool(a.debug_read('xcd_bx3', 1)[0]))
+        assert not bool(b.debug_read('xcd_bx3', 1)[0])
+    assert seen == [True, False, False, True, True]
+    for kname, v in b.get_params().items():
+        assert rel_max(a.get_param(kname), v) < 5e-4, kname
+    assert a.stats()['timeouts'] == 0
+
+
 @pytest.mark.parametrize('order', ['serial', 'partitioned'])
 def test_pair16_kernels_time_out_and_recover(order, monkeypatch):
     """Hidden 1024 on the bf16 matrix pipe (k_lstm_*_pair16, 45 rows, two stacked layers) under a forced time-out: the chain gives up at
