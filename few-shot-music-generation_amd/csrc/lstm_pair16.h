@@ -8,10 +8,12 @@
 // of gemm.hip and of k_lstm_*_xcd16) is 192 `v_mfma_f32_16x16x32_bf16` per wave = 3072 cycles for ANY row count up to 16.
 //
 // Where the weights live: K_h as three bf16 planes is 24 MiB per copy; an XCD pair has 32 MiB of registers.  Planes 0 and 1
-// (five of the six terms read them) sit in the accumulation half of the register file, 256 AGPRs per lane, all of it; plane 2
+// (five of the six terms read them) take 256 registers per lane -- loaded into the accumulation half; hipcc then spreads them over
+// that half and what the arch half has left (456-476 of 512 registers in all, nothing spilled: tools/check_xcd_asm.py); plane 2
 // (read by ONE term) sits in LDS, 128 KiB per CU, each wave reading only its own 32 KiB (one conflict-free ds_read_b128 per
-// operand, 32 per step and wave, hidden under the MFMAs).  The arch half holds the 24 hand-off fragments of a step (96 VGPRs),
-// the accumulators and the cell update.
+// operand, 32 per step and wave, hidden under the MFMAs; backward: read one tile group ahead).  The rest of the registers holds
+// the 24 hand-off fragments of a step (96), the accumulators and the cell update.
+// What a step costs and which of the variants (XCD_PROBE, XCD_STREAM, XCD_LOCAL_PLAIN, XCD_LATE_DRAIN) bought what: DESIGN.md 11.8.
 //
 //   forward : CU c of a pair (64 CUs) owns hidden units 16 c ... 16 c + 15 = packed gate columns 64 c ... (four 16-column
 //             tiles); wave w the K range 256 w ... (eight k steps of 32).  A operand = rows of h, as in k_lstm_fwd_xcd16.
