@@ -190,7 +190,7 @@ int backward(fsmg_model* h, int B, int part) {
             ScopedTimer tm(h, "lstm_bwd");
             if (xcd) {
                 LstmBwdXcdArgs a{};
-                a.rpx = packed ? rpx : 0; a.Hp = Hp; a.bx3 = h->xcd_bx3 ? 1 : 0; a.variant = h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, false, Hp, 0, h->xcd_bx3);
+                a.rpx = packed ? rpx : 0; a.Hp = Hp; a.bx3 = h->xcd_bx3 ? 1 : 0; a.variant = h->xcd_variant_bwd >= 0 ? h->xcd_variant_bwd : (h->xcd_variant >= 0 ? h->xcd_variant : lstm_xcd_default_variant(B, false, Hp, 0, h->xcd_bx3));
                 a.KhXb = h->khx + (size_t)(2 * l + 1) * lstm_xcd_weight_floats((int)Hp, h->xcd_bx3); a.inbox = h->inboxX; a.Z = h->Z[l]; a.Cs = h->Cs[l];
                 a.dc = h->dC; a.dH = h->dH; a.tickets = next_tickets(h); a.err_flag = h->d_err; a.B = B; a.T = T; a.t0 = t0; a.t1 = t1; a.spin_limit = h->chain_spin_limit;
                 HIPCK(h, launch_lstm_bwd_xcd(s, a));

@@ -198,6 +198,7 @@ int fsmg_create(const fsmg_config* cfg, fsmg_handle* out) {
         if (const char* e = std::getenv("FSMG_FWD_RT")) h->force_fwd_rt = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_CHAIN_SPIN_LIMIT")) h->chain_spin_limit = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("FSMG_XCD_VARIANT")) h->xcd_variant = std::atoi(e);      // XCD_* bits, both directions (tests: the non-default paths)
+        if (const char* e = std::getenv("FSMG_XCD_VARIANT_BWD")) h->xcd_variant_bwd = std::atoi(e);
 #ifdef FSMG_EXPERIMENTS         // settled A/Bs: tuning values and rejected alternatives, experiment builds only
         if (const char* e = std::getenv("FSMG_CE_TAIL")) h->ce_tail = (e[0] != '0');
         if (const char* e = std::getenv("FSMG_CE_TAIL_BLOCKS")) h->ce_tail_blocks = std::max(1, std::min(4096, std::atoi(e)));

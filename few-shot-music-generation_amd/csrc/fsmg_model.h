@@ -122,6 +122,7 @@ struct fsmg_model {
     int pair_mode = 2;                  // hidden size 1024 (one copy of K_h per XCD pair): 0 = column-split kernels, 1 = pair kernel forward only
                                         // (6.4 against 7.0 us per step; the backward pair kernel ties with the column-split one), 2 = both directions
     int xcd_variant = -1;               // FSMG_XCD_VARIANT: XCD_* bits for both directions (-1: lstm_xcd_default_variant)
+    int xcd_variant_bwd = -1;           // FSMG_XCD_VARIANT_BWD: the backward kernels' bits alone (-1: xcd_variant / the default)
     float* khx = nullptr;
     bool xcd_bx3 = false;               // the XCD-local recurrence on the bf16 matrix pipe (k_lstm_*_xcd16 at hidden 512, k_lstm_*_pair16 at hidden 1024); one format
                                         // per handle at a time (weight images, hand-off buffer)

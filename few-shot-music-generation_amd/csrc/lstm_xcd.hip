@@ -2202,9 +2202,11 @@ hipError_t launch_repack_kh_xcd(hipStream_t s, const float* Kh, float* fwd, floa
 // Variants chosen per shape (tools/xcd_chain_bench, profiles/r03_xcd_probe6*.log; B = 45: forward 2.21 -> 2.14 us per step with
 // the outputs deferred, backward 2.40 -> 2.34 without the sleep; B = 100: deferring costs 4 %, no sleep is neutral)
 int lstm_xcd_default_variant(int B, bool forward, int Hp, int rpx, bool bx3) {
-    // hidden 1024 on the bf16 pipe (lstm_pair16.h): forward probe + streamed fetch (6.35 -> 5.82 -> 5.65 us per step at B = 45), outputs
-    // deferred behind the fetch; backward same-XCD partials through the L2 and the reset wait behind the first tile group (6.65 -> 5.85)
-    if (Hp == PH && bx3) return forward ? (XCD_NO_POLL_SLEEP | XCD_PROBE | XCD_STREAM | XCD_DEFER_OUTPUTS) : (XCD_NO_POLL_SLEEP | XCD_LOCAL_PLAIN | XCD_LATE_DRAIN);
+    // hidden 1024 on the bf16 pipe (lstm_pair16.h): forward probe + streamed fetch (6.35 -> 5.82 -> 5.37 us per step at B = 45), outputs
+    // deferred behind the fetch; backward same-XCD partials through the L2 (6.65 -> 5.64).  NOT XCD_LATE_DRAIN: alone on the chip the
+    // reset wait behind the first tile group is neutral, in the step -- where the next update's gates / cell states / dH come out of HBM
+    // and the next poll queues behind them -- requesting them 800 ticks later costs 0.25 us per step (cfg-C 405 -> 409, same box)
+    if (Hp == PH && bx3) return forward ? (XCD_NO_POLL_SLEEP | XCD_PROBE | XCD_STREAM | XCD_DEFER_OUTPUTS) : (XCD_NO_POLL_SLEEP | XCD_LOCAL_PLAIN);
     // hidden 1024 (profiles/r03_pair_probe3..5.log, us per step without / with chains): backward 9.0 -> 7.2 (three row groups),
     // 6.75 -> 5.1 (two), 12.2 -> 9.4 (four); forward 4.65 -> 4.2 with two row groups, but 6.1 -> 6.35 / 7.4 -> 8.4 with three / four
     // (its early polls are ready 95 % of the time: the hand-off IS hidden, the per-phase instruction overhead is what is left).
