@@ -7,9 +7,8 @@ import json,sys
 d=json.loads(sys.stdin.read()); r=d.get('roofline',{}); print('$c $name', round(d['value'],1), round(d['ms_per_step'],4), 'fwd/bwd us', round(r.get('forward_us_per_time_step',0),2), round(r.get('backward_us_per_time_step',0),2))"
 }
 for rep in 1 2; do
-run f688 cfg-C FSMG_XCD_VARIANT=688 FSMG_XCD_VARIANT_BWD=288
-run f672 cfg-C FSMG_XCD_VARIANT=672 FSMG_XCD_VARIANT_BWD=288
-run f176 cfg-C FSMG_XCD_VARIANT=176 FSMG_XCD_VARIANT_BWD=288
-run f160 cfg-C FSMG_XCD_VARIANT=160 FSMG_XCD_VARIANT_BWD=288
-run f32 cfg-C FSMG_XCD_VARIANT=32 FSMG_XCD_VARIANT_BWD=288
+run default cfg-B FSMG_DUMMY=1
+run fdefer cfg-B FSMG_XCD_VARIANT=48 FSMG_XCD_VARIANT_BWD=2080
+run bdefer cfg-B FSMG_XCD_VARIANT=32 FSMG_XCD_VARIANT_BWD=2096
+run bsleep cfg-B FSMG_XCD_VARIANT=32 FSMG_XCD_VARIANT_BWD=2048
 done
