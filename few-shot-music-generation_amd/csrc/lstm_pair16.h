@@ -22,8 +22,8 @@
 //   backward: dz slice (rows x the CU's 64 gate columns, two k steps) split by the cell threads into LDS; wave w holds K_h^T
 //             for destination units 256 w ... (sixteen 16-unit tiles = sixteen destination CUs); the D registers of tile nt
 //             are the inbox words (dest 16 w + nt, row group l / 16, producer, unit l % 16) of k_lstm_bwd_pair's inbox.
-// The K-split partials of a step meet in ONE LDS buffer (no step parity): a wave can only overwrite it after its poll of the
-// next step has succeeded, which needs the hand-off stores of this CU's own cell waves, which they issue after reading it.
+// The K-split partials of a step meet in LDS: two buffers by step parity up to three row groups, one buffer and a second barrier at four
+// (two do not fit beside plane 2 there).
 constexpr int P16KS = PKW / 32;                 // k steps of a wave's K range (forward)
 constexpr int P16NF = 3 * P16KS;                // hand-off fragments per lane and step
 constexpr int P16W = 3 * P16KS * 4;             // 16-byte weight words per lane (image), either direction
@@ -50,7 +50,8 @@ template <int RG, bool PROF>
 __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair16(const LstmFwdXcdArgs a) {
     constexpr int HXR = 4 * RG;                  // rows per pair the hand-off buffer is laid out for
     __shared__ __attribute__((aligned(16))) f32x4 w2[4][P16KS * 4][64];          // plane 2 of the weights: [wave][k step, column tile][lane]
-    __shared__ __attribute__((aligned(16))) float red[4][HXR * 16 * 4];          // [wave][row][unit][gate]
+    constexpr bool DB = RG <= 3;                 // the K-split partials in two buffers by step parity where they fit beside plane 2 (24 KiB), else one + a barrier
+    __shared__ __attribute__((aligned(16))) float red[DB ? 2 : 1][4][HXR * 16 * 4];          // [step parity][wave][row][unit][gate]
     __shared__ int s_role[2];
     __shared__ int s_fail;
     __builtin_amdgcn_s_setprio(3);
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair16(const LstmFwdXcdArgs
             plast = __builtin_amdgcn_s_memtime();
         }
         if (akg < rgc) {                           // D: lane = (column 4 g + e of the tile, rows 4 akg ... + 3)
-            float* rp = &red[wave][0] + ((4 * akg) * 16 + (lane & 3)) * 4 + ((lane >> 2) & 3);
+            float* rp = &red[DB ? (t & 1) : 0][wave][0] + ((4 * akg) * 16 + (lane & 3)) * 4 + ((lane >> 2) & 3);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -251,11 +252,20 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair16(const LstmFwdXcdArgs
             __hip_atomic_fetch_add(a.progress + (t - lag), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         P16_STAMP(2)
 
+        // The K-split partials are read HERE, by every cell thread.  Up to three row groups they sit in two buffers by step parity (as in
+        // k_lstm_fwd_xcd16: a wave that is one step ahead writes the other one, and nobody can be two ahead -- the step's barrier needs
+        // every wave).  Four row groups leave room for one buffer beside plane 2, and a second barrier hands it back: a wave's poll covers
+        // the producers of ITS K range only, so "behind my next poll" would not mean "this CU's cell waves have read their partials" (in
+        // practice they read them a microsecond before anybody can have new ones; the barrier makes it a guarantee for ~200 clocks a step).
+        f32x4 r0 = f32x4{0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0;
+        if (act) {
+            const f32x4* rsrc = reinterpret_cast<const f32x4*>(&red[DB ? (t & 1) : 0][0][0]) + lrow * 16 + 4 * cbb + ce;
+            r0 = rsrc[0]; r1 = rsrc[HXR * 16]; r2 = rsrc[2 * HXR * 16]; r3 = rsrc[3 * HXR * 16];
+        }
+        if (!DB) __syncthreads();
         if (cellw) {
             float hn = 0.0f, g_si = 0.f, g_tj = 0.f, g_sf = 0.f, g_so = 0.f;
             if (act) {
-                const f32x4* rsrc = reinterpret_cast<const f32x4*>(&red[0][0]) + lrow * 16 + 4 * cbb + ce;
-                const f32x4 r0 = rsrc[0], r1 = rsrc[HXR * 16], r2 = rsrc[2 * HXR * 16], r3 = rsrc[3 * HXR * 16];
                 float zg[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
