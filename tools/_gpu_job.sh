@@ -1,17 +1,14 @@
 #!/bin/bash
 # scratch runner for one gpurun call (edit, then: gpurun -- 'bash tools/_gpu_job.sh'); what it leaves under gpurun_out/ comes back
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
-export FSMG_LIB=$R/few-shot-music-generation_amd/lib/libfsmg_exp.so
 run() { local name=$1; local c=$2; shift; shift
   env "$@" timeout 300 python bench.py --config $c --no-cpu-baseline --no-other-configs --no-extras 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); r=d.get('roofline',{}); print('$c $name', round(d['value'],1), round(d['ms_per_step'],4), 'fwd/bwd us', round(r.get('forward_us_per_time_step',0),2), round(r.get('backward_us_per_time_step',0),2))"
+d=json.loads(sys.stdin.read()); print('$c $name', round(d['value'],1), round(d['ms_per_step'],4), d['final_loss'])"
 }
 for rep in 1 2; do
-run split4 cfg-B FSMG_XOV_DW_SPLIT=4
-run split3 cfg-B FSMG_XOV_DW_SPLIT=3
-run split5 cfg-B FSMG_XOV_DW_SPLIT=5
-run split6 cfg-B FSMG_XOV_DW_SPLIT=6
-run pub4 cfg-B FSMG_XOV_PUB=4
-run pub8 cfg-B FSMG_XOV_PUB=8
-done
+for c in cfg-C cfg-E cfg-B; do
+run prev $c FSMG_LIB=$R/few-shot-music-generation_amd/lib/libfsmg_prev.so
+run new $c FSMG_DUMMY=1
+done; done
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gemm_variants.py -q -m gpu -x -k "bit or ident or full_size or trajectory" 2>&1 | tail -3
