@@ -202,6 +202,7 @@ enum { XCD_DEFER_OUTPUTS = 16,      // forward: c / h / gate stores of step t ar
        XCD_LOCAL_PLAIN = 256,       // k_lstm_bwd_pair16: partials / resets between CUs of the SAME XCD stay in its L2 (plain stores)
        XCD_LATE_DRAIN = 1024,       // k_lstm_bwd_pair16: the wait for the inbox resets stands in front of the first partial store, not the MFMAs
        XCD_GROUP_STORES = 2048,     // k_lstm_bwd_xcd16: the partials of four destination tiles leave while the other four multiply
+       XCD_PROBE_DELAY = 8192,      // k_lstm_fwd_pair16: x (1 ... 7) = that many times 512 clocks of sleep in front of the first probe of a wave without cell threads
        XCD_STREAM = 512 };          // k_lstm_fwd_pair16 (with XCD_PROBE): behind a successful probe the fragments are ordinary (compiler-counted) loads
                                     // consumed k step by k step under the MFMAs, checked afterwards; a miss redoes the step behind the sc1 poll
 int lstm_xcd_default_variant(int B, bool forward, int Hp = 512, int rpx = 0, bool bx3 = false);

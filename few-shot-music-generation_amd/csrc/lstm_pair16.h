@@ -128,6 +128,12 @@ __global__ __launch_bounds__(256, 1) void k_lstm_fwd_pair16(const LstmFwdXcdArgs
         // fill the CU's memory pipeline in front of the cell waves' stores).  Whatever the probe says, the fragments themselves decide.
         bool stream = false;
         if (a.variant & XCD_PROBE) {
+            // A wave without cell threads reaches its probe a whole cell update before anybody can have stored anything, and its probe rounds
+            // (4 per step) stood in the way of the cell waves' stores and off the grid on which the data arrives: it sleeps first, XCD_PROBE_DELAY
+            // x 512 clocks (bits 13-15 of the variant; 2048 clocks: 5.46 -> 5.00 us per step at B = 45, profiles/r06_pair16_probe6_delay.log).
+            // (The same in front of the backward kernel's first inbox poll: 5.60 -> 5.62 ... 6.10; 256 ... 1024 clocks for the cell waves too:
+            // 4.98 -> 4.97 / 5.05 / 5.14 / 5.15: not taken.)
+            if (!cellw && t > a.t0) { for (int q = (a.variant / XCD_PROBE_DELAY) & 7; q > 0; --q) __builtin_amdgcn_s_sleep(8); }
             const f32x4* sp = af + (2 * P16KS + 2 * (arow & 3) + (akg & 1)) * (HXR * 4);
             for (int spins = 0; spins < a.spin_limit; ++spins) {
                 f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -2206,7 +2206,7 @@ int lstm_xcd_default_variant(int B, bool forward, int Hp, int rpx, bool bx3) {
     // deferred behind the fetch; backward same-XCD partials through the L2 (6.65 -> 5.64).  NOT XCD_LATE_DRAIN: alone on the chip the
     // reset wait behind the first tile group is neutral, in the step -- where the next update's gates / cell states / dH come out of HBM
     // and the next poll queues behind them -- requesting them 800 ticks later costs 0.25 us per step (cfg-C 405 -> 409, same box)
-    if (Hp == PH && bx3) return forward ? (XCD_NO_POLL_SLEEP | XCD_PROBE | XCD_STREAM | XCD_DEFER_OUTPUTS) : (XCD_NO_POLL_SLEEP | XCD_LOCAL_PLAIN);
+    if (Hp == PH && bx3) return forward ? (XCD_NO_POLL_SLEEP | XCD_PROBE | XCD_STREAM | XCD_DEFER_OUTPUTS | 4 * XCD_PROBE_DELAY) : (XCD_NO_POLL_SLEEP | XCD_LOCAL_PLAIN);
     // hidden 1024 (profiles/r03_pair_probe3..5.log, us per step without / with chains): backward 9.0 -> 7.2 (three row groups),
     // 6.75 -> 5.1 (two), 12.2 -> 9.4 (four); forward 4.65 -> 4.2 with two row groups, but 6.1 -> 6.35 / 7.4 -> 8.4 with three / four
     // (its early polls are ready 95 % of the time: the hand-off IS hidden, the per-phase instruction overhead is what is left).
