@@ -444,7 +444,7 @@ static int run_case(int B, int Tcheck, int Ttime, int H) {
             hipFree(A); hipFree(Bm); hipFree(slabs); hipFree(ctl);
         }
         {                    // variants (same results): 16 = XCD_DEFER_OUTPUTS, 32 = XCD_NO_POLL_SLEEP
-            for (int dbg : {688, 33456, 288}) {
+            for (int dbg : {32, 160, 672, 688, 33456, 288, 1312, 2080}) {
                 if ((dbg & (64 | 256 | 1024)) && H != 1024) continue;
                 if ((dbg & (128 | 512 | 2048)) && H == 512 && !g_bx3) continue;          // (the bf16-split kernels' variants)          // XCD_CHAINS: hidden 1024 only
                 float best_f = 1e9f, best_b = 1e9f;
